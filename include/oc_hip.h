@@ -1,0 +1,149 @@
+/* oc_hip.h -- C-ABI of liboc_hip.so: the MI355X (gfx950) implementation of the optimal_crowds hot path.
+ *
+ * The reference (matteobutano/optimal_crowds) has no FFI: the path sits behind Python methods.  Each entry
+ * point below names the reference interface it replaces (file:line into the reference tree).  The host side
+ * (the Python modules of optimal_crowds_amd/) binds these with ctypes; INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative oc_status otherwise; oc_last_error() gives the text.
+ *   - all array arguments are DEVICE pointers owned by the caller (e.g. torch tensors' data_ptr()), valid until
+ *     the stream has drained; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - calls are asynchronous on `stream` unless the documentation says the function returns host values.
+ *   - one handle per device and per simulation; a handle is not thread-safe.
+ *   - grids are row-major (Ny, Nx): cell (i, j) = row i (y index), column j (x index), as in the reference.
+ *   - `dtype` selects the arithmetic of the HJB state and direction field: OC_F32 (product) or OC_F64 (audit).
+ */
+#ifndef OC_HIP_H
+#define OC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OC_ABI_VERSION 1
+
+typedef enum { OC_OK = 0, OC_ERR_ARG = -1, OC_ERR_HIP = -2, OC_ERR_STATE = -3, OC_ERR_SOLVER = -4 } oc_status;
+typedef enum { OC_F32 = 0, OC_F64 = 1 } oc_dtype;
+
+typedef struct oc_handle oc_handle;
+
+/* Scalars of config.json + the room extent (reference simulations.py:54-97, optimals.py:48-74). */
+typedef struct oc_config {
+    int32_t Ny, Nx;               /* int(H//grid_step+1), int(L//grid_step+1)      simulations.py:63-64 */
+    double dx, dy;                /* = grid_step                                   simulations.py:66-67 */
+    double room_length, room_height;
+    double dt;                    /* config "dt" */
+    /* HJB (config "hjb_params") */
+    double sigma, mu, g;
+    double lim;                   /* 10e-3, optimals.py:95 */
+    double rtol, atol;            /* SciPy RK45 defaults 1e-3 / 1e-6 (scipy rk.py:85-86) */
+    /* GCFM */
+    double a_min;                 /* = config b_min (quirk: simulations.py:88, pedestrians.py:74) */
+    double tau_a, b_min, b_max, eta, eta_walls;
+    double repulsion_cutoff, v_max, relaxation;
+    double noise_amp;             /* hjb sigma / 2, simulations.py:303 */
+    double wall_search_radius;    /* <=0: unbounded exact search; else rows beyond this distance are skipped */
+    int32_t max_agents;           /* capacity for scratch */
+    int32_t max_keys;             /* number of distinct target keys */
+} oc_config;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------- */
+int oc_abi_version(void);
+const char* oc_last_error(void);
+/* X0 (Nx) and Y0 (Ny): HOST float64 axes = np.linspace(0, L, Nx) / (0, H, Ny) (simulations.py:69-70). */
+int oc_create(int device, const oc_config* cfg, const double* X0_host, const double* Y0_host, oc_handle** out);
+int oc_destroy(oc_handle* h);
+
+/* ---- HJB: reference optimals.py:124-206 ------------------------------------------------------------------ */
+/* coef = V + g*m on free cells, NaN on walls (V < 0)  -- the (V + g*m) term and the wall mask of
+ * optimals.py:159-162.  V: float32 (Ny,Nx) finalised potential {-100,0,1}; m: dtype (Ny,Nx) or NULL (= 0). */
+int oc_hjb_make_coef(oc_handle* h, int dtype, const float* V, const void* m, void* coef, void* stream);
+
+/* out = hjb(t, phi, m): replaces the closure `hjb` at optimals.py:144-164.  phi/out: dtype (Ny*Nx). */
+int oc_hjb_rhs(oc_handle* h, int dtype, const void* phi, const void* coef, void* out, void* stream);
+
+typedef struct oc_hjb_stats {
+    int32_t nfev, n_attempt, n_accept, n_rescale;
+    double h_abs0, h_min, h_max;
+    int32_t final_exponent;       /* state carried as phi * 2^-exponent (fp32 range management) */
+    int32_t n_slices_written;
+    double seconds;               /* host wall time of the call (synchronous) */
+} oc_hjb_stats;
+
+/* Replaces compute_optimal_velocity's solve_ivp(RK45, t_eval=linspace(T,0,nt)) + vels() fill loop,
+ * optimals.py:193-204 (+ SciPy RK45 rk.py:14-180, 552-575; common.py:63-134; ivp.py:598-723).
+ *   nt        = round((T - t_now)/dt)   (optimals.py:139-142); slices s = 0..nt-2 of vx_out/vy_out are written:
+ *               vx_out[s] = direction field of phi(t = s*T/(nt-1)), layout (nslice, Ny-2, Nx-2) of `dtype`.
+ *   keep_idx  : optional HOST list of n_keep t_eval indices k whose phi(t_eval[k]) is stored unscaled as
+ *               float64 (n_keep, Ny, Nx) in phi_keep (device) -- audit/tests only.
+ *   t_steps   : optional HOST buffer (cap t_steps_cap) receiving accepted step end times.
+ * Synchronous: returns after the solve has drained; stats are host values. */
+int oc_hjb_solve(oc_handle* h, int dtype, const void* coef, double T, int32_t nt,
+                 void* vx_out, void* vy_out,
+                 const int32_t* keep_idx, int32_t n_keep, double* phi_keep,
+                 double* t_steps, int32_t t_steps_cap,
+                 oc_hjb_stats* stats, void* stream);
+
+/* Direction field of one phi (float64 input, dtype output (Ny-2, Nx-2)): replaces `vels`, optimals.py:168-186. */
+int oc_hjb_vels(oc_handle* h, int dtype, const void* phi, double scale, void* vx, void* vy, void* stream);
+
+/* ---- per-key data used by the agent step ------------------------------------------------------------------ */
+/* Register the direction field of key `key`: arrays as written by oc_hjb_solve; nt_opt = current horizon
+ * (optimals.nt_opt), nslice_alloc = allocated slices (nt0-1).  Replaces attribute access optimals.vx_opt. */
+int oc_set_field(oc_handle* h, int key, int dtype, const void* vx, const void* vy, int32_t nslice_alloc, int32_t nt_opt);
+/* Exit rectangles (cx,cy,w,h) of a key's possible targets: pedestrians.py:132-136. rects: HOST (n,4) float64. */
+int oc_set_key_targets(oc_handle* h, int key, const double* rects, int32_t n);
+/* Nearest-"wall"-cell structure of Vs[key] for pedestrians.py:311-315.  V: float32 device (Ny,Nx);
+ * vmin = min(V) (host value): cells with V == vmin are the candidate set of the reference's argmin. */
+int oc_wallmap_build(oc_handle* h, int key, const float* V, float vmin, void* stream);
+
+/* ---- GCFM agent update: reference simulations.py:252-342, pedestrians.py:216-334 ----------------------------- */
+/* Agent state (SoA, device, length N): x,y,vx,vy,v_des float64; status uint8 (1 = inside); key int32;
+ * agent_time float64 (ped.time). */
+typedef struct oc_agents {
+    int32_t N;
+    double *x, *y, *vx, *vy;
+    const double* v_des;
+    uint8_t* status;
+    const int32_t* key;
+    double* agent_time;
+} oc_agents;
+
+/* floor-field lookup for every agent: des = v_des * choose_optimal_velocity(pos, step)  (optimals.py:212-250,
+ * simulations.py:281).  des: float64 (N,2).  err_flag (device int32[2], may be NULL): [0] set to 1 + agent index
+ * if an agent is in the reference's IndexError band (quirk Q8). */
+int oc_field_lookup(oc_handle* h, const oc_agents* a, int32_t simu_step, double* des, int32_t* err_flag, void* stream);
+/* index of the reference's argmin (flat row-major, int64 (N)) and wall force float64 (N,2): pedestrians.py:282-334 */
+int oc_wall_force(oc_handle* h, const oc_agents* a, int64_t* index_out, double* force_out, void* stream);
+/* sum of agents_repulsion over active j != i within the cutoff: float64 (N,2).  simulations.py:285-295 */
+int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out, void* stream);
+
+/* One synchronous (frozen-snapshot) step of every active agent, in place: simulations.py:277-332.
+ *   noise : float64 (N,2) standard normals (noise[i] = agent i's draw) or NULL -> device Philox(seed, step).
+ *   counters (device int32[4], zeroed by the call): [0] number of agents that exited this step,
+ *            [1] 1+index of an agent in the IndexError band (0 = none), [2] active agents after the step.
+ * Rebuilds the spatial order every `resort_every` steps (0 = library default). */
+int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise, uint64_t seed,
+                 int32_t* counters, void* stream);
+int oc_set_resort_every(oc_handle* h, int32_t steps);
+
+/* d = sum over active agents of exp(-r^2/(2 sigma^2)) / (2 pi sigma), zero where V_all < 0:
+ * simulations.py:453-487.  out: dtype (Ny,Nx); V_all float32 (Ny,Nx) (simulation.V) or NULL.
+ * trunc_sigmas: contributions beyond this many sigmas are dropped (<= 0: 6.0). */
+int oc_density(oc_handle* h, int dtype, const oc_agents* a, double sigma, const float* V_all, double trunc_sigmas,
+               void* out, void* stream);
+
+/* ---- introspection for bench.py / tests --------------------------------------------------------------------- */
+/* HIP-event time (ms) of the most recent launch of the named kernel class on its stream:
+ * "hjb_step", "hjb_out", "gcfm_pair", "gcfm_wall"; returns <0 if never launched. */
+double oc_last_kernel_ms(oc_handle* h, const char* name);
+int oc_set_profiling(oc_handle* h, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

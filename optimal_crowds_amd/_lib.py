@@ -1,0 +1,119 @@
+"""ctypes binding of liboc_hip.so (C-ABI: include/oc_hip.h).
+
+There is no CPU fallback: if the shared library is missing, cannot be loaded, or no MI355X is
+present, the first use raises.  `build()` compiles the library in-tree with hipcc for gfx950.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboc_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+OC_F32, OC_F64 = 0, 1
+
+
+class OcConfig(C.Structure):
+    _fields_ = [
+        ("Ny", C.c_int32), ("Nx", C.c_int32),
+        ("dx", C.c_double), ("dy", C.c_double),
+        ("room_length", C.c_double), ("room_height", C.c_double),
+        ("dt", C.c_double),
+        ("sigma", C.c_double), ("mu", C.c_double), ("g", C.c_double),
+        ("lim", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
+        ("a_min", C.c_double), ("tau_a", C.c_double), ("b_min", C.c_double), ("b_max", C.c_double),
+        ("eta", C.c_double), ("eta_walls", C.c_double),
+        ("repulsion_cutoff", C.c_double), ("v_max", C.c_double), ("relaxation", C.c_double),
+        ("noise_amp", C.c_double), ("wall_search_radius", C.c_double),
+        ("max_agents", C.c_int32), ("max_keys", C.c_int32),
+    ]
+
+
+class OcHjbStats(C.Structure):
+    _fields_ = [
+        ("nfev", C.c_int32), ("n_attempt", C.c_int32), ("n_accept", C.c_int32), ("n_rescale", C.c_int32),
+        ("h_abs0", C.c_double), ("h_min", C.c_double), ("h_max", C.c_double),
+        ("final_exponent", C.c_int32), ("n_slices_written", C.c_int32),
+        ("seconds", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class OcAgents(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32),
+        ("x", C.c_void_p), ("y", C.c_void_p), ("vx", C.c_void_p), ("vy", C.c_void_p),
+        ("v_des", C.c_void_p), ("status", C.c_void_p), ("key", C.c_void_p), ("agent_time", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/oc_hip.h declares
+SIGNATURES = {
+    "oc_abi_version": (C.c_int, []),
+    "oc_last_error": (C.c_char_p, []),
+    "oc_create": (C.c_int, [C.c_int, C.POINTER(OcConfig), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "oc_destroy": (C.c_int, [C.c_void_p]),
+    "oc_hjb_make_coef": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "oc_hjb_rhs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "oc_hjb_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                               C.POINTER(OcHjbStats), C.c_void_p]),
+    "oc_hjb_vels": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "oc_set_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "oc_set_key_targets": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]),
+    "oc_wallmap_build": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
+    "oc_field_lookup": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "oc_wall_force": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "oc_pair_force": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_void_p, C.c_void_p]),
+    "oc_gcfm_step": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p,
+                               C.c_void_p]),
+    "oc_set_resort_every": (C.c_int, [C.c_void_p, C.c_int32]),
+    "oc_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(OcAgents), C.c_double, C.c_void_p, C.c_double,
+                             C.c_void_p, C.c_void_p]),
+    "oc_last_kernel_ms": (C.c_double, [C.c_void_p, C.c_char_p]),
+    "oc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+_lib = None
+
+
+class OcError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile liboc_hip.so in-tree (hipcc --offload-arch=gfx950).  Works without a GPU."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+        print(r.stderr)
+    if r.returncode != 0:
+        raise OcError("building liboc_hip.so failed:\n" + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library and declare every entry point; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OcError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.oc_abi_version() != 1:
+        raise OcError("liboc_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise OcError("liboc_hip: error %d: %s" % (rc, load().oc_last_error().decode(errors="replace")))

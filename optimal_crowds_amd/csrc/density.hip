@@ -1,0 +1,161 @@
+// Gaussian crowd density on the room grid: replaces simulation.gaussian_density, reference simulations.py:453-487.
+//   d[i,j] = sum_{active a} exp(-((X_j-x_a)^2 + (Y_i-y_a)^2) / (2 sigma^2)) / (2 pi sigma);   d[V_all < 0] = 0
+// Agents are ordered by coarse cells of side R = trunc_sigmas*sigma; an output tile only visits the agents of the
+// coarse cells that intersect tile +- R (row-major keys make each coarse row one contiguous slot range).  Everything
+// inside those cells is summed exactly (no radial test), what is dropped is < exp(-trunc^2/2) relative.
+#include "oc_internal.h"
+#include <cmath>
+
+namespace {
+
+struct DensParams {
+    int32_t Ny, Nx;
+    double cell;
+    int32_t ncx, ncy;
+    double inv2s2, invC;
+};
+
+__global__ void k_dens_keys(const double* __restrict__ x, const double* __restrict__ y,
+                            const uint8_t* __restrict__ status, int N, DensParams P, uint32_t* __restrict__ keys,
+                            int32_t* __restrict__ vals) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    uint32_t key = 0x3FFFFFFFu;
+    if (status[i]) {
+        double fx = floor(x[i] / P.cell), fy = floor(y[i] / P.cell);
+        int cx = fx < 0 ? 0 : (fx > P.ncx - 1 ? P.ncx - 1 : (int)fx);
+        int cy = fy < 0 ? 0 : (fy > P.ncy - 1 ? P.ncy - 1 : (int)fy);
+        key = (uint32_t)(cy * P.ncx + cx);
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+
+__global__ void k_dens_gather(const double* __restrict__ x, const double* __restrict__ y,
+                              const int32_t* __restrict__ order, int N, double2* __restrict__ spos) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    int i = order[k];
+    spos[k] = make_double2(x[i], y[i]);
+}
+
+// cell_start[c] = first slot with key >= c   (c = 0..ncell)
+__global__ void k_dens_cellstart(const uint32_t* __restrict__ keys_sorted, int N, int ncell, int32_t* __restrict__ cs) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > ncell) return;
+    int lo = 0, hi = N;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (keys_sorted[mid] < (uint32_t)c) lo = mid + 1;
+        else hi = mid;
+    }
+    cs[c] = lo;
+}
+
+// block = 16 x 16 output cells
+template <typename T>
+__global__ void __launch_bounds__(256) k_density(DensParams P, const double2* __restrict__ spos,
+                                                 const int32_t* __restrict__ cs, const double* __restrict__ X0,
+                                                 const double* __restrict__ Y0, const float* __restrict__ Vall,
+                                                 T* __restrict__ out) {
+    __shared__ double2 l_p[256];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + tx, i = blockIdx.y * 16 + ty;
+    const int j0 = blockIdx.x * 16, i0 = blockIdx.y * 16;
+    const int j1 = min(j0 + 15, P.Nx - 1), i1 = min(i0 + 15, P.Ny - 1);
+    const bool valid = (i < P.Ny && j < P.Nx);
+    const double X = valid ? X0[j] : 0.0, Y = valid ? Y0[i] : 0.0;
+    // coarse cells intersecting tile +- cell
+    auto cc = [&](double v, int n) {
+        double f = floor(v / P.cell);
+        return f < 0 ? 0 : (f > n - 1 ? n - 1 : (int)f);
+    };
+    const int cx0 = cc(X0[j0] - P.cell, P.ncx), cx1 = cc(X0[j1] + P.cell, P.ncx);
+    const int cy0 = cc(Y0[i0] - P.cell, P.ncy), cy1 = cc(Y0[i1] + P.cell, P.ncy);
+    double acc = 0.0;
+    for (int cy = cy0; cy <= cy1; ++cy) {
+        const int s0 = cs[cy * P.ncx + cx0], s1 = cs[cy * P.ncx + cx1 + 1];
+        for (int base = s0; base < s1; base += 256) {
+            __syncthreads();
+            int k = base + threadIdx.x;
+            if (k < s1) l_p[threadIdx.x] = spos[k];
+            __syncthreads();
+            int cnt = min(256, s1 - base);
+            if (valid) {
+                for (int q = 0; q < cnt; ++q) {
+                    double2 p = l_p[q];
+                    double ddx = X - p.x, ddy = Y - p.y;
+                    acc += exp(-(ddx * ddx + ddy * ddy) * P.inv2s2) * P.invC;
+                }
+            }
+        }
+    }
+    if (valid) {
+        size_t o = (size_t)i * P.Nx + j;
+        if (Vall && Vall[o] < 0.f) acc = 0.0;
+        out[o] = (T)acc;
+    }
+}
+
+}   // namespace
+
+extern "C" int oc_density(oc_handle* h, int dtype, const oc_agents* a, double sigma, const float* V_all,
+                          double trunc_sigmas, void* out, void* stream) {
+    OC_REQUIRE(h && a && out, "null argument");
+    OC_REQUIRE(a->N >= 0 && a->N <= h->cfg.max_agents, "agent count exceeds max_agents");
+    OC_REQUIRE(sigma > 0, "sigma must be positive");
+    OC_REQUIRE(dtype == OC_F32 || dtype == OC_F64, "bad dtype");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const oc_config& c = h->cfg;
+    if (trunc_sigmas <= 0) trunc_sigmas = 6.0;
+    DensParams P;
+    P.Ny = c.Ny;
+    P.Nx = c.Nx;
+    P.cell = trunc_sigmas * sigma;
+    P.ncx = (int)(c.room_length / P.cell) + 1;
+    P.ncy = (int)(c.room_height / P.cell) + 1;
+    P.inv2s2 = 1.0 / (2 * sigma * sigma);
+    P.invC = 1.0 / std::sqrt(4 * M_PI * M_PI * sigma * sigma);
+    const int N = a->N, ncell = P.ncx * P.ncy;
+    OC_REQUIRE((int64_t)P.ncx * P.ncy < 0x3FFFFFFF, "too many coarse cells");
+    // scratch: keys/vals x2, sorted positions, cell starts
+    size_t need = (size_t)N * (2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + sizeof(double2)) +
+                  sizeof(int32_t) * (size_t)(ncell + 2) + 4096;
+    static thread_local void* buf = nullptr;
+    static thread_local size_t buf_bytes = 0;
+    if (need > buf_bytes) {
+        if (buf) OC_HIP_CHECK(hipFree(buf));
+        buf = nullptr;
+        OC_HIP_CHECK(hipMalloc(&buf, need));
+        buf_bytes = need;
+    }
+    char* p = (char*)buf;
+    auto take = [&](size_t bytes) {
+        char* q = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return (void*)q;
+    };
+    double2* spos = (double2*)take(sizeof(double2) * (size_t)N);
+    uint32_t* ka = (uint32_t*)take(sizeof(uint32_t) * (size_t)N);
+    uint32_t* kb = (uint32_t*)take(sizeof(uint32_t) * (size_t)N);
+    int32_t* va = (int32_t*)take(sizeof(int32_t) * (size_t)N);
+    int32_t* vb = (int32_t*)take(sizeof(int32_t) * (size_t)N);
+    int32_t* cs = (int32_t*)take(sizeof(int32_t) * (size_t)(ncell + 2));
+    int nact_slots = 0;
+    if (N > 0) {
+        hipLaunchKernelGGL(k_dens_keys, dim3((N + 255) / 256), dim3(256), 0, s, a->x, a->y, a->status, N, P, ka, va);
+        int rc = oc_sort_pairs(h, ka, kb, va, vb, N, 30, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_dens_gather, dim3((N + 255) / 256), dim3(256), 0, s, a->x, a->y, vb, N, spos);
+        nact_slots = N;
+    }
+    hipLaunchKernelGGL(k_dens_cellstart, dim3((ncell + 1 + 255) / 256), dim3(256), 0, s, kb, nact_slots, ncell, cs);
+    dim3 g((c.Nx + 15) / 16, (c.Ny + 15) / 16);
+    if (dtype == OC_F32)
+        hipLaunchKernelGGL(k_density<float>, g, dim3(256), 0, s, P, spos, cs, h->X0, h->Y0, V_all, (float*)out);
+    else
+        hipLaunchKernelGGL(k_density<double>, g, dim3(256), 0, s, P, spos, cs, h->X0, h->Y0, V_all, (double*)out);
+    OC_HIP_CHECK(hipGetLastError());
+    return OC_OK;
+}

@@ -1,0 +1,737 @@
+// GCFM agent update (Generalized Centrifugal Force Model), synchronous (frozen-snapshot) form.
+// Replaces reference simulations.py:252-342 (step driver), pedestrians.py:216-280 (agents_repulsion),
+// pedestrians.py:282-334 (wall_repulsion), optimals.py:212-250 (choose_optimal_velocity).
+//
+// Layout: caller-owned SoA state in agent order (float64 x,y,vx,vy,v_des; uint8 status; int32 key).
+// Each step the state is gathered through `order` (agents sorted by 4 m coarse cell) into a packed snapshot
+// in SLOT order (tiles of 64 slots = one wavefront):
+//   ppos  double2 (x,y)            pvel  float4 (vx,vy,|v|,1/a^2)     phead float2 (unit heading, (1,0) if v=0)
+//   tile_box double4 (minx,miny,maxx,maxy) of the active agents of a tile
+// Pair forces: one wavefront per i-tile; j-tiles whose box is farther than the cutoff are skipped (ballot over
+// 64 tile tests), surviving j-tiles are staged in LDS and broadcast-read.  The distance/cutoff test is float64
+// on absolute positions (same decision as the reference's sqrt(dx^2+dy^2) < cutoff), the force arithmetic is
+// float32 on the float64-differenced relative vector, the per-agent sum is float64.
+// Per-agent work (lookup, wall search + force, integration, exit test) is float64.
+#include "oc_internal.h"
+#include <cmath>
+
+namespace {
+
+struct KeyDev {
+    const void* vx;
+    const void* vy;
+    const int32_t* left;
+    const int32_t* right;
+    double off;
+    int32_t dtype, nslice_alloc, nt_opt, nrect;
+    double rect[OC_MAX_TARGET_RECTS][4];
+};
+
+struct GcfmParams {
+    int32_t Ny, Nx;
+    double dx, dy, L, H, dt;
+    double a_min, tau_a, b_min, b_max, eta, eta_walls, cutoff, v_max, relaxation, noise_amp;
+    double wall_radius;
+    double cell;        // coarse cell size for ordering
+    int32_t ncx, ncy;
+};
+
+struct Scratch {
+    uint32_t *keys_a, *keys_b;
+    int32_t *vals_a, *vals_b;
+    double2* ppos;
+    float4* pvel;
+    float2* phead;
+    int32_t* pidx;
+    double4* tile_box;
+    double2 *f_pair, *f_wall, *des;
+    long long* widx;
+    int32_t* counters;
+    int32_t Np, ntiles;
+};
+
+__device__ __forceinline__ double wmin(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wmax(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------- ordering
+__global__ void k_cell_keys(const double* __restrict__ x, const double* __restrict__ y,
+                            const uint8_t* __restrict__ status, int N, GcfmParams P, uint32_t* __restrict__ keys,
+                            int32_t* __restrict__ vals) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    uint32_t key = 0x3FFFFFFFu;                     // inactive agents sort to the end
+    if (status[i]) {
+        double fx = x[i] / P.cell, fy = y[i] / P.cell;
+        int cx = (fx > 0) ? (fx < P.ncx - 1 ? (int)fx : P.ncx - 1) : 0;
+        int cy = (fy > 0) ? (fy < P.ncy - 1 ? (int)fy : P.ncy - 1) : 0;
+        key = (uint32_t)(cy * P.ncx + cx);
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+
+// one wavefront per tile of 64 slots
+__global__ void __launch_bounds__(64) k_pack(const double* __restrict__ x, const double* __restrict__ y,
+                                             const double* __restrict__ vx, const double* __restrict__ vy,
+                                             const uint8_t* __restrict__ status, const int32_t* __restrict__ order,
+                                             int N, GcfmParams P, Scratch S) {
+    int k = blockIdx.x * 64 + threadIdx.x;
+    int i = (k < N) ? order[k] : -1;
+    bool act = (i >= 0) && status[i];
+    double px = 1e300, py = 1e300;
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 ph = make_float2(1.f, 0.f);
+    if (act) {
+        px = x[i];
+        py = y[i];
+        double vxd = vx[i], vyd = vy[i];
+        double s = sqrt(vxd * vxd + vyd * vyd);
+        double a = P.a_min + P.tau_a * s;
+        pv = make_float4((float)vxd, (float)vyd, (float)s, (float)(1.0 / (a * a)));
+        if (s > 0) ph = make_float2((float)(vxd / s), (float)(vyd / s));
+    }
+    S.ppos[k] = make_double2(px, py);
+    S.pvel[k] = pv;
+    S.phead[k] = ph;
+    S.pidx[k] = act ? i : -1;
+    double mnx = wmin(act ? px : INFINITY), mny = wmin(act ? py : INFINITY);
+    double mxx = wmax(act ? px : -INFINITY), mxy = wmax(act ? py : -INFINITY);
+    if (threadIdx.x == 0) S.tile_box[blockIdx.x] = make_double4(mnx, mny, mxx, mxy);
+}
+
+// ---------------------------------------------------------------------------------- pair forces
+#define COS_VISION (-0.58778525229247312917f)   // cos(0.7 pi), pedestrians.py:262
+
+// force of j on i (pedestrians.py:242-280) in trig-free form: cos(alpha-beta) = e.h, sin = h x e
+__device__ __forceinline__ void pair_term(float Rx, float Ry, float vxi, float vyi, float si, float hxi, float hyi,
+                                          float ia2_i, float ib2_i, float inv_vdes_i, float4 vj, float2 hj,
+                                          const GcfmParams& P, float b_max, float db, float inv_eta, double& fx,
+                                          double& fy) {
+    float r2 = Rx * Rx + Ry * Ry;
+    float r = sqrtf(r2);
+    float inv_r = 1.0f / r;
+    float ex = Rx * inv_r, ey = Ry * inv_r;
+    // closing speed (pedestrians.py:254-255)
+    float vrel = fmaxf((vxi - vj.x) * ex + (vyi - vj.y) * ey, 0.f);
+    // vision factor (pedestrians.py:259-262)
+    float k = 0.f;
+    if (si > 0.f) k = fmaxf((vxi * ex + vyi * ey) / si - COS_VISION, 0.f) / (1.f - COS_VISION);
+    // ellipse radii along the centre line (pedestrians.py:266-271)
+    float ci = ex * hxi + ey * hyi, sn_i = hxi * ey - hyi * ex;
+    float q_i = sqrtf(1.0f / (ci * ci * ia2_i + sn_i * sn_i * ib2_i));
+    float b_j = b_max - db * fminf(vj.z * inv_vdes_i, 1.f);          // Q6: i's v_des
+    float cj = ex * hj.x + ey * hj.y, sn_j = hj.x * ey - hj.y * ex;
+    float q_j = sqrtf(1.0f / (cj * cj * vj.w + sn_j * sn_j / (b_j * b_j)));
+    float dist = r - q_i - q_j;
+    float rep = fminf(k * expf(-dist * inv_eta / (1.f + vrel)), 1.f);
+    fx += (double)(-rep * Rx);
+    fy += (double)(-rep * Ry);
+}
+
+// one wavefront per i-tile; 4 wavefronts per block, each with a private LDS staging area
+__global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const double* __restrict__ v_des) {
+    __shared__ double2 l_pos[4][64];
+    __shared__ float4 l_vel[4][64];
+    __shared__ float2 l_head[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int it = blockIdx.x * 4 + w;
+    if (it >= S.ntiles) return;                       // whole wavefront exits together
+    const int k = it * 64 + lane;
+    const int i = S.pidx[k];
+    const double2 pi = S.ppos[k];
+    const float4 vi = S.pvel[k];
+    const float2 hi = S.phead[k];
+    float inv_vdes = 0.f, ib2_i = 0.f;
+    const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min), inv_eta = (float)(1.0 / P.eta);
+    if (i >= 0) {
+        double vd = v_des[i];
+        inv_vdes = (float)(1.0 / vd);
+        double b = P.b_max - (P.b_max - P.b_min) * fmin((double)vi.z / vd, 1.0);
+        ib2_i = (float)(1.0 / (b * b));
+    }
+    const double4 bi = S.tile_box[it];
+    const double c = P.cutoff;
+    const double c2 = c * c, c2_lo = c2 * (1.0 - 1e-15), c2_hi = c2 * (1.0 + 1e-15);
+    double fx = 0.0, fy = 0.0;
+    for (int tb = 0; tb < S.ntiles; tb += 64) {
+        int t = tb + lane;
+        bool hit = false;
+        if (t < S.ntiles) {
+            double4 bj = S.tile_box[t];
+            hit = !(bj.x > bi.z + c || bj.z < bi.x - c || bj.y > bi.w + c || bj.w < bi.y - c);
+        }
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            int jt = tb + b;
+            // stage tile jt (wave-private LDS; LDS ops of one wavefront complete in order)
+            __builtin_amdgcn_wave_barrier();
+            l_pos[w][lane] = S.ppos[jt * 64 + lane];
+            l_vel[w][lane] = S.pvel[jt * 64 + lane];
+            l_head[w][lane] = S.phead[jt * 64 + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (i >= 0) {
+#pragma unroll 4
+                for (int jj = 0; jj < 64; ++jj) {
+                    double2 pj = l_pos[w][jj];
+                    double ddx = pj.x - pi.x, ddy = pj.y - pi.y;
+                    double d2 = ddx * ddx + ddy * ddy;
+                    // reference: sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291); j != i
+                    bool nearp = (d2 < c2_lo) || (d2 < c2_hi && sqrt(d2) < c);
+                    if (nearp && !(jt == it && jj == lane)) {
+                        pair_term((float)ddx, (float)ddy, vi.x, vi.y, vi.z, hi.x, hi.y, vi.w, ib2_i, inv_vdes,
+                                  l_vel[w][jj], l_head[w][jj], P, b_max, db, inv_eta, fx, fy);
+                    }
+                }
+            }
+        }
+    }
+    S.f_pair[k] = make_double2(fx, fy);
+}
+
+// ---------------------------------------------------------------------------------- wall search + force
+// Exact nearest-site query (same cell as numpy's argmin over the full grid, see oracle WallMap for the proof
+// sketch): per grid row only the nearest site left and right of the agent's column can be the row minimum.
+__device__ __forceinline__ void wall_try(double px, double py, int r, int cnd, int Nx, const double* __restrict__ X0,
+                                         double yr, double off, double& best_d2, double& thr, double& best_f,
+                                         long long& best_flat) {
+    if (cnd < 0 || cnd >= Nx) return;
+    double ddx = X0[cnd] - px, ddy = yr - py;
+    double d2 = ddx * ddx + ddy * ddy;
+    if (d2 > thr) return;
+    double f = sqrt(d2) + off;                  // fl(fl(sqrt) + V*10e3): the reference's objective
+    long long flat = (long long)r * Nx + cnd;
+    if (f < best_f || (f == best_f && flat < best_flat)) {
+        best_f = f;
+        best_flat = flat;
+    }
+    if (d2 < best_d2) {
+        best_d2 = d2;
+        double bd = sqrt(d2);
+        thr = d2 + 4.8e-10 * bd + 1e-19;        // anything farther cannot tie after rounding at ulp(1e6)
+    }
+}
+
+__global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
+                                             const int32_t* __restrict__ key_of, const double* __restrict__ v_des,
+                                             const double* __restrict__ X0, const double* __restrict__ Y0) {
+    int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= S.Np) return;
+    int i = S.pidx[k];
+    long long best_flat = -1;
+    if (i >= 0) {
+        const KeyDev& kd = keys[key_of[i]];
+        const double2 p = S.ppos[k];
+        const int Nx = P.Nx, Ny = P.Ny;
+        const double hx = P.L / (Nx - 1), hy = P.H / (Ny - 1);
+        // column bracket: X0[jx] <= px < X0[jx+1], clipped
+        int jx = (int)floor(p.x / hx);
+        jx = jx < 0 ? 0 : (jx > Nx - 1 ? Nx - 1 : jx);
+        while (jx > 0 && X0[jx] > p.x) --jx;
+        while (jx < Nx - 1 && X0[jx + 1] <= p.x) ++jx;
+        int jr = (jx + 1 < Nx) ? jx + 1 : -1;
+        int r0 = (int)floor(p.y / hy + 0.5);
+        r0 = r0 < 0 ? 0 : (r0 > Ny - 1 ? Ny - 1 : r0);
+        double best_d2 = INFINITY, thr = INFINITY, best_f = INFINITY;
+        const double rad = P.wall_radius;
+        bool up = true, dn = true;
+        for (int o = 0; up || dn; ++o) {
+            // upward row r0+o
+            if (up) {
+                int r = r0 + o;
+                if (r >= Ny) up = false;
+                else {
+                    double yr = Y0[r], ady = fabs(yr - p.y);
+                    if (ady * ady > thr || (rad > 0 && ady > rad)) {
+                        if (yr > p.y) up = false;     // monotone beyond the agent's row
+                    } else {
+                        wall_try(p.x, p.y, r, kd.left[(long long)r * Nx + jx], Nx, X0, yr, kd.off, best_d2, thr,
+                                 best_f, best_flat);
+                        if (jr >= 0)
+                            wall_try(p.x, p.y, r, kd.right[(long long)r * Nx + jr], Nx, X0, yr, kd.off, best_d2, thr,
+                                     best_f, best_flat);
+                    }
+                }
+            }
+            if (dn && o > 0) {
+                int r = r0 - o;
+                if (r < 0) dn = false;
+                else {
+                    double yr = Y0[r], ady = fabs(yr - p.y);
+                    if (ady * ady > thr || (rad > 0 && ady > rad)) {
+                        if (yr < p.y) dn = false;
+                    } else {
+                        wall_try(p.x, p.y, r, kd.left[(long long)r * Nx + jx], Nx, X0, yr, kd.off, best_d2, thr,
+                                 best_f, best_flat);
+                        if (jr >= 0)
+                            wall_try(p.x, p.y, r, kd.right[(long long)r * Nx + jr], Nx, X0, yr, kd.off, best_d2, thr,
+                                     best_f, best_flat);
+                    }
+                }
+            }
+        }
+    }
+    S.widx[k] = best_flat;
+}
+
+// wall force from the selected cell, float64 (pedestrians.py:317-334)
+__global__ void k_wall_force(GcfmParams P, Scratch S, const double* __restrict__ vx, const double* __restrict__ vy,
+                             const double* __restrict__ v_des, const double* __restrict__ X0,
+                             const double* __restrict__ Y0) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S.Np) return;
+    int i = S.pidx[k];
+    long long flat = S.widx[k];
+    double2 out = make_double2(0.0, 0.0);
+    if (i >= 0 && flat >= 0) {
+        int r = (int)(flat / P.Nx), cc = (int)(flat % P.Nx);
+        double2 p = S.ppos[k];
+        double Rx = X0[cc] - p.x, Ry = Y0[r] - p.y;
+        double rr = sqrt(Rx * Rx + Ry * Ry);
+        double ex = Rx / rr, ey = Ry / rr;
+        double vxd = vx[i], vyd = vy[i];
+        double d = vxd * ex + vyd * ey;
+        double vrel = 0.5 * (d + fabs(d));
+        double s = sqrt(vxd * vxd + vyd * vyd);
+        double hx = 1.0, hy = 0.0;
+        if (s > 0) {
+            hx = vxd / s;
+            hy = vyd / s;
+        }
+        double a = P.a_min + P.tau_a * s;
+        double b = P.b_max - (P.b_max - P.b_min) * fmin(s / v_des[i], 1.0);
+        double ca = (ex * hx + ey * hy) / a, sb = (hx * ey - hy * ex) / b;
+        double q = 1.0 / (ca * ca + sb * sb);                 // Q12: no square root
+        double dist = rr - q;
+        double rep = fmin(exp(-dist / (P.eta_walls * (1.0 + vrel))), 1.0);
+        out = make_double2(-3.0 * rep * Rx, -3.0 * rep * Ry);
+    }
+    S.f_wall[k] = out;
+}
+
+// ---------------------------------------------------------------------------------- lookup
+// Python float floor division (CPython floatobject.c float_floor_div / numpy npy_divmod)
+__device__ __forceinline__ double py_floordiv(double vx, double wx) {
+    double mod = fmod(vx, wx);
+    double div = (vx - mod) / wx;
+    if (mod != 0.0) {
+        if ((wx < 0) != (mod < 0)) div -= 1.0;
+    }
+    double fl;
+    if (div != 0.0) {
+        fl = floor(div);
+        if (div - fl > 0.5) fl += 1.0;
+    } else {
+        fl = copysign(0.0, vx / wx);
+    }
+    return fl;
+}
+
+template <typename T>
+__device__ __forceinline__ double2 field_fetch(const KeyDev& kd, int step, int i0, int i1, int j0, int j1, int Nx,
+                                               int Ny) {
+    const size_t W = (size_t)(Nx - 2), Hh = (size_t)(Ny - 2);
+    const T* fx = (const T*)kd.vx + (size_t)step * W * Hh;
+    const T* fy = (const T*)kd.vy + (size_t)step * W * Hh;
+    double ax = (double)fx[(size_t)i0 * W + j0], bx = (double)fx[(size_t)i1 * W + j1];
+    double ay = (double)fy[(size_t)i0 * W + j0], by = (double)fy[(size_t)i1 * W + j1];
+    return make_double2((ax + bx) / 2, (ay + by) / 2);
+}
+
+// des = v_des * choose_optimal_velocity(pos, step)  (optimals.py:212-250, simulations.py:281)
+__device__ __forceinline__ double2 lookup(const GcfmParams& P, const KeyDev& kd, double x, double y, double vdes,
+                                          int step, int agent, int32_t* err) {
+    if (step >= kd.nt_opt - 1) return make_double2(0.0, 0.0);
+    const int Nx = P.Nx, Ny = P.Ny;
+    int j0, j1, i0, i1;
+    if (x < P.L - P.dx) {
+        j0 = (int)py_floordiv(x, P.dx);
+        j1 = (x > P.dx) ? j0 + 1 : j0;
+    } else {
+        j0 = j1 = Nx - 3;
+    }
+    if (y < P.H - P.dy) {
+        i0 = (int)py_floordiv(y, P.dy);
+        i1 = (y > P.dy) ? i0 + 1 : i0;
+    } else {
+        i0 = i1 = Ny - 3;
+    }
+    // numpy index semantics on axes of size Nx-2 / Ny-2: negative wraps once, else IndexError (quirk Q8)
+    bool bad = false;
+    auto fix = [&](int& v, int n) {
+        if (v < 0) v += n;
+        if (v < 0 || v >= n) {
+            bad = true;
+            v = v < 0 ? 0 : n - 1;
+        }
+    };
+    fix(j0, Nx - 2);
+    fix(j1, Nx - 2);
+    fix(i0, Ny - 2);
+    fix(i1, Ny - 2);
+    if (bad && err) atomicMax(err, agent + 1);
+    if (step >= kd.nslice_alloc) return make_double2(0.0, 0.0);
+    double2 d = (kd.dtype == OC_F32) ? field_fetch<float>(kd, step, i0, i1, j0, j1, Nx, Ny)
+                                     : field_fetch<double>(kd, step, i0, i1, j0, j1, Nx, Ny);
+    return make_double2(vdes * d.x, vdes * d.y);
+}
+
+__global__ void k_lookup(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
+                         const int32_t* __restrict__ key_of, const double* __restrict__ v_des, int step,
+                         int32_t* err) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S.Np) return;
+    int i = S.pidx[k];
+    double2 d = make_double2(0.0, 0.0);
+    if (i >= 0) {
+        double2 p = S.ppos[k];
+        d = lookup(P, keys[key_of[i]], p.x, p.y, v_des[i], step, i, err);
+    }
+    S.des[k] = d;
+}
+
+// ---------------------------------------------------------------------------------- noise (Philox4x32-10)
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ---------------------------------------------------------------------------------- integrate
+// simulations.py:303-332 for every active agent, in place (forces were computed from the packed snapshot)
+__global__ void k_integrate(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
+                            const int32_t* __restrict__ key_of, double* __restrict__ x, double* __restrict__ y,
+                            double* __restrict__ vx, double* __restrict__ vy, uint8_t* __restrict__ status,
+                            double* __restrict__ agent_time, const double* __restrict__ noise, uint64_t seed,
+                            int step) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S.Np) return;
+    int i = S.pidx[k];
+    if (i < 0) return;
+    double n0, n1;
+    if (noise) {
+        n0 = noise[2 * (size_t)i];
+        n1 = noise[2 * (size_t)i + 1];
+    } else {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)i, (uint32_t)step, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        double u1 = ((double)r[0] + 0.5) * 0x1p-32, u2 = ((double)r[1] + 0.5) * 0x1p-32;
+        double rad = sqrt(-2.0 * log(u1));
+        n0 = rad * cos(6.283185307179586 * u2);
+        n1 = rad * sin(6.283185307179586 * u2);
+    }
+    double2 p = S.ppos[k], fp = S.f_pair[k], fw = S.f_wall[k], ds = S.des[k];
+    double vxd = vx[i], vyd = vy[i];
+    double cvx = vxd + P.noise_amp * n0 + fp.x + fw.x;
+    double cvy = vyd + P.noise_amp * n1 + fp.y + fw.y;
+    double ax = (ds.x - cvx) / P.relaxation, ay = (ds.y - cvy) / P.relaxation;
+    double dt = P.dt, dt2 = dt * dt;
+    double nx = p.x + cvx * dt + 0.5 * ax * dt2;
+    double ny = p.y + cvy * dt + 0.5 * ay * dt2;
+    double nvx = cvx + ax * dt, nvy = cvy + ay * dt;
+    double nrm = sqrt(nvx * nvx + nvy * nvy);
+    if (!(nrm < P.v_max)) {
+        double sc = P.v_max / nrm;
+        nvx *= sc;
+        nvy *= sc;
+    }
+    x[i] = nx;
+    y[i] = ny;
+    vx[i] = nvx;
+    vy[i] = nvy;
+    if (agent_time) agent_time[i] += dt;
+    // exit test against the agent's own targets, strict (pedestrians.py:132-136)
+    const KeyDev& kd = keys[key_of[i]];
+    bool out = false;
+    for (int q = 0; q < kd.nrect; ++q)
+        if (fabs(nx - kd.rect[q][0]) < kd.rect[q][2] * 0.5 && fabs(ny - kd.rect[q][1]) < kd.rect[q][3] * 0.5)
+            out = true;
+    if (out) {
+        status[i] = 0;
+        atomicAdd(&S.counters[0], 1);
+    } else {
+        atomicAdd(&S.counters[2], 1);
+    }
+}
+
+template <typename TV>
+__global__ void k_scatter(const TV* __restrict__ src, const int32_t* __restrict__ pidx, int Np, TV* __restrict__ dst) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Np) return;
+    int i = pidx[k];
+    if (i >= 0) dst[i] = src[k];
+}
+
+// ---------------------------------------------------------------------------------- wall map build
+// left[i][j] = largest site column <= j (or -1); right[i][j] = smallest site column >= j (or Nx).  One thread per row.
+__global__ void k_wallmap(const float* __restrict__ V, float vmin, int Ny, int Nx, int32_t* __restrict__ left,
+                          int32_t* __restrict__ right) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= Ny) return;
+    const float* row = V + (size_t)r * Nx;
+    int last = -1;
+    for (int j = 0; j < Nx; ++j) {
+        if (row[j] == vmin) last = j;
+        left[(size_t)r * Nx + j] = last;
+    }
+    last = Nx;
+    for (int j = Nx - 1; j >= 0; --j) {
+        if (row[j] == vmin) last = j;
+        right[(size_t)r * Nx + j] = last;
+    }
+}
+
+// ---------------------------------------------------------------------------------- host helpers
+GcfmParams make_params(const oc_handle* h) {
+    const oc_config& c = h->cfg;
+    GcfmParams P;
+    P.Ny = c.Ny; P.Nx = c.Nx;
+    P.dx = c.dx; P.dy = c.dy; P.L = c.room_length; P.H = c.room_height; P.dt = c.dt;
+    P.a_min = c.a_min; P.tau_a = c.tau_a; P.b_min = c.b_min; P.b_max = c.b_max; P.eta = c.eta;
+    P.eta_walls = c.eta_walls; P.cutoff = c.repulsion_cutoff; P.v_max = c.v_max; P.relaxation = c.relaxation;
+    P.noise_amp = c.noise_amp; P.wall_radius = c.wall_search_radius;
+    P.cell = c.repulsion_cutoff > 0 ? c.repulsion_cutoff : 4.0;
+    P.ncx = (int)(c.room_length / P.cell) + 1;
+    P.ncy = (int)(c.room_height / P.cell) + 1;
+    return P;
+}
+
+int carve(oc_handle* h, int N, Scratch* S) {
+    int Np = ((N + 63) / 64) * 64;
+    if (Np == 0) Np = 64;
+    size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + sizeof(double2) + sizeof(float4) + sizeof(float2) +
+                 sizeof(int32_t) + 3 * sizeof(double2) + sizeof(long long);
+    size_t need = per * (size_t)Np + sizeof(double4) * (size_t)(Np / 64) + 64 + 4096;
+    if (need > h->gcfm_bytes) {
+        if (h->gcfm_buf) OC_HIP_CHECK(hipFree(h->gcfm_buf));
+        h->gcfm_buf = nullptr;
+        OC_HIP_CHECK(hipMalloc(&h->gcfm_buf, need));
+        h->gcfm_bytes = need;
+        h->sorted_N = -1;
+    }
+    char* p = (char*)h->gcfm_buf;
+    auto take = [&](size_t bytes) {
+        char* q = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return (void*)q;
+    };
+    // carve order: 16-byte aligned types first
+    S->ppos = (double2*)take(sizeof(double2) * Np);
+    S->pvel = (float4*)take(sizeof(float4) * Np);
+    S->f_pair = (double2*)take(sizeof(double2) * Np);
+    S->f_wall = (double2*)take(sizeof(double2) * Np);
+    S->des = (double2*)take(sizeof(double2) * Np);
+    S->tile_box = (double4*)take(sizeof(double4) * (Np / 64));
+    S->widx = (long long*)take(sizeof(long long) * Np);
+    S->phead = (float2*)take(sizeof(float2) * Np);
+    S->keys_a = (uint32_t*)take(sizeof(uint32_t) * Np);
+    S->keys_b = (uint32_t*)take(sizeof(uint32_t) * Np);
+    S->vals_a = (int32_t*)take(sizeof(int32_t) * Np);
+    S->vals_b = (int32_t*)take(sizeof(int32_t) * Np);
+    S->pidx = (int32_t*)take(sizeof(int32_t) * Np);
+    S->counters = (int32_t*)take(64);
+    S->Np = Np;
+    S->ntiles = Np / 64;
+    return OC_OK;
+}
+
+int upload_keys(oc_handle* h, hipStream_t s) {
+    if (!h->key_tables_dirty && h->key_tables_dev) return OC_OK;
+    size_t nk = h->fields.size();
+    std::vector<KeyDev> host(nk);
+    for (size_t k = 0; k < nk; ++k) {
+        KeyDev& d = host[k];
+        memset(&d, 0, sizeof(d));
+        d.vx = h->fields[k].vx;
+        d.vy = h->fields[k].vy;
+        d.dtype = h->fields[k].dtype;
+        d.nslice_alloc = h->fields[k].nslice_alloc;
+        d.nt_opt = h->fields[k].vx ? h->fields[k].nt_opt : 0;
+        d.left = h->wallmaps[k].left;
+        d.right = h->wallmaps[k].right;
+        d.off = h->wallmaps[k].off;
+        d.nrect = h->rects[k].n;
+        memcpy(d.rect, h->rects[k].r, sizeof(d.rect));
+    }
+    if (!h->key_tables_dev) OC_HIP_CHECK(hipMalloc(&h->key_tables_dev, sizeof(KeyDev) * nk));
+    // synchronous copy of a small table: happens only when a field / target / wall map changed
+    OC_HIP_CHECK(hipStreamSynchronize(s));
+    OC_HIP_CHECK(hipMemcpy(h->key_tables_dev, host.data(), sizeof(KeyDev) * nk, hipMemcpyHostToDevice));
+    h->key_tables_dirty = false;
+    return OC_OK;
+}
+
+int check_agents(const oc_handle* h, const oc_agents* a) {
+    OC_REQUIRE(h && a, "null argument");
+    OC_REQUIRE(a->N >= 0 && a->N <= h->cfg.max_agents, "agent count exceeds max_agents");
+    OC_REQUIRE(a->N == 0 || (a->x && a->y && a->vx && a->vy && a->v_des && a->status && a->key), "null agent array");
+    return OC_OK;
+}
+
+// order + packed snapshot of the current state
+int prepare(oc_handle* h, const oc_agents* a, bool force_sort, Scratch* S, GcfmParams* P, hipStream_t s) {
+    int rc = carve(h, a->N, S);
+    if (rc) return rc;
+    *P = make_params(h);
+    const int N = a->N;
+    if (force_sort || h->sorted_N != N || h->steps_since_sort >= h->resort_every) {
+        if (N > 0) {
+            hipLaunchKernelGGL(k_cell_keys, dim3((N + 255) / 256), dim3(256), 0, s, a->x, a->y, a->status, N, *P,
+                               S->keys_a, S->vals_a);
+            rc = oc_sort_pairs(h, S->keys_a, S->keys_b, S->vals_a, S->vals_b, N, 30, s);
+            if (rc) return rc;
+        }
+        h->sorted_N = N;
+        h->steps_since_sort = 0;
+    }
+    hipLaunchKernelGGL(k_pack, dim3(S->ntiles), dim3(64), 0, s, a->x, a->y, a->vx, a->vy, a->status, S->vals_b, N, *P,
+                       *S);
+    return OC_OK;
+}
+
+}   // namespace
+
+// ---------------------------------------------------------------------------------- C ABI
+extern "C" int oc_wallmap_build(oc_handle* h, int key, const float* V, float vmin, void* stream) {
+    OC_REQUIRE(h && V && key >= 0 && key < (int)h->wallmaps.size(), "bad argument");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    oc_wallmap& w = h->wallmaps[key];
+    size_t bytes = sizeof(int32_t) * (size_t)h->ncell;
+    if (!w.left) OC_HIP_CHECK(hipMalloc(&w.left, bytes));
+    if (!w.right) OC_HIP_CHECK(hipMalloc(&w.right, bytes));
+    hipLaunchKernelGGL(k_wallmap, dim3((h->cfg.Ny + 63) / 64), dim3(64), 0, s, V, vmin, h->cfg.Ny, h->cfg.Nx, w.left,
+                       w.right);
+    OC_HIP_CHECK(hipGetLastError());
+    w.off = (double)vmin * 10e3;
+    w.built = true;
+    h->key_tables_dirty = true;
+    return OC_OK;
+}
+
+static int require_wallmaps(oc_handle* h) {
+    for (size_t k = 0; k < h->wallmaps.size(); ++k)
+        if (!h->wallmaps[k].built) {
+            oc_set_error("wall map of key %d not built (oc_wallmap_build)", (int)k);
+            return OC_ERR_STATE;
+        }
+    return OC_OK;
+}
+
+extern "C" int oc_field_lookup(oc_handle* h, const oc_agents* a, int32_t simu_step, double* des, int32_t* err_flag,
+                               void* stream) {
+    int rc = check_agents(h, a);
+    if (rc) return rc;
+    OC_REQUIRE(des, "null output");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scratch S;
+    GcfmParams P;
+    if ((rc = upload_keys(h, s))) return rc;
+    if ((rc = prepare(h, a, false, &S, &P, s))) return rc;
+    OC_HIP_CHECK(hipMemsetAsync(des, 0, sizeof(double) * 2 * (size_t)a->N, s));
+    if (err_flag) OC_HIP_CHECK(hipMemsetAsync(err_flag, 0, sizeof(int32_t) * 2, s));
+    hipLaunchKernelGGL(k_lookup, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, (const KeyDev*)h->key_tables_dev,
+                       a->key, a->v_des, simu_step, err_flag);
+    hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.des, S.pidx, S.Np,
+                       (double2*)des);
+    OC_HIP_CHECK(hipGetLastError());
+    return OC_OK;
+}
+
+extern "C" int oc_wall_force(oc_handle* h, const oc_agents* a, int64_t* index_out, double* force_out, void* stream) {
+    int rc = check_agents(h, a);
+    if (rc) return rc;
+    if ((rc = require_wallmaps(h))) return rc;
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scratch S;
+    GcfmParams P;
+    if ((rc = upload_keys(h, s))) return rc;
+    if ((rc = prepare(h, a, false, &S, &P, s))) return rc;
+    hipLaunchKernelGGL(k_wall, dim3(S.ntiles), dim3(64), 0, s, P, S, (const KeyDev*)h->key_tables_dev, a->key, a->v_des,
+                       h->X0, h->Y0);
+    hipLaunchKernelGGL(k_wall_force, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, a->vx, a->vy, a->v_des, h->X0,
+                       h->Y0);
+    if (index_out) {
+        OC_HIP_CHECK(hipMemsetAsync(index_out, 0xFF, sizeof(int64_t) * (size_t)a->N, s));
+        hipLaunchKernelGGL(k_scatter<long long>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.widx, S.pidx, S.Np,
+                           (long long*)index_out);
+    }
+    if (force_out) {
+        OC_HIP_CHECK(hipMemsetAsync(force_out, 0, sizeof(double) * 2 * (size_t)a->N, s));
+        hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_wall, S.pidx, S.Np,
+                           (double2*)force_out);
+    }
+    OC_HIP_CHECK(hipGetLastError());
+    return OC_OK;
+}
+
+extern "C" int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out, void* stream) {
+    int rc = check_agents(h, a);
+    if (rc) return rc;
+    OC_REQUIRE(force_out, "null output");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scratch S;
+    GcfmParams P;
+    if ((rc = prepare(h, a, false, &S, &P, s))) return rc;
+    oc_timer_begin(h, "gcfm_pair", s);
+    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, a->v_des);
+    oc_timer_end(h, "gcfm_pair", s);
+    OC_HIP_CHECK(hipMemsetAsync(force_out, 0, sizeof(double) * 2 * (size_t)a->N, s));
+    hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_pair, S.pidx, S.Np,
+                       (double2*)force_out);
+    OC_HIP_CHECK(hipGetLastError());
+    return OC_OK;
+}
+
+extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise, uint64_t seed,
+                            int32_t* counters, void* stream) {
+    int rc = check_agents(h, a);
+    if (rc) return rc;
+    if ((rc = require_wallmaps(h))) return rc;
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scratch S;
+    GcfmParams P;
+    if ((rc = upload_keys(h, s))) return rc;
+    if ((rc = prepare(h, a, false, &S, &P, s))) return rc;
+    ++h->steps_since_sort;
+    OC_HIP_CHECK(hipMemsetAsync(S.counters, 0, 64, s));
+    const KeyDev* kd = (const KeyDev*)h->key_tables_dev;
+    dim3 g256((S.Np + 255) / 256);
+    hipLaunchKernelGGL(k_lookup, g256, dim3(256), 0, s, P, S, kd, a->key, a->v_des, simu_step, S.counters + 1);
+    oc_timer_begin(h, "gcfm_pair", s);
+    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, a->v_des);
+    oc_timer_end(h, "gcfm_pair", s);
+    oc_timer_begin(h, "gcfm_wall", s);
+    hipLaunchKernelGGL(k_wall, dim3(S.ntiles), dim3(64), 0, s, P, S, kd, a->key, a->v_des, h->X0, h->Y0);
+    hipLaunchKernelGGL(k_wall_force, g256, dim3(256), 0, s, P, S, a->vx, a->vy, a->v_des, h->X0, h->Y0);
+    oc_timer_end(h, "gcfm_wall", s);
+    hipLaunchKernelGGL(k_integrate, g256, dim3(256), 0, s, P, S, kd, a->key, a->x, a->y, a->vx, a->vy, a->status,
+                       a->agent_time, noise, seed, simu_step);
+    if (counters)
+        OC_HIP_CHECK(hipMemcpyAsync(counters, S.counters, sizeof(int32_t) * 4, hipMemcpyDeviceToDevice, s));
+    OC_HIP_CHECK(hipGetLastError());
+    return OC_OK;
+}

@@ -1,0 +1,576 @@
+// HJB solve on the room grid: Cole-Hopf-linearised equation integrated backwards in time with
+// Dormand-Prince RK45 (SciPy's controller and dense output), reduced to a unit-or-zero direction field.
+// Replaces reference optimals.py:124-206 (closure hjb :144-164, vels :168-186, fill loop :200-204) and the
+// SciPy arithmetic it calls (scipy/integrate/_ivp/rk.py:14-180,552-575; common.py:63-134; ivp.py:598-723).
+//
+// Data layout (HBM): every grid array is row-major (Ny, Nx) of T (float = product, double = audit).
+//   coef   : (V + g m)/(mu sigma^2) on free cells, NaN on walls  (make_coef)
+//   y,K0..6: RK state / stage derivatives, carried as phi * 2^-e (e tracked on the host; the PDE is linear and
+//            wall cells are frozen, so a power-of-two rescale is exact) -- keeps fp32 in range for e^{T/(mu s^2)}.
+//   vx,vy  : (nslice, Ny-2, Nx-2) direction field, slice s <-> time s*T/(nt-1).
+#include "oc_internal.h"
+#include <cmath>
+#include <chrono>
+
+namespace {
+
+// ---- Dormand-Prince tables (scipy rk.py:377-404), double on the host
+const double RK_A[6][5] = {
+    {0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+const double RK_B[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+const double RK_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+const double RK_P[7][4] = {
+    {1, -8048581381.0 / 2820520608, 8663915743.0 / 2820520608, -12715105075.0 / 11282082432},
+    {0, 0, 0, 0},
+    {0, 131558114200.0 / 32700410799, -68118460800.0 / 10900136933, 87487479700.0 / 32700410799},
+    {0, -1754552775.0 / 470086768, 14199869525.0 / 1410260304, -10690763975.0 / 1880347072},
+    {0, 127303824393.0 / 49829197408, -318862633887.0 / 49829197408, 701980252875.0 / 199316789632},
+    {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
+    {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
+
+template <typename T>
+struct Lin8 {   // out = base + sum_j c[j] * K[j]
+    const T* k[8];
+    T c[8];
+    int n;
+};
+
+// ------------------------------------------------------------------------------------------ kernels
+template <typename T>
+__global__ void k_make_coef(const float* __restrict__ V, const T* __restrict__ m, double g, double inv_musig2,
+                            T* __restrict__ coef, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = V[i];
+    if (v < 0.f) {
+        coef[i] = (T)NAN;
+    } else {
+        double mm = m ? (double)m[i] : 0.0;
+        coef[i] = (T)(((double)v + g * mm) * inv_musig2);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T rhs_point(const T* __restrict__ p, const T* __restrict__ coef, int i, int j, int Ny,
+                                       int Nx, T a_lap) {
+    int64_t c = (int64_t)i * Nx + j;
+    T cf = coef[c];
+    if (cf != cf) return (T)0;                        // wall: optimals.py:162
+    int iu = (i == 0) ? 1 : i - 1;                    // mirror ghosts: optimals.py:149-152
+    int id = (i == Ny - 1) ? Ny - 2 : i + 1;
+    int jl = (j == 0) ? 1 : j - 1;
+    int jr = (j == Nx - 1) ? Nx - 2 : j + 1;
+    T C = p[c];
+    T s = p[(int64_t)iu * Nx + j] + p[(int64_t)id * Nx + j] + p[(int64_t)i * Nx + jl] + p[(int64_t)i * Nx + jr] -
+          (T)4 * C;
+    return a_lap * s - cf * C;
+}
+
+template <typename T>
+__global__ void k_rhs(const T* __restrict__ p, const T* __restrict__ coef, T* __restrict__ out, int Ny, int Nx,
+                      T a_lap) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= Ny || j >= Nx) return;
+    out[(int64_t)i * Nx + j] = rhs_point(p, coef, i, j, Ny, Nx, a_lap);
+}
+
+template <typename T>
+__global__ void k_lincomb(const T* __restrict__ base, Lin8<T> L, T* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T acc = (T)0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (j < L.n) acc += L.c[j] * L.k[j][i];
+    out[i] = base[i] + acc;
+}
+
+template <typename T>
+__global__ void k_fill(T* __restrict__ p, T v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+template <typename T>
+__global__ void k_scale(T* __restrict__ a, T* __restrict__ b, T s, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        a[i] *= s;
+        b[i] *= s;
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// block (256 threads) reduction of (sum, max) -> partial[2*block]
+__device__ __forceinline__ void block_reduce_store(double s, double m, double* __restrict__ partial) {
+    __shared__ double ls[4], lm[4];
+    s = wave_sum(s);
+    m = wave_max(m);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        ls[w] = s;
+        lm[w] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = ls[0] + ls[1] + ls[2] + ls[3];
+        partial[2 * blockIdx.x + 1] = fmax(fmax(lm[0], lm[1]), fmax(lm[2], lm[3]));
+    }
+}
+
+// mode 0: sum (a/scale)^2, scale = atol + |y| rtol                      (select_initial_step d0/d1)
+// mode 1: sum ((a-b)/scale)^2                                            (d2)
+template <typename T, int MODE>
+__global__ void k_norm_scaled(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ y, T atol,
+                              T rtol, int64_t n, double* __restrict__ partial) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        T sc = atol + fabs(y[i]) * rtol;
+        T v = (MODE == 0) ? a[i] / sc : (a[i] - b[i]) / sc;
+        s += (double)v * (double)v;
+    }
+    block_reduce_store(s, 0.0, partial);
+}
+
+// error norm of a step (scipy rk.py:146-147) + max |y_new| for range management
+template <typename T>
+__global__ void k_err_norm(const T* __restrict__ y, const T* __restrict__ ynew, Lin8<T> E /* h*E_j */, T atol,
+                           T rtol, int64_t n, double* __restrict__ partial) {
+    double s = 0.0, mx = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        T e = (T)0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < E.n) e += E.c[j] * E.k[j][i];
+        T yn = ynew[i];
+        T sc = atol + fmax(fabs(y[i]), fabs(yn)) * rtol;
+        T v = e / sc;
+        s += (double)v * (double)v;
+        mx = fmax(mx, (double)fabs(yn));
+    }
+    block_reduce_store(s, mx, partial);
+}
+
+__global__ void k_reduce_final(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+    double s = 0.0, m = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+        s += partial[2 * i];
+        m = fmax(m, partial[2 * i + 1]);
+    }
+    __shared__ double ls[4], lm[4];
+    s = wave_sum(s);
+    m = wave_max(m);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        ls[w] = s;
+        lm[w] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = ls[0] + ls[1] + ls[2] + ls[3];
+        out[1] = fmax(fmax(lm[0], lm[1]), fmax(lm[2], lm[3]));
+    }
+}
+
+// dense output (scipy rk.py:560-575): phi = y_old + h * sum_p (sum_j K_j P_jp) x^(p+1)
+template <typename T>
+__global__ void k_dense(const T* __restrict__ yold, Lin8<T> W /* c_j = h * sum_p P_jp x^(p+1) */,
+                        T* __restrict__ out, double* __restrict__ keep, double unscale, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T acc = (T)0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (j < W.n) acc += W.c[j] * W.k[j][i];
+    T v = yold[i] + acc;
+    if (out) out[i] = v;
+    if (keep) keep[i] = (double)v * unscale;
+}
+
+// vels (optimals.py:168-186) on a phi carried as phi*scale: lim -> lim*scale; everything else is a ratio.
+template <typename TI, typename TO>
+__global__ void k_vels(const TI* __restrict__ phi, TO* __restrict__ vx, TO* __restrict__ vy, int Ny, int Nx,
+                       TI lim_s, TI lim, TI mu, TI inv2dx, TI inv2dy) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    int i = blockIdx.y * blockDim.y + threadIdx.y + 1;
+    if (i >= Ny - 1 || j >= Nx - 1) return;
+    auto clip = [&](TI p) { return (p > lim_s) ? p : ((p < lim_s) ? lim_s : (TI)0); };   // p==lim -> 0 (Q15)
+    TI pe = clip(phi[(int64_t)i * Nx + j + 1]);
+    TI pw = clip(phi[(int64_t)i * Nx + j - 1]);
+    TI pn = clip(phi[(int64_t)(i + 1) * Nx + j]);
+    TI ps = clip(phi[(int64_t)(i - 1) * Nx + j]);
+    TI pc = clip(phi[(int64_t)i * Nx + j]);
+    TI gx = (pe - pw) * inv2dx;
+    TI gy = (pn - ps) * inv2dy;
+    TI ux = gx / (mu * pc);
+    TI uy = gy / (mu * pc);
+    TI norm = sqrt(ux * ux + uy * uy);
+    TI ox, oy;
+    if (norm > lim) {
+        ox = ux / norm;
+        oy = uy / norm;
+    } else if (norm < lim) {
+        ox = (TI)0;
+        oy = (TI)0;
+    } else {            // norm == lim (-> 0/0 in the reference) or NaN
+        ox = (TI)NAN;
+        oy = (TI)NAN;
+    }
+    int64_t o = (int64_t)(i - 1) * (Nx - 2) + (j - 1);
+    vx[o] = (TO)ox;
+    vy[o] = (TO)oy;
+}
+
+// ------------------------------------------------------------------------------------------ host side
+template <typename T>
+struct Solver {
+    oc_handle* h;
+    hipStream_t s;
+    int Ny, Nx;
+    int64_t n;
+    T *y, *ynew, *ytmp, *K[7], *phi_tmp;
+    const T* coef;
+    T a_lap;
+    int nfev = 0;
+
+    int alloc() {
+        size_t need = sizeof(T) * (size_t)n * 12;
+        if (h->hjb_buf == nullptr || h->hjb_elem < sizeof(T)) {
+            if (h->hjb_buf) OC_HIP_CHECK(hipFree(h->hjb_buf));
+            h->hjb_buf = nullptr;
+            OC_HIP_CHECK(hipMalloc(&h->hjb_buf, need));
+            h->hjb_elem = sizeof(T);
+        }
+        T* b = (T*)h->hjb_buf;
+        y = b;
+        ynew = b + n;
+        ytmp = b + 2 * n;
+        for (int k = 0; k < 7; ++k) K[k] = b + (3 + k) * n;
+        phi_tmp = b + 10 * n;
+        return OC_OK;
+    }
+    dim3 g1() const { return dim3((unsigned)((n + 255) / 256)); }
+    dim3 b2() const { return dim3(64, 4); }
+    dim3 g2(int nx, int ny) const { return dim3((nx + 63) / 64, (ny + 3) / 4); }
+
+    void rhs(const T* p, T* out) {
+        hipLaunchKernelGGL(k_rhs<T>, g2(Nx, Ny), b2(), 0, s, p, coef, out, Ny, Nx, a_lap);
+        ++nfev;
+    }
+    int reduce(double* sum, double* mx) {   // partials already written by a 1024-block kernel
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, h->red_partial, 1024, h->red_out);
+        OC_HIP_CHECK(hipMemcpyAsync(h->red_host, h->red_out, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+        OC_HIP_CHECK(hipStreamSynchronize(s));
+        *sum = h->red_host[0];
+        if (mx) *mx = h->red_host[1];
+        return OC_OK;
+    }
+};
+
+template <typename T>
+int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, void* vx_out, void* vy_out,
+                const int32_t* keep_idx, int32_t n_keep, double* phi_keep, double* t_steps, int32_t t_steps_cap,
+                oc_hjb_stats* st, hipStream_t s) {
+    const oc_config& c = h->cfg;
+    Solver<T> S;
+    S.h = h;
+    S.s = s;
+    S.Ny = c.Ny;
+    S.Nx = c.Nx;
+    S.n = h->ncell;
+    S.coef = (const T*)coef_v;
+    S.a_lap = (T)(-0.5 * c.sigma * c.sigma / (c.dx * c.dy));
+    int rc = S.alloc();
+    if (rc) return rc;
+    const int64_t n = S.n;
+    const double rtol = c.rtol, atol0 = c.atol;
+    const int RB = 1024;
+
+    oc_hjb_stats stats;
+    memset(&stats, 0, sizeof(stats));
+    stats.h_min = 1e300;
+    if (nt <= 1) {   // linspace(T,0,nt) has no slice that the fill loop would use (optimals.py:200)
+        if (st) *st = stats;
+        return OC_OK;
+    }
+    // t_eval = np.linspace(T, 0, nt)
+    std::vector<double> te(nt);
+    {
+        double step = (0.0 - Tfinal) / (double)(nt - 1);
+        for (int k = 0; k < nt; ++k) te[k] = (double)k * step + Tfinal;
+        te[nt - 1] = 0.0;
+    }
+    std::vector<int> keep_slot(nt, -1);
+    for (int q = 0; q < n_keep; ++q) {
+        OC_REQUIRE(keep_idx[q] >= 0 && keep_idx[q] < nt, "keep index out of range");
+        keep_slot[keep_idx[q]] = q;
+    }
+
+    int expo = 0;                       // state = phi * 2^-expo
+    auto scale_of = [&]() { return std::ldexp(1.0, -expo); };
+
+    hipLaunchKernelGGL(k_fill<T>, S.g1(), dim3(256), 0, s, S.y, (T)1, n);
+    const double t0 = Tfinal, tf = 0.0, direction = -1.0;
+    double t = t0;
+    S.rhs(S.y, S.K[6]);                 // f0 lives in K[6] (FSAL slot)
+    // ---- select_initial_step (scipy common.py:68-134), order = 4
+    double h_abs;
+    {
+        double interval = std::fabs(tf - t0);
+        double s0, s1, s2;
+        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, S.y, (const T*)nullptr, S.y, (T)atol0,
+                           (T)rtol, n, h->red_partial);
+        if ((rc = S.reduce(&s0, nullptr))) return rc;
+        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, S.K[6], (const T*)nullptr, S.y,
+                           (T)atol0, (T)rtol, n, h->red_partial);
+        if ((rc = S.reduce(&s1, nullptr))) return rc;
+        double d0 = std::sqrt(s0) / std::sqrt((double)n), d1 = std::sqrt(s1) / std::sqrt((double)n);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = std::min(h0, interval);
+        Lin8<T> L;
+        L.n = 1;
+        L.k[0] = S.K[6];
+        L.c[0] = (T)(h0 * direction);
+        hipLaunchKernelGGL(k_lincomb<T>, S.g1(), dim3(256), 0, s, S.y, L, S.ytmp, n);
+        S.rhs(S.ytmp, S.K[0]);
+        hipLaunchKernelGGL((k_norm_scaled<T, 1>), dim3(RB), dim3(256), 0, s, S.K[0], S.K[6], S.y, (T)atol0, (T)rtol,
+                           n, h->red_partial);
+        if ((rc = S.reduce(&s2, nullptr))) return rc;
+        double d2 = std::sqrt(s2) / std::sqrt((double)n) / h0;
+        double h1;
+        if (d1 <= 1e-15 && d2 <= 1e-15)
+            h1 = std::max(1e-6, h0 * 1e-3);
+        else
+            h1 = std::pow(0.01 / std::max(d1, d2), 1.0 / 5.0);
+        h_abs = std::min(std::min(100 * h0, h1), interval);
+    }
+    stats.h_abs0 = h_abs;
+    int n_steps_rec = 0;
+    if (t_steps && t_steps_cap > 0) t_steps[n_steps_rec++] = t;
+
+    int k_next = 0;                     // next t_eval index to emit
+    const size_t slice_elems = (size_t)(c.Ny - 2) * (c.Nx - 2);
+    const double err_exp = -1.0 / 5.0;
+
+    while (t != tf) {
+        double min_step = 10 * std::fabs(std::nextafter(t, direction * INFINITY) - t);
+        if (h_abs < min_step) h_abs = min_step;
+        bool accepted = false, rejected = false;
+        double t_new = t, hh = 0;
+        // FSAL: K0 <- f (swap pointers K0 <-> K6)
+        std::swap(S.K[0], S.K[6]);
+        while (!accepted) {
+            if (h_abs < min_step) {
+                oc_set_error("RK45: step size too small at t=%g", t);
+                return OC_ERR_SOLVER;
+            }
+            hh = h_abs * direction;
+            t_new = t + hh;
+            if (direction * (t_new - tf) > 0) t_new = tf;
+            hh = t_new - t;
+            h_abs = std::fabs(hh);
+            ++stats.n_attempt;
+            for (int sg = 1; sg < 6; ++sg) {
+                Lin8<T> L;
+                L.n = sg;
+                for (int j = 0; j < sg; ++j) {
+                    L.k[j] = S.K[j];
+                    L.c[j] = (T)(RK_A[sg][j] * hh);
+                }
+                hipLaunchKernelGGL(k_lincomb<T>, S.g1(), dim3(256), 0, s, S.y, L, S.ytmp, n);
+                S.rhs(S.ytmp, S.K[sg]);
+            }
+            {
+                Lin8<T> L;
+                L.n = 6;
+                for (int j = 0; j < 6; ++j) {
+                    L.k[j] = S.K[j];
+                    L.c[j] = (T)(RK_B[j] * hh);
+                }
+                hipLaunchKernelGGL(k_lincomb<T>, S.g1(), dim3(256), 0, s, S.y, L, S.ynew, n);
+                S.rhs(S.ynew, S.K[6]);
+            }
+            Lin8<T> E;
+            E.n = 7;
+            for (int j = 0; j < 7; ++j) {
+                E.k[j] = S.K[j];
+                E.c[j] = (T)(RK_E[j] * hh);
+            }
+            double atol_s = atol0 * scale_of();
+            hipLaunchKernelGGL(k_err_norm<T>, dim3(RB), dim3(256), 0, s, S.y, S.ynew, E, (T)atol_s, (T)rtol, n,
+                               h->red_partial);
+            double esum, ymax;
+            if ((rc = S.reduce(&esum, &ymax))) return rc;
+            double err = std::sqrt(esum) / std::sqrt((double)n);
+            if (!(err == err)) {
+                oc_set_error("RK45: NaN error norm at t=%g (state overflow?)", t);
+                return OC_ERR_SOLVER;
+            }
+            if (err < 1) {
+                double factor = (err == 0) ? 10.0 : std::min(10.0, 0.9 * std::pow(err, err_exp));
+                if (rejected) factor = std::min(1.0, factor);
+                h_abs *= factor;
+                accepted = true;
+                stats.h_min = std::min(stats.h_min, std::fabs(hh));
+                stats.h_max = std::max(stats.h_max, std::fabs(hh));
+                // ---- dense output for t_eval points in (t_new, t]  (scipy ivp.py:706-723)
+                while (k_next < nt && te[k_next] >= t_new) {
+                    int k = k_next++;
+                    bool want_v = (k >= 1);
+                    bool want_keep = keep_slot[k] >= 0;
+                    if (!want_v && !want_keep) continue;
+                    double x = (te[k] - t) / hh;
+                    double xp[4] = {x, x * x, x * x * x, x * x * x * x};
+                    Lin8<T> W;
+                    W.n = 7;
+                    for (int j = 0; j < 7; ++j) {
+                        double w = 0;
+                        for (int p = 0; p < 4; ++p) w += RK_P[j][p] * xp[p];
+                        W.k[j] = S.K[j];
+                        W.c[j] = (T)(hh * w);
+                    }
+                    double* kp = want_keep ? phi_keep + (size_t)keep_slot[k] * n : nullptr;
+                    hipLaunchKernelGGL(k_dense<T>, S.g1(), dim3(256), 0, s, S.y, W, S.phi_tmp, kp,
+                                       std::ldexp(1.0, expo), n);
+                    if (want_v) {
+                        int sidx = nt - 1 - k;
+                        T* vx = (T*)vx_out + (size_t)sidx * slice_elems;
+                        T* vy = (T*)vy_out + (size_t)sidx * slice_elems;
+                        hipLaunchKernelGGL((k_vels<T, T>), S.g2(c.Nx - 2, c.Ny - 2), S.b2(), 0, s, S.phi_tmp, vx, vy,
+                                           c.Ny, c.Nx, (T)(c.lim * scale_of()), (T)c.lim, (T)c.mu,
+                                           (T)(1.0 / (2 * c.dx)), (T)(1.0 / (2 * c.dy)));
+                        ++stats.n_slices_written;
+                    }
+                }
+                // ---- advance
+                std::swap(S.y, S.ynew);
+                t = t_new;
+                ++stats.n_accept;
+                if (t_steps && n_steps_rec < t_steps_cap) t_steps[n_steps_rec++] = t;
+                // ---- range management (fp32): keep max|y| below 2^64
+                if (sizeof(T) == 4 && ymax > 0x1p64) {
+                    int e = (int)std::floor(std::log2(ymax)) - 32;
+                    T sc = (T)std::ldexp(1.0, -e);
+                    hipLaunchKernelGGL(k_scale<T>, S.g1(), dim3(256), 0, s, S.y, S.K[6], sc, n);
+                    expo += e;
+                    ++stats.n_rescale;
+                }
+            } else {
+                h_abs *= std::max(0.2, 0.9 * std::pow(err, err_exp));
+                rejected = true;
+            }
+        }
+        if (direction * (t - tf) >= 0) break;
+    }
+    OC_HIP_CHECK(hipStreamSynchronize(s));
+    stats.nfev = S.nfev;
+    stats.final_exponent = expo;
+    if (st) *st = stats;
+    return OC_OK;
+}
+
+}   // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" int oc_hjb_make_coef(oc_handle* h, int dtype, const float* V, const void* m, void* coef, void* stream) {
+    OC_REQUIRE(h && V && coef, "null argument");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const oc_config& c = h->cfg;
+    double inv = 1.0 / (c.mu * c.sigma * c.sigma);
+    int64_t n = h->ncell;
+    dim3 g((unsigned)((n + 255) / 256));
+    if (dtype == OC_F32)
+        hipLaunchKernelGGL(k_make_coef<float>, g, dim3(256), 0, s, V, (const float*)m, c.g, inv, (float*)coef, n);
+    else if (dtype == OC_F64)
+        hipLaunchKernelGGL(k_make_coef<double>, g, dim3(256), 0, s, V, (const double*)m, c.g, inv, (double*)coef, n);
+    else
+        OC_REQUIRE(false, "bad dtype");
+    OC_HIP_CHECK(hipGetLastError());
+    return OC_OK;
+}
+
+extern "C" int oc_hjb_rhs(oc_handle* h, int dtype, const void* phi, const void* coef, void* out, void* stream) {
+    OC_REQUIRE(h && phi && coef && out, "null argument");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const oc_config& c = h->cfg;
+    double a = -0.5 * c.sigma * c.sigma / (c.dx * c.dy);
+    dim3 b(64, 4), g((c.Nx + 63) / 64, (c.Ny + 3) / 4);
+    if (dtype == OC_F32)
+        hipLaunchKernelGGL(k_rhs<float>, g, b, 0, s, (const float*)phi, (const float*)coef, (float*)out, c.Ny, c.Nx,
+                           (float)a);
+    else if (dtype == OC_F64)
+        hipLaunchKernelGGL(k_rhs<double>, g, b, 0, s, (const double*)phi, (const double*)coef, (double*)out, c.Ny,
+                           c.Nx, a);
+    else
+        OC_REQUIRE(false, "bad dtype");
+    OC_HIP_CHECK(hipGetLastError());
+    return OC_OK;
+}
+
+extern "C" int oc_hjb_vels(oc_handle* h, int dtype, const void* phi, double scale, void* vx, void* vy, void* stream) {
+    OC_REQUIRE(h && phi && vx && vy, "null argument");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const oc_config& c = h->cfg;
+    dim3 b(64, 4), g((c.Nx - 2 + 63) / 64, (c.Ny - 2 + 3) / 4);
+    double i2x = 1.0 / (2 * c.dx), i2y = 1.0 / (2 * c.dy);
+    if (dtype == OC_F32)
+        hipLaunchKernelGGL((k_vels<double, float>), g, b, 0, s, (const double*)phi, (float*)vx, (float*)vy, c.Ny,
+                           c.Nx, c.lim * scale, c.lim, c.mu, i2x, i2y);
+    else if (dtype == OC_F64)
+        hipLaunchKernelGGL((k_vels<double, double>), g, b, 0, s, (const double*)phi, (double*)vx, (double*)vy, c.Ny,
+                           c.Nx, c.lim * scale, c.lim, c.mu, i2x, i2y);
+    else
+        OC_REQUIRE(false, "bad dtype");
+    OC_HIP_CHECK(hipGetLastError());
+    return OC_OK;
+}
+
+extern "C" int oc_hjb_solve(oc_handle* h, int dtype, const void* coef, double T, int32_t nt, void* vx_out,
+                            void* vy_out, const int32_t* keep_idx, int32_t n_keep, double* phi_keep, double* t_steps,
+                            int32_t t_steps_cap, oc_hjb_stats* stats, void* stream) {
+    OC_REQUIRE(h && coef, "null argument");
+    OC_REQUIRE(nt <= 1 || (vx_out && vy_out), "null output field");
+    OC_REQUIRE(n_keep == 0 || (keep_idx && phi_keep), "keep list without buffer");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    if (dtype == OC_F32)
+        rc = hjb_solve_t<float>(h, coef, T, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, t_steps, t_steps_cap,
+                                stats, s);
+    else if (dtype == OC_F64)
+        rc = hjb_solve_t<double>(h, coef, T, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, t_steps, t_steps_cap,
+                                 stats, s);
+    else {
+        oc_set_error("bad dtype %d", dtype);
+        return OC_ERR_ARG;
+    }
+    if (rc == OC_OK) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            oc_set_error("hjb_solve: %s", hipGetErrorString(e));
+            return OC_ERR_HIP;
+        }
+        if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return rc;
+}

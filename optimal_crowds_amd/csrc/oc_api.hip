@@ -1,0 +1,138 @@
+// Handle lifetime, error reporting and kernel timers of liboc_hip.so.
+#include "oc_internal.h"
+#include <cstdarg>
+
+static thread_local char g_err[1024] = "";
+
+void oc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int oc_abi_version(void) { return OC_ABI_VERSION; }
+extern "C" const char* oc_last_error(void) { return g_err; }
+
+extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host, const double* Y0_host,
+                         oc_handle** out) {
+    OC_REQUIRE(cfg && out && X0_host && Y0_host, "null argument");
+    OC_REQUIRE(cfg->Nx >= 3 && cfg->Ny >= 3, "grid must be at least 3x3");
+    OC_REQUIRE(cfg->max_keys >= 1 && cfg->max_agents >= 0, "bad capacities");
+    int ndev = 0;
+    OC_HIP_CHECK(hipGetDeviceCount(&ndev));
+    OC_REQUIRE(device >= 0 && device < ndev, "no such HIP device");
+    OC_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    OC_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        oc_set_error("liboc_hip is built for gfx950 (MI355X); device %d is %s", device, prop.gcnArchName);
+        return OC_ERR_STATE;
+    }
+    oc_handle* h = new oc_handle();
+    h->device = device;
+    h->cfg = *cfg;
+    h->ncell = (int64_t)cfg->Nx * cfg->Ny;
+    h->fields.resize(cfg->max_keys);
+    h->wallmaps.resize(cfg->max_keys);
+    h->rects.resize(cfg->max_keys);
+    OC_HIP_CHECK(hipMalloc(&h->X0, sizeof(double) * cfg->Nx));
+    OC_HIP_CHECK(hipMalloc(&h->Y0, sizeof(double) * cfg->Ny));
+    OC_HIP_CHECK(hipMemcpy(h->X0, X0_host, sizeof(double) * cfg->Nx, hipMemcpyHostToDevice));
+    OC_HIP_CHECK(hipMemcpy(h->Y0, Y0_host, sizeof(double) * cfg->Ny, hipMemcpyHostToDevice));
+    h->red_blocks = 4096;
+    OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * 4 * h->red_blocks));
+    OC_HIP_CHECK(hipMalloc(&h->red_out, sizeof(double) * 16));
+    OC_HIP_CHECK(hipHostMalloc(&h->red_host, sizeof(double) * 16));
+    *out = h;
+    return OC_OK;
+}
+
+extern "C" int oc_destroy(oc_handle* h) {
+    if (!h) return OC_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(h->X0);
+    (void)hipFree(h->Y0);
+    (void)hipFree(h->hjb_buf);
+    (void)hipFree(h->red_partial);
+    (void)hipFree(h->red_out);
+    (void)hipHostFree(h->red_host);
+    for (auto& w : h->wallmaps) {
+        (void)hipFree(w.left);
+        (void)hipFree(w.right);
+    }
+    (void)hipFree(h->key_tables_dev);
+    (void)hipFree(h->gcfm_buf);
+    (void)hipFree(h->sort_tmp);
+    for (auto& kv : h->timers) {
+        if (kv.second.a) (void)hipEventDestroy(kv.second.a);
+        if (kv.second.b) (void)hipEventDestroy(kv.second.b);
+    }
+    delete h;
+    return OC_OK;
+}
+
+extern "C" int oc_set_profiling(oc_handle* h, int enabled) {
+    OC_REQUIRE(h, "null handle");
+    h->profiling = enabled != 0;
+    return OC_OK;
+}
+
+void oc_timer_begin(oc_handle* h, const char* name, hipStream_t s) {
+    if (!h->profiling) return;
+    oc_timer& t = h->timers[name];
+    if (!t.a) {
+        (void)hipEventCreate(&t.a);
+        (void)hipEventCreate(&t.b);
+    }
+    (void)hipEventRecord(t.a, s);
+}
+
+void oc_timer_end(oc_handle* h, const char* name, hipStream_t s) {
+    if (!h->profiling) return;
+    oc_timer& t = h->timers[name];
+    (void)hipEventRecord(t.b, s);
+    t.valid = true;
+}
+
+extern "C" double oc_last_kernel_ms(oc_handle* h, const char* name) {
+    if (!h || !name) return -1.0;
+    auto it = h->timers.find(name);
+    if (it == h->timers.end() || !it->second.valid) return -1.0;
+    if (hipEventSynchronize(it->second.b) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, it->second.a, it->second.b) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+extern "C" int oc_set_field(oc_handle* h, int key, int dtype, const void* vx, const void* vy, int32_t nslice_alloc,
+                            int32_t nt_opt) {
+    OC_REQUIRE(h && key >= 0 && key < (int)h->fields.size(), "bad key");
+    OC_REQUIRE(dtype == OC_F32 || dtype == OC_F64, "bad dtype");
+    oc_field_desc& f = h->fields[key];
+    f.dtype = dtype;
+    f.vx = vx;
+    f.vy = vy;
+    f.nslice_alloc = nslice_alloc;
+    f.nt_opt = nt_opt;
+    h->key_tables_dirty = true;
+    return OC_OK;
+}
+
+extern "C" int oc_set_key_targets(oc_handle* h, int key, const double* rects, int32_t n) {
+    OC_REQUIRE(h && key >= 0 && key < (int)h->rects.size(), "bad key");
+    OC_REQUIRE(n >= 0 && n <= OC_MAX_TARGET_RECTS, "too many target rectangles for one key");
+    OC_REQUIRE(n == 0 || rects, "null rects");
+    h->rects[key].n = n;
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 4; ++c) h->rects[key].r[i][c] = rects[4 * i + c];
+    h->key_tables_dirty = true;
+    return OC_OK;
+}
+
+extern "C" int oc_set_resort_every(oc_handle* h, int32_t steps) {
+    OC_REQUIRE(h, "null handle");
+    h->resort_every = steps > 0 ? steps : 16;
+    return OC_OK;
+}

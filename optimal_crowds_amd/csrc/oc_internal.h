@@ -1,0 +1,97 @@
+// Internal declarations shared by the translation units of liboc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/oc_hip.h"
+
+void oc_set_error(const char* fmt, ...);
+
+#define OC_HIP_CHECK(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            oc_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));  \
+            return OC_ERR_HIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+#define OC_REQUIRE(cond, msg)                                              \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            oc_set_error("%s:%d: %s (%s)", __FILE__, __LINE__, msg, #cond); \
+            return OC_ERR_ARG;                                             \
+        }                                                                  \
+    } while (0)
+
+struct oc_field_desc {
+    int dtype = -1;
+    const void* vx = nullptr;
+    const void* vy = nullptr;
+    int32_t nslice_alloc = 0;
+    int32_t nt_opt = 0;
+};
+
+struct oc_wallmap {
+    int32_t* left = nullptr;    // (Ny, Nx): largest site column <= j, or -1
+    int32_t* right = nullptr;   // (Ny, Nx): smallest site column >= j, or Nx
+    double off = 0.0;           // vmin * 10e3 (the reference adds V*10e3 before the argmin)
+    bool built = false;
+};
+
+#define OC_MAX_TARGET_RECTS 8
+
+struct oc_key_rects {
+    int32_t n = 0;
+    double r[OC_MAX_TARGET_RECTS][4];
+};
+
+struct oc_timer {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool valid = false;
+};
+
+struct oc_handle {
+    int device = 0;
+    oc_config cfg;
+    int64_t ncell = 0;
+    double* X0 = nullptr;       // device (Nx)
+    double* Y0 = nullptr;       // device (Ny)
+    // ---- HJB scratch (allocated lazily per dtype size)
+    size_t hjb_elem = 0;        // element size the scratch was allocated for
+    void* hjb_buf = nullptr;    // y, ynew, ytmp, K0..K6, phi_tmp  (11 arrays)
+    double* red_partial = nullptr;   // per-block partial sums
+    double* red_out = nullptr;       // device: few doubles
+    double* red_host = nullptr;      // pinned host mirror
+    int32_t red_blocks = 0;
+    // ---- per-key data
+    std::vector<oc_field_desc> fields;
+    std::vector<oc_wallmap> wallmaps;
+    std::vector<oc_key_rects> rects;
+    void* key_tables_dev = nullptr;  // device copy of per-key descriptors for the step kernels
+    bool key_tables_dirty = true;
+    // ---- GCFM scratch
+    int32_t resort_every = 16;
+    int32_t steps_since_sort = 1 << 30;
+    int32_t sorted_N = -1;
+    void* gcfm_buf = nullptr;   // carved in gcfm.hip
+    size_t gcfm_bytes = 0;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    // ---- profiling
+    bool profiling = false;
+    std::map<std::string, oc_timer> timers;
+};
+
+// timers (oc_api.hip)
+void oc_timer_begin(oc_handle* h, const char* name, hipStream_t s);
+void oc_timer_end(oc_handle* h, const char* name, hipStream_t s);
+
+// sort.hip: order[] = agent indices sorted by (cellkey, index); keys/vals scratch live in the handle
+int oc_sort_pairs(oc_handle* h, uint32_t* keys_in, uint32_t* keys_out, int32_t* vals_in, int32_t* vals_out,
+                  int n, int end_bit, hipStream_t s);

@@ -1,0 +1,213 @@
+"""Device engine: owns the liboc_hip handle and the HBM buffers (torch tensors used purely as device
+memory + stream plumbing) for one simulation.  Everything numerical happens in the HIP library.
+
+Buffers in HBM (row-major, N agents, K keys, grid Ny x Nx, nt0 = round(T/dt)):
+  V[k]      float32 (Ny,Nx)      finalised potential of key k ({-100,0,1})
+  coef      dtype   (Ny,Nx)      (V + g m)/(mu sigma^2), NaN on walls
+  vx[k],vy[k] dtype (nt0-1, Ny-2, Nx-2)   direction field of key k  (the big one: 33.5 GB/key at 2048^2 fp32)
+  x,y,vx,vy,v_des,agent_time float64 (N);  status uint8 (N);  key int32 (N)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import OC_F32, OC_F64, OcAgents, OcConfig, OcHjbStats, check
+
+LIM = 10e-3          # reference optimals.py:95
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Engine:
+    def __init__(self, cfg, room_length, room_height, Nx, Ny, X0, Y0, n_keys, max_agents,
+                 device="cuda:0", dtype="float32", wall_search_radius=0.0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.OcError("no HIP device visible: optimal_crowds_amd needs an MI355X (there is no CPU path)")
+        self.device = torch.device(device)
+        self.dev_index = self.device.index or 0
+        self.dtype = OC_F32 if dtype in ("float32", "f32", torch.float32) else OC_F64
+        self.tdtype = torch.float32 if self.dtype == OC_F32 else torch.float64
+        self.Nx, self.Ny, self.n_keys = Nx, Ny, n_keys
+        hp = cfg["hjb_params"]
+        c = OcConfig()
+        c.Ny, c.Nx = Ny, Nx
+        c.dx = c.dy = cfg["grid_step"]
+        c.room_length, c.room_height = room_length, room_height
+        c.dt = cfg["dt"]
+        c.sigma, c.mu, c.g = hp["sigma"], hp["mu"], hp["g"]
+        c.lim, c.rtol, c.atol = LIM, cfg.get("rtol", 1e-3), cfg.get("atol", 1e-6)
+        c.a_min = cfg["b_min"]        # reference quirk: a_min := b_min (simulations.py:88)
+        c.tau_a, c.b_min, c.b_max = cfg["tau_a"], cfg["b_min"], cfg["b_max"]
+        c.eta, c.eta_walls = cfg["eta"], cfg["eta_walls"]
+        c.repulsion_cutoff, c.v_max, c.relaxation = cfg["repulsion_cutoff"], cfg["v_max"], cfg["relaxation"]
+        c.noise_amp = hp["sigma"] / 2
+        c.wall_search_radius = wall_search_radius
+        c.max_agents, c.max_keys = max(int(max_agents), 1), max(int(n_keys), 1)
+        self.cfg_struct = c
+        X0 = np.ascontiguousarray(X0, dtype=np.float64)
+        Y0 = np.ascontiguousarray(Y0, dtype=np.float64)
+        h = C.c_void_p()
+        check(self.lib.oc_create(self.dev_index, C.byref(c), X0.ctypes.data_as(C.c_void_p),
+                                 Y0.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self.h = h
+        self.V = [None] * n_keys
+        self.fields = [None] * n_keys
+        self.coef = torch.empty((Ny, Nx), dtype=self.tdtype, device=self.device)
+        self.counters = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.agents = None
+        self._astruct = None
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            torch.cuda.synchronize(self.device)
+            self.lib.oc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_profiling(self, on=True):
+        check(self.lib.oc_set_profiling(self.h, int(on)))
+
+    def last_kernel_ms(self, name):
+        return self.lib.oc_last_kernel_ms(self.h, name.encode())
+
+    # ------------------------------------------------------------------ per-key data
+    def set_potential(self, key, V_host, rects):
+        """V_host: finalised potential (Ny,Nx) float64 of key; rects: (n,4) exit rectangles of its targets."""
+        Vt = torch.as_tensor(np.ascontiguousarray(V_host, dtype=np.float32)).to(self.device)
+        self.V[key] = Vt
+        check(self.lib.oc_wallmap_build(self.h, key, _ptr(Vt), C.c_float(float(V_host.min())), self.stream()))
+        r = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
+        check(self.lib.oc_set_key_targets(self.h, key, r.ctypes.data_as(C.c_void_p), len(r)))
+
+    def alloc_field(self, key, nslice):
+        shape = (max(nslice, 0), self.Ny - 2, self.Nx - 2)
+        vx = torch.zeros(shape, dtype=self.tdtype, device=self.device)
+        vy = torch.zeros(shape, dtype=self.tdtype, device=self.device)
+        self.fields[key] = [vx, vy, nslice, 0]
+        return vx, vy
+
+    def make_coef(self, key, m=None, out=None):
+        out = self.coef if out is None else out
+        if m is not None:
+            m = m.to(device=self.device, dtype=self.tdtype).contiguous()
+        check(self.lib.oc_hjb_make_coef(self.h, self.dtype, _ptr(self.V[key]), _ptr(m), _ptr(out), self.stream()))
+        return out
+
+    def rhs(self, phi, coef=None):
+        coef = self.coef if coef is None else coef
+        out = torch.empty_like(phi)
+        check(self.lib.oc_hjb_rhs(self.h, self.dtype, _ptr(phi), _ptr(coef), _ptr(out), self.stream()))
+        return out
+
+    def vels(self, phi64, scale=1.0):
+        vx = torch.empty((self.Ny - 2, self.Nx - 2), dtype=self.tdtype, device=self.device)
+        vy = torch.empty_like(vx)
+        check(self.lib.oc_hjb_vels(self.h, self.dtype, _ptr(phi64), float(scale), _ptr(vx), _ptr(vy), self.stream()))
+        return vx, vy
+
+    def solve(self, key, T, nt, m=None, keep=None, want_steps=False):
+        """HJB solve for `key` with horizon nt = round((T - t)/dt); fills slices 0..nt-2 of the key's field.
+        keep: list of t_eval indices whose phi is returned (float64, (len, Ny, Nx))."""
+        vx, vy, nslice, _ = self.fields[key]
+        if nt - 1 > nslice:
+            raise ValueError("horizon exceeds allocated field slices")
+        self.make_coef(key, m)
+        stats = OcHjbStats()
+        keep_arr = phi_keep = None
+        n_keep = 0
+        if keep is not None and len(keep):
+            keep_arr = np.ascontiguousarray(keep, dtype=np.int32)
+            n_keep = len(keep_arr)
+            phi_keep = torch.empty((n_keep, self.Ny, self.Nx), dtype=torch.float64, device=self.device)
+        cap = 100000 if want_steps else 0
+        tsteps = np.zeros(max(cap, 1))
+        check(self.lib.oc_hjb_solve(self.h, self.dtype, _ptr(self.coef), float(T), int(nt), _ptr(vx), _ptr(vy),
+                                    keep_arr.ctypes.data_as(C.c_void_p) if keep_arr is not None else None, n_keep,
+                                    _ptr(phi_keep), tsteps.ctypes.data_as(C.c_void_p) if cap else None, cap,
+                                    C.byref(stats), self.stream()))
+        self.fields[key][3] = nt
+        check(self.lib.oc_set_field(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt)))
+        st = stats.as_dict()
+        if want_steps:
+            st["t_steps"] = tsteps[:st["n_accept"] + 1].copy()
+        return st, phi_keep
+
+    def set_field_horizon(self, key, nt):
+        vx, vy, nslice, _ = self.fields[key]
+        self.fields[key][3] = nt
+        check(self.lib.oc_set_field(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt)))
+
+    # ------------------------------------------------------------------ agents
+    def set_agents(self, x, y, vx, vy, v_des, key, status=None, agent_time=None):
+        dev, f64 = self.device, torch.float64
+        N = len(x)
+        mk = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        st = np.ones(N, dtype=np.uint8) if status is None else np.ascontiguousarray(status, dtype=np.uint8)
+        self.agents = dict(
+            N=N, x=mk(x), y=mk(y), vx=mk(vx), vy=mk(vy), v_des=mk(v_des),
+            status=torch.as_tensor(st).to(dev),
+            key=torch.as_tensor(np.ascontiguousarray(key, dtype=np.int32)).to(dev),
+            agent_time=mk(np.zeros(N) if agent_time is None else agent_time))
+        a = OcAgents()
+        a.N = N
+        for f in ("x", "y", "vx", "vy", "v_des", "status", "key", "agent_time"):
+            setattr(a, f, self.agents[f].data_ptr())
+        self._astruct = a
+
+    def get_state(self):
+        a = self.agents
+        return {k: a[k].cpu().numpy() for k in ("x", "y", "vx", "vy", "status", "agent_time")}
+
+    def lookup(self, simu_step):
+        N = self.agents["N"]
+        des = torch.empty((N, 2), dtype=torch.float64, device=self.device)
+        err = torch.zeros(2, dtype=torch.int32, device=self.device)
+        check(self.lib.oc_field_lookup(self.h, C.byref(self._astruct), int(simu_step), _ptr(des), _ptr(err),
+                                       self.stream()))
+        return des, int(err[0].item())
+
+    def wall_force(self):
+        N = self.agents["N"]
+        idx = torch.empty(N, dtype=torch.int64, device=self.device)
+        f = torch.empty((N, 2), dtype=torch.float64, device=self.device)
+        check(self.lib.oc_wall_force(self.h, C.byref(self._astruct), _ptr(idx), _ptr(f), self.stream()))
+        return idx, f
+
+    def pair_force(self):
+        N = self.agents["N"]
+        f = torch.empty((N, 2), dtype=torch.float64, device=self.device)
+        check(self.lib.oc_pair_force(self.h, C.byref(self._astruct), _ptr(f), self.stream()))
+        return f
+
+    def step(self, simu_step, noise=None, seed=0, sync=True):
+        """One synchronous GCFM step in place.  noise: (N,2) float64 tensor/array or None (device Philox)."""
+        if noise is not None and not torch.is_tensor(noise):
+            noise = torch.as_tensor(np.ascontiguousarray(noise, dtype=np.float64)).to(self.device)
+        check(self.lib.oc_gcfm_step(self.h, C.byref(self._astruct), int(simu_step), _ptr(noise),
+                                    C.c_uint64(int(seed)), _ptr(self.counters), self.stream()))
+        if sync:
+            c = self.counters.cpu().numpy()
+            return int(c[0]), int(c[1]), int(c[2])
+        return None
+
+    def density(self, sigma, V_all=None, trunc_sigmas=6.0, out_dtype=None):
+        dt = self.dtype if out_dtype is None else out_dtype
+        out = torch.empty((self.Ny, self.Nx), dtype=torch.float32 if dt == OC_F32 else torch.float64,
+                          device=self.device)
+        check(self.lib.oc_density(self.h, dt, C.byref(self._astruct), float(sigma), _ptr(V_all),
+                                  float(trunc_sigmas), _ptr(out), self.stream()))
+        return out
