@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- simulation steps/sec of the optimal_crowds hot path (HJB solve + GCFM update) on MI355X.
+
+Workload (BASELINE.json configs[3], the config the metric is quoted on): room `metro_station`,
+204.75 m -> 2048 x 2048 grid (grid_step 0.1), 100 000 agents, 2 target keys, T = 20 s -> nt = 1000.
+
+A "step" is one simulation step of `simulation.run()`: one GCFM update of every agent; the HJB solve of every
+key happens once per nt steps, exactly where run() does it (before step 0), INSIDE the timed region.  With the
+default --steps 1000 the timed region is one complete run: K solves + 1000 steps.  For other K the region holds
+ceil(K/nt) solve rounds.  Inputs (potentials, agent state) are resident in HBM when the clock starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload metro_station|slalom|exit_opposite|room_test]
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs an independent replica of the
+workload ("replicas only"): value = N * K / max-over-ranks time, scaling = weak.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+WORKLOADS = {   # name -> (room, grid_step, T)
+    "metro_station": ("metro_station", 0.1, 20.0),
+    "slalom": ("slalom", 0.1, 20.0),
+    "exit_opposite": ("exit_opposite", 0.1, 20.0),
+    "room_test": ("room_test", 0.05, 20.0),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def build_sim(workload, seed=20240807):
+    import io
+    import contextlib
+    from optimal_crowds_amd import host, simulations
+    room, gs, T = WORKLOADS[workload]
+    cfg = copy.deepcopy(host.load_config(os.path.join(REPO, "optimal_crowds_amd", "config.json")))
+    cfg["grid_step"] = gs
+    np.random.seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim = simulations.simulation(room, T, config=cfg, noise="device", seed=seed, record=False, history=False,
+                                     wall_search_radius=25.0)
+    return sim, cfg
+
+
+def solve_round(sim):
+    """what run() does before the first step: one HJB solve per key (m = 0 at step 0)."""
+    stats = []
+    for k, key in enumerate(sim._key_names):
+        st, _ = sim._engine.solve(k, sim.T, sim._nt0, m=None)
+        stats.append(st)
+    return stats
+
+
+def run_steps(sim, K, nt, timed_stats=None):
+    eng = sim._engine
+    done = 0
+    while done < K:
+        if done % nt == 0:
+            st = solve_round(sim)
+            if timed_stats is not None:
+                timed_stats.append(st)
+        eng.step(done % nt, noise=None, seed=sim._seed + done // nt, sync=False)
+        done += 1
+
+
+def cpu_baseline(sim, cfg, nfev, n_accept, budget_s=20.0):
+    """Oracle (NumPy float64 restatement of the reference) timed on this host, 1 core, on a bounded sample:
+    HJB: RHS calls at full grid size extrapolated by the solver's own nfev (+ dense output and vels per slice);
+    GCFM: full per-agent work for a sample of agents against all N."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from oracle import oc_oracle as oc
+    hp = cfg["hjb_params"]
+    Ny, Nx = sim.Ny, sim.Nx
+    key = sim._key_names[0]
+    V = sim.Vs[key]
+    m = np.zeros_like(V)
+    phi = np.ones(Ny * Nx)
+    t0 = time.perf_counter()
+    nr = 0
+    while time.perf_counter() - t0 < budget_s * 0.25:
+        phi = phi + 1e-3 * oc.hjb_rhs(phi, V, m, hp["sigma"], hp["mu"], hp["g"], cfg["grid_step"], cfg["grid_step"])
+        nr += 1
+    t_rhs = (time.perf_counter() - t0) / nr
+    t0 = time.perf_counter()
+    nv = 0
+    while time.perf_counter() - t0 < budget_s * 0.15:
+        oc.vels(phi, Ny, Nx, hp["mu"], cfg["grid_step"], cfg["grid_step"])
+        nv += 1
+    t_vels = (time.perf_counter() - t0) / nv
+    nt = sim._nt0
+    # per attempted RK step: 6 RHS + ~8 axpy-like passes (counted inside t_rhs scale: 1 RHS ~ 10 array passes)
+    t_hjb = nfev * t_rhs * 1.3 + (nt - 1) * (t_vels + 0.8 * t_rhs)
+    # GCFM sample
+    st = sim._engine.get_state()
+    x, y, vx, vy = st["x"], st["y"], st["vx"], st["vy"]
+    status = st["status"].astype(bool)
+    N = sim.N
+    rng = np.random.RandomState(0)
+    sample = rng.choice(N, size=min(N, 4000), replace=False)
+    wm = oc.WallMap(sim._X0, sim._Y0, V)
+    X, Y = None, None
+    t0 = time.perf_counter()
+    ns = 0
+    for i in sample:
+        if time.perf_counter() - t0 > budget_s * 0.6:
+            break
+        dist = np.sqrt((x - x[i]) ** 2 + (y - y[i]) ** 2)
+        sel = status & (dist < cfg["repulsion_cutoff"])
+        sel[i] = False
+        js = np.nonzero(sel)[0]
+        if len(js):
+            oc.pair_force(np.array((x[i], y[i])), np.array((vx[i], vy[i])), sim._v_des[i],
+                          np.column_stack([x[js], y[js]]), np.column_stack([vx[js], vy[js]]), cfg).sum(axis=0)
+        wm.query(x[i], y[i])
+        ns += 1
+    t_agent = (time.perf_counter() - t0) / max(ns, 1)
+    t_step = t_agent * int(status.sum())
+    K = len(sim._key_names)
+    value = nt / (K * t_hjb + nt * t_step)
+    return {"value": value, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": "NumPy float64 oracle: %d full-grid RHS calls (%.3f s each) x nfev=%d + %d vels calls; "
+                      "GCFM: %d of %d agents vs all agents (%.2e s/agent); extrapolated to K=%d keys, nt=%d steps"
+                      % (nr, t_rhs, nfev, nv, ns, N, t_agent, K, nt),
+            "t_hjb_solve_s": t_hjb, "t_step_s": t_step}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="metro_station", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import optimal_crowds_amd.engine  # noqa: F401  (fails loudly without the HIP library)
+    t_init = time.perf_counter()
+    sim, cfg = build_sim(args.workload)
+    t_init = time.perf_counter() - t_init
+    eng = sim._engine
+    nt = sim._nt0
+    K, W = args.steps, args.warmup
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup (untimed): one solve round + W steps
+    if W > 0:
+        run_steps(sim, W, nt)
+    barrier()
+    # ---- timed region: exactly K steps (+ the solve rounds run() would do)
+    eng.set_profiling(True)
+    stats = []
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(sim, K, nt, stats)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    # ---- breakdown (untimed extras for the report)
+    t_hjb = sum(s["seconds"] for rnd in stats for s in rnd)
+    nfev = stats[0][0]["nfev"] if stats else 0
+    n_att = stats[0][0]["n_attempt"] if stats else 0
+    n_acc = stats[0][0]["n_accept"] if stats else 0
+    ncell = sim.Nx * sim.Ny
+    pair_ms = eng.last_kernel_ms("gcfm_pair")
+    wall_ms = eng.last_kernel_ms("gcfm_wall")
+    out_ms = eng.last_kernel_ms("hjb_out")
+    out_launch_bytes = eng.lib.oc_last_kernel_ms(eng.h, b"hjb_out_bytes")
+    roof = None
+    if out_ms and out_ms > 0 and out_launch_bytes > 0:
+        ach = out_launch_bytes / (out_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "hjb_out (dense output + direction-field writer)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+    result = {
+        "metric": "sim steps/sec (HJB sweep + GCFM update), 2048^2 grid x 100k agents",
+        "value": world * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s %dx%d grid, %d agents, %d keys, T=%g (nt=%d), recompute=False"
+                               % (args.workload, sim.Nx, sim.Ny, sim.N, len(sim._key_names), sim.T, nt),
+                   "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
+                   "noise": "device Philox", "agent_state": "f64", "pair_math": "f32", "hjb_state": "f32"},
+        "roofline": roof,
+        "breakdown": {"hjb_solve_s_total": t_hjb, "hjb_solves": sum(len(r) for r in stats),
+                      "gcfm_ms_per_step": 1e3 * (elapsed - t_hjb) / K, "nfev": nfev, "rk_attempts": n_att,
+                      "rk_accepted": n_acc, "pair_kernel_ms_last": pair_ms, "wall_kernel_ms_last": wall_ms,
+                      "init_s": t_init, "active_agents_end": int(eng.counters.cpu()[2])},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sim, cfg, nfev, n_acc)
+        result["cpu_baseline"]["host_cpus"] = os.cpu_count()
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -180,6 +180,23 @@ class Engine:
                                        self.stream()))
         return des, int(err[0].item())
 
+    def _with_probe(self, x, y, vx, vy, v_des, key, fn):
+        """Run fn() with a temporary agent set (single-point queries of the facade), then restore."""
+        saved = (self.agents, self._astruct)
+        try:
+            self.set_agents(x, y, vx, vy, v_des, key)
+            return fn()
+        finally:
+            self.agents, self._astruct = saved
+
+    def lookup_points(self, key, xs, ys, simu_step):
+        n = len(xs)
+
+        def fn():
+            des, err = self.lookup(simu_step)
+            return des.cpu().numpy(), err
+        return self._with_probe(xs, ys, np.zeros(n), np.zeros(n), np.ones(n), np.full(n, key, dtype=np.int32), fn)
+
     def wall_force(self):
         N = self.agents["N"]
         idx = torch.empty(N, dtype=torch.int64, device=self.device)

@@ -1,0 +1,104 @@
+"""`optimals.optimals(room, V, T, target)` -- the reference's HJB / floor-field object
+(reference optimals.py:11-250) backed by the HIP solver.
+
+compute_optimal_velocity(t, m) runs the Cole-Hopf HJB solve (RK45 with SciPy's controller and dense output)
+on the GPU and leaves the direction field in HBM; vx_opt / vy_opt are array-like views that copy slices to the
+host on demand (the field is 33.5 GB per key at 2048^2, nt = 1000).
+"""
+import numpy as np
+import torch
+
+from . import host
+
+
+class DeviceField:
+    """Read-only array-like over a (nslice, Ny-2, Nx-2) device tensor; indexing returns float64 NumPy."""
+
+    def __init__(self, tensor):
+        self._t = tensor
+
+    @property
+    def shape(self):
+        return tuple(self._t.shape)
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float64)
+
+    def __len__(self):
+        return self._t.shape[0]
+
+    def __getitem__(self, idx):
+        return self._t[idx].double().cpu().numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._t.double().cpu().numpy()
+        return a if dtype is None else a.astype(dtype)
+
+
+class optimals:
+    def __init__(self, room, V, T, target, *, config=None, device="cuda:0", dtype="float32", _sim=None,
+                 _key_index=0):
+        var_config = _sim._cfg if _sim is not None else host.load_config(config)
+        var_room = _sim._room if _sim is not None else host.load_room(room)
+        self.room_length = var_room['room_length']
+        self.room_height = var_room['room_height']
+        self.grid_step = var_config['grid_step']
+        self.Nx, self.Ny = host.grid_dims(self.room_length, self.room_height, self.grid_step)
+        self.dx = self.dy = self.grid_step
+        self._X0, self._Y0 = host.axes(self.room_length, self.room_height, self.Nx, self.Ny)
+        hp = var_config['hjb_params']
+        self.sigma, self.mu = hp['sigma'], hp['mu']
+        self.pot, self.pot_target, self.g = hp['wall_potential'], hp['target_potential'], hp['g']
+        self.dt = var_config['dt']
+        self.T = T
+        self.nt_opt = round(self.T / self.dt)
+        self.target = target
+        self.V = host.finalize_potential(V, var_config)      # in place, like the reference (optimals.py:89-91)
+        self.lim = 10e-3
+        self.t = 0.
+        self.stats = None
+        self._k = _key_index
+        if _sim is not None:
+            self._engine = _sim._engine
+        else:
+            from .engine import Engine
+            self._engine = Engine(var_config, self.room_length, self.room_height, self.Nx, self.Ny, self._X0,
+                                  self._Y0, 1, 16, device=device, dtype=dtype)
+            rects = np.array([var_room['targets'][t] for t in target.split(' or ') if t in var_room['targets']],
+                             dtype=np.float64).reshape(-1, 4)
+            self._engine.set_potential(0, self.V, rects)
+            self._engine.alloc_field(0, self.nt_opt - 1)
+
+    @property
+    def X_opt(self):
+        return np.meshgrid(self._X0, self._Y0)[0]
+
+    @property
+    def Y_opt(self):
+        return np.meshgrid(self._X0, self._Y0)[1]
+
+    @property
+    def vx_opt(self):
+        return DeviceField(self._engine.fields[self._k][0])
+
+    @property
+    def vy_opt(self):
+        return DeviceField(self._engine.fields[self._k][1])
+
+    def compute_optimal_velocity(self, t, m):
+        """reference optimals.py:124-206.  m: (Ny,Nx) density (NumPy array or device tensor) or None/0."""
+        self.t = t
+        self.nt_opt = round((self.T - self.t) / self.dt)
+        mt = None
+        if m is not None and not np.isscalar(m):
+            mt = m if torch.is_tensor(m) else torch.as_tensor(np.ascontiguousarray(m, dtype=np.float64))
+        self.stats, _ = self._engine.solve(self._k, self.T, self.nt_opt, m=mt)
+        print('Optimal trajectories have been learnt for ' + self.target)
+
+    def choose_optimal_velocity(self, pos, t):
+        """reference optimals.py:212-250 for one position (device lookup; raises IndexError like the reference)."""
+        des, err = self._engine.lookup_points(self._k, np.array([pos[0]]), np.array([pos[1]]), int(t))
+        if err:
+            raise IndexError("index out of bounds for the floor field")
+        return des[0]

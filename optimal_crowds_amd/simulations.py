@@ -1,0 +1,267 @@
+"""`simulations.simulation(room, T, recompute=False).run()` -- the reference's driver surface
+(reference simulations.py:18-451) on top of the MI355X engine.
+
+Same constructor arguments, attributes, printed lines and room / config formats; the per-step work
+(floor-field lookup, all-pairs GCFM repulsion, wall repulsion, noisy relaxation step, exit test), the HJB
+solves and the density run in HIP kernels through liboc_hip.so.  Agent state lives in HBM as SoA buffers;
+`agents[i]` are light views (pedestrians.ped) onto it.
+
+Differences a user can observe (DESIGN.md "Deviations"):
+  * the agent update is synchronous (all agents see the positions of the step's start); the reference updates
+    agents one by one in a random order.  The random permutation is still drawn (noise='host') so that the
+    global np.random stream is consumed exactly like the reference's.
+  * noise='device' (default above `host_noise_max_agents`) draws the step noise with Philox on the GPU.
+"""
+import warnings
+
+import numpy as np
+import torch
+
+from . import host, optimals as optimals_mod, pedestrians
+from .engine import Engine
+
+warnings.filterwarnings("ignore")
+
+HOST_NOISE_MAX_AGENTS = 20000
+
+
+class _History(dict):
+    """history[time] -> frame, built lazily from the device recorder (reference simulations.py:579-589)."""
+
+    def __init__(self, sim):
+        super().__init__()
+        self._sim = sim
+        self._steps = {}
+
+    def _mark(self, time, step):
+        self._steps[time] = step
+        dict.__setitem__(self, time, None)
+
+    def __getitem__(self, time):
+        v = dict.__getitem__(self, time)
+        if v is None:
+            v = self._sim._frame(self._steps[time])
+            dict.__setitem__(self, time, v)
+        return v
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
+class simulation:
+    def __init__(self, room, T, recompute=False, *, config=None, device="cuda:0", dtype="float32",
+                 noise=None, seed=20240807, history=None, record=None, wall_search_radius=None):
+        self.recompute = recompute
+        var_config = host.load_config(config)
+        var_room = host.load_room(room)
+        self._cfg, self._room = var_config, var_room
+        self.room_length = var_room["room_length"]
+        self.room_height = var_room["room_height"]
+        self.grid_step = var_config["grid_step"]
+        self.Nx, self.Ny = host.grid_dims(self.room_length, self.room_height, self.grid_step)
+        self.dx = self.dy = self.grid_step
+        self._X0, self._Y0 = host.axes(self.room_length, self.room_height, self.Nx, self.Ny)
+        self.sigma_convolution = var_config["sigma_convolution"]
+        self.pot = var_config["hjb_params"]["wall_potential"]
+        self.lim = 10e-3
+        self.T = T
+        self.time = 0.
+        self.simu_step = 0
+        self.dt = var_config["dt"]
+        self.relaxation = var_config["relaxation"]
+        self.noise_intensity = var_config["hjb_params"]["sigma"]
+        self.a_min = var_config["b_min"]
+        self.tau_a = var_config["tau_a"]
+        self.b_min = var_config["b_min"]
+        self.b_max = var_config["b_max"]
+        self.eta = var_config["eta"]
+        self.eta_walls = var_config["eta_walls"]
+        self.repulsion_cutoff = var_config["repulsion_cutoff"]
+        self.v_max = var_config["v_max"]
+        self.recompute_step = var_config["recompute_frequency"]
+
+        # ---- potentials, keys and the crowd (reference simulations.py:104-160)
+        self.Vs = {}
+        self.V = np.zeros((self.Ny, self.Nx)) + 1
+        self.place_ped = np.zeros((self.Ny, self.Nx))
+        key_names, xs, ys, vd, kk = [], [], [], [], []
+        self._possible = {}
+        for box in var_room["initial_boxes"].values():
+            targets = box[5:]
+            key = " or ".join(targets)
+            V = host.create_potential(var_room, targets, self._X0, self._Y0)
+            host.finalize_potential(V, var_config)       # what optimals.__init__ does to the caller's array
+            self.Vs[key] = V
+            if key not in key_names:
+                key_names.append(key)
+            self._possible[key] = targets
+            self.V += V
+            bx, by, bv = host.sample_box(box, self._X0, self._Y0, self.place_ped)
+            xs.append(bx), ys.append(by), vd.append(bv)
+            kk.append(np.full(len(bx), key_names.index(key), dtype=np.int32))
+        self.V[self.V > np.min(self.V)] = 0
+        cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
+        x0, y0 = cat(xs, float), cat(ys, float)
+        self._v_des = cat(vd, float)
+        self._key_of = cat(kk, np.int32)
+        self._key_names = key_names
+        self.N = len(x0)
+        self.inside = self.N
+        self._x0, self._y0 = x0.copy(), y0.copy()
+
+        # ---- device side
+        nt0 = round(self.T / self.dt)
+        self._nt0 = nt0
+        if wall_search_radius is None:
+            wall_search_radius = 0.0
+        self._engine = Engine(var_config, self.room_length, self.room_height, self.Nx, self.Ny, self._X0, self._Y0,
+                              len(key_names), self.N, device=device, dtype=dtype,
+                              wall_search_radius=wall_search_radius)
+        eng = self._engine
+        self.targets = {}
+        for k, key in enumerate(key_names):
+            rects = np.array([var_room["targets"][t] for t in self._possible[key]], dtype=np.float64)
+            eng.set_potential(k, self.Vs[key], rects)
+            eng.alloc_field(k, nt0 - 1)
+            self.targets[key] = optimals_mod.optimals(room, self.Vs[key], T, key, _sim=self, _key_index=k)
+        eng.set_agents(x0, y0, np.zeros(self.N), np.zeros(self.N), self._v_des, self._key_of)
+        self._V_all_dev = torch.as_tensor(self.V.astype(np.float32)).to(eng.device)
+        self._noise_mode = noise or ("host" if self.N <= HOST_NOISE_MAX_AGENTS else "device")
+        self._seed = seed
+        self._status_host = np.ones(self.N, dtype=bool)
+        # trajectory recorder (ped.traj / ped.vels / history): (steps+1, 4, N) float64 in HBM when it fits
+        if record is None:
+            record = (nt0 + 3) * max(self.N, 1) * 32 <= 8 << 30
+        self._rec = None
+        if record and self.N > 0:
+            self._rec = torch.empty((nt0 + 3, 4, self.N), dtype=torch.float64, device=eng.device)
+            self._rec_status = torch.empty((nt0 + 3, self.N), dtype=torch.uint8, device=eng.device)
+            self._record(0)
+        self._history_on = (self._rec is not None) if history is None else bool(history)
+        self.history = _History(self)
+        self._agents = None
+        print('ABM simulation room created!')
+
+    # ------------------------------------------------------------------ reference attributes
+    @property
+    def X_opt(self):
+        return np.meshgrid(self._X0, self._Y0)[0]
+
+    @property
+    def Y_opt(self):
+        return np.meshgrid(self._X0, self._Y0)[1]
+
+    @property
+    def agents(self):
+        if self._agents is None:
+            self._agents = np.array([pedestrians.ped._view(self, i) for i in range(self.N)], dtype=object)
+        return self._agents
+
+    # ------------------------------------------------------------------ recorder
+    def _record(self, slot):
+        if self._rec is None or slot >= self._rec.shape[0]:
+            return
+        a = self._engine.agents
+        r = self._rec[slot]
+        r[0].copy_(a["x"]), r[1].copy_(a["y"]), r[2].copy_(a["vx"]), r[3].copy_(a["vy"])
+        self._rec_status[slot].copy_(a["status"])
+
+    def _frame(self, step):
+        if self._rec is None:
+            raise RuntimeError("history needs the trajectory recorder (record=True)")
+        st = self._rec[step].cpu().numpy()
+        act = self._rec_status[step].cpu().numpy().astype(bool)
+        frame = [[np.array((st[0, i], st[1, i])), np.array((st[2, i], st[3, i])),
+                  self._key_names[self._key_of[i]], self._v_des[i]] for i in np.nonzero(act)[0]]
+        frame.append(self._density_of(self._rec[step][0], self._rec[step][1], self._rec_status[step],
+                                      self.sigma_convolution))
+        return frame
+
+    def write_history(self, time):
+        """reference simulations.py:579-589; frames (agents + density) are materialised on access."""
+        if self._history_on:
+            self.history._mark(time, self.simu_step)
+
+    # ------------------------------------------------------------------ step (reference simulations.py:252-342)
+    def step(self, dt, verbose=False):
+        eng = self._engine
+        if dt != self.dt:
+            raise ValueError("the device step uses config dt (%g)" % self.dt)
+        noise = None
+        if self._noise_mode == "host":
+            # same draws, in the same order, as the reference: one permutation, then 2 normals per active agent
+            perm = np.random.choice(np.arange(self.N), self.N, replace=False)
+            noise = np.zeros((self.N, 2))
+            act = perm[self._status_host[perm]]
+            noise[act] = np.random.normal(size=(len(act), 2))
+        exited, bad, active = eng.step(self.simu_step, noise=noise, seed=self._seed)
+        if bad:
+            raise IndexError("agent %d left the region covered by the floor field (index %d is out of bounds)"
+                             % (bad - 1, bad - 1))
+        if exited:
+            self.inside -= exited
+            self._status_host = eng.agents["status"].cpu().numpy().astype(bool)
+        self.time += dt
+        self.simu_step += 1
+        self._record(self.simu_step)
+        if verbose:
+            print('t = {:.2f}s exit = {}/{}'.format(self.time, self.N - self.inside, self.N) + 10 * ' ', end='\n')
+
+    def evac_times(self, draw=False):
+        if self.inside > 0:
+            raise ValueError('There are still people inside!')
+        return self._engine.agents["agent_time"].cpu().numpy().copy()
+
+    def initial_positions(self):
+        return self._x0.copy(), self._y0.copy()
+
+    # ------------------------------------------------------------------ run (reference simulations.py:401-451)
+    def _solve_all(self):
+        m = self._density_dev(self.sigma_convolution) if self.simu_step > 0 else None
+        for key in self.targets:
+            self.targets[key].compute_optimal_velocity(self.time, m)
+
+    def run(self, verbose=False, draw=False, mode='scatter'):
+        print(f"Computing trajectories at time {self.time}")
+        self._solve_all()
+        while (self.inside > 0) & (self.time < self.T):
+            if self.recompute and (self.simu_step % self.recompute_step == 0) and self.simu_step > 0:
+                print(f"Computing trajectories at time {self.time}")
+                self._solve_all()
+            self.write_history(self.time)
+            self.step(self.dt, verbose=verbose)
+            if draw and (self.simu_step % 10) == 0:
+                self.draw(mode)
+        if self.inside == 0:
+            print('Evacuation complete in {:.2f}s!'.format(self.time))
+        else:
+            print('Evacuation failed!' + 10 * ' ')
+
+    # ------------------------------------------------------------------ density (reference simulations.py:453-487)
+    def _density_dev(self, sigma):
+        return self._engine.density(sigma, self._V_all_dev)
+
+    def _density_of(self, x, y, status, sigma):
+        eng = self._engine
+        saved, sstruct = eng.agents, eng._astruct
+        try:
+            eng.set_agents(x.cpu().numpy(), y.cpu().numpy(), np.zeros(self.N), np.zeros(self.N), self._v_des,
+                           self._key_of, status=status.cpu().numpy())
+            return eng.density(sigma, self._V_all_dev, out_dtype=1).cpu().numpy()
+        finally:
+            eng.agents, eng._astruct = saved, sstruct
+
+    def gaussian_density(self, sigma):
+        return self._engine.density(sigma, self._V_all_dev, out_dtype=1).cpu().numpy()
+
+    def create_potential(self, var_room, targets):
+        return host.create_potential(var_room, targets, self._X0, self._Y0)
+
+    # ------------------------------------------------------------------ plotting: out of scope
+    def draw(self, mode='scatter'):
+        raise NotImplementedError("plotting is outside the accelerated path; read sim.agents / sim.history")
+
+    draw_final_trajectories = draw_history = draw

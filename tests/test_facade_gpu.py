@@ -1,0 +1,122 @@
+"""The reference-shaped Python surface (simulations.simulation / optimals / pedestrians) on the GPU."""
+import copy
+import io
+import contextlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oc_oracle as oc                     # noqa: E402  (checker only)
+from optimal_crowds_amd import room_library            # noqa: E402
+
+
+def _cfg():
+    return copy.deepcopy(oc.DEFAULT_CONFIG)
+
+
+def test_run_matches_oracle_synchronous_and_reference_statistics(golden):
+    """simulation('room_test', T).run() with host noise consumes np.random exactly like the reference, so the
+    oracle in synchronous mode (same seed) is the trajectory-level checker; the reference's own sequential run
+    (fixture G8) is the statistical one."""
+    from optimal_crowds_amd import simulations
+    T = 6.0
+    np.random.seed(1)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        sim = simulations.simulation("room_test", T, config=_cfg(), noise="host")
+        sim.run()
+    printed = buf.getvalue()
+    assert printed.startswith("ABM simulation room created!\nComputing trajectories at time 0.0\n"
+                              "Optimal trajectories have been learnt for door\n")
+    np.random.seed(1)
+    ref = oc.Simulation(room_library.ROOMS["room_test"](), T, cfg=_cfg(), mode="synchronous")
+    g1 = golden("G1_room_test.npz")
+    assert np.array_equal(sim._x0, g1["x"]) and np.array_equal(sim._v_des, g1["v_des"])   # same start as reference
+    ref.run()
+    assert sim.simu_step == ref.simu_step and sim.inside == ref.inside
+    assert sim.time == pytest.approx(ref.time, abs=1e-12)
+    st = sim._engine.get_state()
+    assert np.array_equal(st["status"].astype(bool), ref.status)
+    assert np.abs(st["x"] - ref.x).max() < 2e-3 and np.abs(st["y"] - ref.y).max() < 2e-3
+    assert np.allclose(st["agent_time"], ref.agent_time, atol=1e-9)
+    # facade views
+    a = sim.agents[3]
+    assert a.target == "door" and len(a.traj) == int(round(a.time / sim.dt)) + 1
+    assert np.allclose(a.traj[0], a.initial_position) and np.allclose(a.traj[-1], a.position())
+    xs, ys = sim.initial_positions()
+    assert np.array_equal(xs, g1["x"])
+    with pytest.raises(ValueError):
+        sim.evac_times()
+    # history frame: active agents + density; density equals the oracle's on the same snapshot
+    t1 = sorted(sim.history)[10]
+    frame = sim.history[t1]
+    assert frame[-1].shape == (sim.Ny, sim.Nx) and len(frame) - 1 <= sim.N
+    d = sim.gaussian_density(0.5)
+    want = oc.gaussian_density(st["x"], st["y"], st["status"].astype(bool), ref.X, ref.Y, ref.V, 0.5)
+    assert np.abs(d - want).max() <= 2e-7 * max(want.max(), 1e-30)
+    # lazily exposed direction field
+    vx = sim.targets["door"].vx_opt
+    assert vx.shape == (round(T / 0.02) - 1, sim.Ny - 2, sim.Nx - 2)
+    o = ref.targets["door"].vx_opt[5]
+    assert (np.abs(vx[5] - o) < 1e-2).mean() > 0.995
+
+
+def test_full_run_statistics_vs_reference_g8(golden):
+    """T = 20 run of room_test: the synchronous GPU run evacuates the same number of agents (+-2) as the
+    reference's sequential run with the same seed, at similar times."""
+    from optimal_crowds_amd import simulations
+    g = golden("G8_run_room_test.npz")
+    np.random.seed(int(g["seed"]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim = simulations.simulation("room_test", float(g["T"]), config=_cfg(), noise="host")
+        sim.run()
+    assert sim.simu_step == int(g["nsteps"])
+    assert abs(sim.inside - int(g["inside"])) <= 2
+    t_gpu = np.sort(sim._engine.get_state()["agent_time"])
+    t_ref = np.sort(g["agent_time"])
+    k = min((t_gpu < 20).sum(), (t_ref < 20).sum())
+    assert np.abs(t_gpu[:k] - t_ref[:k]).max() < 1.5          # exit times of the evacuated agents, seconds
+
+
+def test_recompute_horizon_semantics(golden):
+    """recompute=True: nt_opt shrinks at every recompute exactly like the reference (quirk Q9)."""
+    from optimal_crowds_amd import simulations
+    g = golden("G8_run_gold_b_recompute.npz")
+    np.random.seed(int(g["seed"]))
+    nts = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim = simulations.simulation("gold_b", float(g["T"]), recompute=True, config=_cfg(), noise="host")
+        for key, opt in sim.targets.items():
+            f = opt.compute_optimal_velocity
+
+            def wrapped(t, m, _f=f, _o=opt):
+                _f(t, m)
+                nts.append((sim.simu_step, _o.nt_opt))
+            opt.compute_optimal_velocity = wrapped
+        sim.run()
+    assert np.array_equal(np.array(nts), g["nt_after"])
+    assert sim.simu_step == int(g["nsteps"])
+    assert abs(sim.inside - int(g["inside"])) <= 3
+
+
+def test_single_point_api():
+    from optimal_crowds_amd import simulations
+    np.random.seed(12)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim = simulations.simulation("gold_b", 1.0, config=_cfg(), noise="host")
+        sim.targets["east"].compute_optimal_velocity(0.0, None)
+    v = sim.targets["east"].choose_optimal_velocity(np.array((7.2, 3.1)), 3)
+    assert v.shape == (2,) and abs(np.hypot(*v) - 1.0) < 1e-5
+    assert np.all(sim.targets["east"].choose_optimal_velocity(np.array((3.0, 3.0)), 10 ** 6) == 0)
+    with pytest.raises(IndexError):
+        sim.targets["east"].choose_optimal_velocity(np.array(((sim.Nx - 3) * sim.dx + 0.01, 3.0)), 3)
+    a = sim.agents[0]
+    f = a.wall_repulsion(sim.X_opt, sim.Y_opt, sim.Vs[a.target])
+    ref = oc.wall_force(a.position(), a.velocity(), a.v_des, sim.X_opt, sim.Y_opt, sim.Vs[a.target], _cfg())
+    assert np.allclose(f, ref, rtol=1e-10, atol=1e-14)
+    pj, vj = a.position() + np.array((0.4, 0.1)), np.array((-0.5, 0.2))
+    fr = a.agents_repulsion(pj, vj)
+    want = oc.pair_force(a.position(), a.velocity(), a.v_des, pj, vj, _cfg())
+    assert np.allclose(fr, want, rtol=5e-5, atol=1e-7)
