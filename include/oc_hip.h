@@ -138,10 +138,15 @@ int oc_density(oc_handle* h, int dtype, const oc_agents* a, double sigma, const 
                void* out, void* stream);
 
 /* ---- introspection for bench.py / tests --------------------------------------------------------------------- */
-/* HIP-event time (ms) of the most recent launch of the named kernel class on its stream:
- * "hjb_step", "hjb_out", "gcfm_pair", "gcfm_wall"; returns <0 if never launched. */
-double oc_last_kernel_ms(oc_handle* h, const char* name);
+/* With profiling enabled every launch of a named kernel class is bracketed by HIP events on its own stream.
+ * oc_kernel_stats returns, since the last reset: number of launches, summed event time (ms) and summed
+ * ALGORITHMIC bytes (DESIGN.md section "Rooflines").  Classes: "hjb_stage" (one RK attempt = 6 fused stage
+ * launches), "hjb_out" (dense output + direction-field writer), "gcfm_pair", "gcfm_wall".  Synchronises. */
 int oc_set_profiling(oc_handle* h, int enabled);
+int oc_kernel_stats(oc_handle* h, const char* name, int64_t* launches, double* total_ms, double* total_bytes);
+int oc_reset_kernel_stats(oc_handle* h);
+/* 0 = fused HJB kernels (default), 1 = simple one-array-pass kernels (cross-check). */
+int oc_set_hjb_variant(oc_handle* h, int variant);
 
 #ifdef __cplusplus
 }

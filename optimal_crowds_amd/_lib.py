@@ -73,8 +73,11 @@ SIGNATURES = {
     "oc_set_resort_every": (C.c_int, [C.c_void_p, C.c_int32]),
     "oc_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(OcAgents), C.c_double, C.c_void_p, C.c_double,
                              C.c_void_p, C.c_void_p]),
-    "oc_last_kernel_ms": (C.c_double, [C.c_void_p, C.c_char_p]),
     "oc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "oc_kernel_stats": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double)]),
+    "oc_reset_kernel_stats": (C.c_int, [C.c_void_p]),
+    "oc_set_hjb_variant": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib = None

@@ -110,47 +110,51 @@ __global__ void __launch_bounds__(64) k_pack(const double* __restrict__ x, const
 // ---------------------------------------------------------------------------------- pair forces
 #define COS_VISION (-0.58778525229247312917f)   // cos(0.7 pi), pedestrians.py:262
 
-// force of j on i (pedestrians.py:242-280) in trig-free form: cos(alpha-beta) = e.h, sin = h x e
+// force of j on i (pedestrians.py:242-280) in trig-free form: cos(alpha-beta) = e.h, sin = h x e.
+// float32 with hardware rcp/rsq/exp2 (1 ulp); R is the float64-differenced relative vector rounded to float32.
 __device__ __forceinline__ void pair_term(float Rx, float Ry, float vxi, float vyi, float si, float hxi, float hyi,
                                           float ia2_i, float ib2_i, float inv_vdes_i, float4 vj, float2 hj,
-                                          const GcfmParams& P, float b_max, float db, float inv_eta, double& fx,
-                                          double& fy) {
-    float r2 = Rx * Rx + Ry * Ry;
-    float r = sqrtf(r2);
-    float inv_r = 1.0f / r;
+                                          float b_max, float db, float neg_inv_eta_log2e, double& fx, double& fy) {
+    float r2 = __builtin_fmaf(Rx, Rx, Ry * Ry);
+    float inv_r = __builtin_amdgcn_rsqf(r2);
+    float r = r2 * inv_r;
     float ex = Rx * inv_r, ey = Ry * inv_r;
     // closing speed (pedestrians.py:254-255)
-    float vrel = fmaxf((vxi - vj.x) * ex + (vyi - vj.y) * ey, 0.f);
-    // vision factor (pedestrians.py:259-262)
-    float k = 0.f;
-    if (si > 0.f) k = fmaxf((vxi * ex + vyi * ey) / si - COS_VISION, 0.f) / (1.f - COS_VISION);
+    float vrel = fmaxf(__builtin_fmaf(vxi - vj.x, ex, (vyi - vj.y) * ey), 0.f);
     // ellipse radii along the centre line (pedestrians.py:266-271)
-    float ci = ex * hxi + ey * hyi, sn_i = hxi * ey - hyi * ex;
-    float q_i = sqrtf(1.0f / (ci * ci * ia2_i + sn_i * sn_i * ib2_i));
-    float b_j = b_max - db * fminf(vj.z * inv_vdes_i, 1.f);          // Q6: i's v_des
-    float cj = ex * hj.x + ey * hj.y, sn_j = hj.x * ey - hj.y * ex;
-    float q_j = sqrtf(1.0f / (cj * cj * vj.w + sn_j * sn_j / (b_j * b_j)));
+    float ci = __builtin_fmaf(ex, hxi, ey * hyi), sn_i = __builtin_fmaf(hxi, ey, -hyi * ex);
+    // vision factor (pedestrians.py:259-262): v_i.e/|v_i| = h_i.e when |v_i| > 0
+    float k = (si > 0.f) ? fmaxf(ci - COS_VISION, 0.f) * (1.f / (1.f - COS_VISION)) : 0.f;
+    float q_i = __builtin_amdgcn_rsqf(__builtin_fmaf(ci * ci, ia2_i, sn_i * sn_i * ib2_i));
+    float b_j = __builtin_fmaf(-db, fminf(vj.z * inv_vdes_i, 1.f), b_max);          // Q6: i's v_des
+    float ib2_j = __builtin_amdgcn_rcpf(b_j * b_j);
+    float cj = __builtin_fmaf(ex, hj.x, ey * hj.y), sn_j = __builtin_fmaf(hj.x, ey, -hj.y * ex);
+    float q_j = __builtin_amdgcn_rsqf(__builtin_fmaf(cj * cj, vj.w, sn_j * sn_j * ib2_j));
     float dist = r - q_i - q_j;
-    float rep = fminf(k * expf(-dist * inv_eta / (1.f + vrel)), 1.f);
+    float rep = fminf(k * __builtin_amdgcn_exp2f(dist * neg_inv_eta_log2e * __builtin_amdgcn_rcpf(1.f + vrel)), 1.f);
     fx += (double)(-rep * Rx);
     fy += (double)(-rep * Ry);
 }
 
-// one wavefront per i-tile; 4 wavefronts per block, each with a private LDS staging area
+// One block (4 wavefronts) per i-tile: lane <-> agent slot, the wavefronts split the surviving j-tiles.
+// Per j-tile: phase 1 builds, per lane, a 64-bit mask of candidate j (float32 test on box-relative coordinates,
+// conservative); phase 2 walks each lane's own mask: exact float64 cutoff decision, then the float32 force.
 __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const double* __restrict__ v_des) {
     __shared__ double2 l_pos[4][64];
     __shared__ float4 l_vel[4][64];
     __shared__ float2 l_head[4][64];
+    __shared__ float2 l_rel[4][64];
+    __shared__ double2 l_red[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int it = blockIdx.x * 4 + w;
-    if (it >= S.ntiles) return;                       // whole wavefront exits together
+    const int it = blockIdx.x;
     const int k = it * 64 + lane;
     const int i = S.pidx[k];
     const double2 pi = S.ppos[k];
     const float4 vi = S.pvel[k];
     const float2 hi = S.phead[k];
     float inv_vdes = 0.f, ib2_i = 0.f;
-    const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min), inv_eta = (float)(1.0 / P.eta);
+    const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
+    const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
     if (i >= 0) {
         double vd = v_des[i];
         inv_vdes = (float)(1.0 / vd);
@@ -160,7 +164,10 @@ __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const dou
     const double4 bi = S.tile_box[it];
     const double c = P.cutoff;
     const double c2 = c * c, c2_lo = c2 * (1.0 - 1e-15), c2_hi = c2 * (1.0 + 1e-15);
+    const double ox = bi.x, oy = bi.y;                 // origin of the box-relative float32 coordinates
+    const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
     double fx = 0.0, fy = 0.0;
+    int ord = 0;
     for (int tb = 0; tb < S.ntiles; tb += 64) {
         int t = tb + lane;
         bool hit = false;
@@ -168,36 +175,59 @@ __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const dou
             double4 bj = S.tile_box[t];
             hit = !(bj.x > bi.z + c || bj.z < bi.x - c || bj.y > bi.w + c || bj.w < bi.y - c);
         }
-        unsigned long long mask = __ballot(hit);
-        while (mask) {
-            int b = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
+        unsigned long long tmask = __ballot(hit);
+        while (tmask) {
+            int b = __ffsll((long long)tmask) - 1;
+            tmask &= tmask - 1;
+            if (((ord++) & 3) != w) continue;           // this hit belongs to another wavefront of the block
             int jt = tb + b;
-            // stage tile jt (wave-private LDS; LDS ops of one wavefront complete in order)
+            // stage tile jt in this wavefront's LDS area (LDS ops of one wavefront complete in order)
             __builtin_amdgcn_wave_barrier();
-            l_pos[w][lane] = S.ppos[jt * 64 + lane];
+            double2 pj_own = S.ppos[jt * 64 + lane];
+            l_pos[w][lane] = pj_own;
+            l_rel[w][lane] = make_float2((float)(pj_own.x - ox), (float)(pj_own.y - oy));
             l_vel[w][lane] = S.pvel[jt * 64 + lane];
             l_head[w][lane] = S.phead[jt * 64 + lane];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (i >= 0) {
-#pragma unroll 4
-                for (int jj = 0; jj < 64; ++jj) {
-                    double2 pj = l_pos[w][jj];
-                    double ddx = pj.x - pi.x, ddy = pj.y - pi.y;
-                    double d2 = ddx * ddx + ddy * ddy;
-                    // reference: sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291); j != i
-                    bool nearp = (d2 < c2_lo) || (d2 < c2_hi && sqrt(d2) < c);
-                    if (nearp && !(jt == it && jj == lane)) {
-                        pair_term((float)ddx, (float)ddy, vi.x, vi.y, vi.z, hi.x, hi.y, vi.w, ib2_i, inv_vdes,
-                                  l_vel[w][jj], l_head[w][jj], P, b_max, db, inv_eta, fx, fy);
-                    }
-                }
+            // conservative float32 bound: rounding of the relative coordinates scales with the two boxes' extent
+            double4 bj = S.tile_box[jt];
+            float ext = (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
+                                fmax(fmax(bi.w, bj.w) - oy, oy - fmin(bi.y, bj.y)));
+            const float c2f = (float)c2 * 1.00001f + 1e-6f * ext * (ext + (float)c);
+            // phase 1: candidate mask of this lane's agent
+            unsigned long long m = 0ull;
+#pragma unroll 8
+            for (int jj = 0; jj < 64; ++jj) {
+                float2 q = l_rel[w][jj];
+                float ddx = q.x - xi_f, ddy = q.y - yi_f;
+                float d2 = __builtin_fmaf(ddx, ddx, ddy * ddy);
+                m |= (d2 < c2f) ? (1ull << jj) : 0ull;
+            }
+            if (jt == it) m &= ~(1ull << lane);        // j != i
+            if (i < 0) m = 0ull;
+            // phase 2: this lane's candidates
+            while (m) {
+                int jj = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                double2 pj = l_pos[w][jj];
+                double ddx = pj.x - pi.x, ddy = pj.y - pi.y;
+                double d2 = ddx * ddx + ddy * ddy;
+                // the reference's decision: sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291)
+                bool nearp = (d2 < c2_lo) || (d2 < c2_hi && sqrt(d2) < c);
+                if (nearp)
+                    pair_term((float)ddx, (float)ddy, vi.x, vi.y, vi.z, hi.x, hi.y, vi.w, ib2_i, inv_vdes,
+                              l_vel[w][jj], l_head[w][jj], b_max, db, neg_inv_eta_log2e, fx, fy);
             }
         }
     }
-    S.f_pair[k] = make_double2(fx, fy);
+    l_red[w][lane] = make_double2(fx, fy);
+    __syncthreads();
+    if (w == 0) {
+        double2 a0 = l_red[0][lane], a1 = l_red[1][lane], a2 = l_red[2][lane], a3 = l_red[3][lane];
+        S.f_pair[k] = make_double2((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
+    }
 }
 
 // ---------------------------------------------------------------------------------- wall search + force
@@ -223,6 +253,15 @@ __device__ __forceinline__ void wall_try(double px, double py, int r, int cnd, i
     }
 }
 
+// search radius when P.wall_radius < 0: beyond it the force 3|R| exp(-(|R| - q)/(eta_w (1 + v_rel))) is below
+// 1e-12 m/s for this agent's own speed (q <= a^2, v_rel <= |v|; 33 = ln(3 * 60 m / 1e-12 m/s) rounded up)
+__device__ __forceinline__ double wall_radius_of(const GcfmParams& P, double s) {
+    if (P.wall_radius >= 0) return P.wall_radius;
+    double a = P.a_min + P.tau_a * s;
+    return a * a + P.eta_walls * (1.0 + s) * 33.0;
+}
+
+#define WALL_UNROLL 4
 __global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
                                              const int32_t* __restrict__ key_of, const double* __restrict__ v_des,
                                              const double* __restrict__ X0, const double* __restrict__ Y0) {
@@ -240,46 +279,49 @@ __global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyD
         jx = jx < 0 ? 0 : (jx > Nx - 1 ? Nx - 1 : jx);
         while (jx > 0 && X0[jx] > p.x) --jx;
         while (jx < Nx - 1 && X0[jx + 1] <= p.x) ++jx;
-        int jr = (jx + 1 < Nx) ? jx + 1 : -1;
+        const int jr = (jx + 1 < Nx) ? jx + 1 : -1;
         int r0 = (int)floor(p.y / hy + 0.5);
         r0 = r0 < 0 ? 0 : (r0 > Ny - 1 ? Ny - 1 : r0);
         double best_d2 = INFINITY, thr = INFINITY, best_f = INFINITY;
-        const double rad = P.wall_radius;
+        const double rad = wall_radius_of(P, (double)S.pvel[k].z);
+        const double rad2 = rad > 0 ? rad * rad : INFINITY;
+        // rows r0, r0+1, r0-1, r0+2, ... in groups: all loads of a group are issued before they are used
         bool up = true, dn = true;
-        for (int o = 0; up || dn; ++o) {
-            // upward row r0+o
-            if (up) {
-                int r = r0 + o;
-                if (r >= Ny) up = false;
-                else {
-                    double yr = Y0[r], ady = fabs(yr - p.y);
-                    if (ady * ady > thr || (rad > 0 && ady > rad)) {
-                        if (yr > p.y) up = false;     // monotone beyond the agent's row
-                    } else {
-                        wall_try(p.x, p.y, r, kd.left[(long long)r * Nx + jx], Nx, X0, yr, kd.off, best_d2, thr,
-                                 best_f, best_flat);
-                        if (jr >= 0)
-                            wall_try(p.x, p.y, r, kd.right[(long long)r * Nx + jr], Nx, X0, yr, kd.off, best_d2, thr,
-                                     best_f, best_flat);
-                    }
-                }
+        for (int o = 0; up || dn; o += WALL_UNROLL) {
+            int rows[2 * WALL_UNROLL], cl[2 * WALL_UNROLL], cr[2 * WALL_UNROLL];
+            double yr[2 * WALL_UNROLL];
+#pragma unroll
+            for (int u = 0; u < WALL_UNROLL; ++u) {
+                int ru = r0 + o + u, rd = r0 - o - u;
+                bool vu = up && ru < Ny, vd = dn && rd >= 0 && (o + u) > 0;
+                rows[2 * u] = vu ? ru : -1;
+                rows[2 * u + 1] = vd ? rd : -1;
             }
-            if (dn && o > 0) {
-                int r = r0 - o;
-                if (r < 0) dn = false;
-                else {
-                    double yr = Y0[r], ady = fabs(yr - p.y);
-                    if (ady * ady > thr || (rad > 0 && ady > rad)) {
-                        if (yr < p.y) dn = false;
-                    } else {
-                        wall_try(p.x, p.y, r, kd.left[(long long)r * Nx + jx], Nx, X0, yr, kd.off, best_d2, thr,
-                                 best_f, best_flat);
-                        if (jr >= 0)
-                            wall_try(p.x, p.y, r, kd.right[(long long)r * Nx + jr], Nx, X0, yr, kd.off, best_d2, thr,
-                                     best_f, best_flat);
-                    }
-                }
+#pragma unroll
+            for (int q = 0; q < 2 * WALL_UNROLL; ++q) {
+                int r = rows[q];
+                bool v = r >= 0;
+                int rr = v ? r : 0;
+                yr[q] = Y0[rr];
+                cl[q] = v ? kd.left[(long long)rr * Nx + jx] : -1;
+                cr[q] = (v && jr >= 0) ? kd.right[(long long)rr * Nx + jr] : -1;
             }
+#pragma unroll
+            for (int q = 0; q < 2 * WALL_UNROLL; ++q) {
+                int r = rows[q];
+                if (r < 0) continue;
+                double ady = fabs(yr[q] - p.y), ady2 = ady * ady;
+                if (ady2 > thr || ady2 > rad2) {
+                    // rows only get farther in this direction once they are past the agent
+                    if ((q & 1) == 0) { if (yr[q] > p.y) up = false; }
+                    else { if (yr[q] < p.y) dn = false; }
+                    continue;
+                }
+                wall_try(p.x, p.y, r, cl[q], Nx, X0, yr[q], kd.off, best_d2, thr, best_f, best_flat);
+                wall_try(p.x, p.y, r, cr[q], Nx, X0, yr[q], kd.off, best_d2, thr, best_f, best_flat);
+            }
+            if (r0 + o + WALL_UNROLL >= Ny) up = false;
+            if (r0 - o - WALL_UNROLL < 0) dn = false;
         }
     }
     S.widx[k] = best_flat;
@@ -465,12 +507,11 @@ __global__ void k_integrate(GcfmParams P, Scratch S, const KeyDev* __restrict__ 
     for (int q = 0; q < kd.nrect; ++q)
         if (fabs(nx - kd.rect[q][0]) < kd.rect[q][2] * 0.5 && fabs(ny - kd.rect[q][1]) < kd.rect[q][3] * 0.5)
             out = true;
-    if (out) {
-        status[i] = 0;
-        atomicAdd(&S.counters[0], 1);
-    } else {
-        atomicAdd(&S.counters[2], 1);
-    }
+    if (out) status[i] = 0;
+    // one atomic per wavefront and counter (100k same-address atomics cost > 1 ms)
+    unsigned long long m_out = __ballot(out), m_in = __ballot(!out);
+    if (m_out && (threadIdx.x & 63) == __ffsll((long long)m_out) - 1) atomicAdd(&S.counters[0], __popcll(m_out));
+    if (m_in && (threadIdx.x & 63) == __ffsll((long long)m_in) - 1) atomicAdd(&S.counters[2], __popcll(m_in));
 }
 
 template <typename TV>
@@ -696,7 +737,7 @@ extern "C" int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out
     GcfmParams P;
     if ((rc = prepare(h, a, false, &S, &P, s))) return rc;
     oc_timer_begin(h, "gcfm_pair", s);
-    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, a->v_des);
+    hipLaunchKernelGGL(k_pair, dim3(S.ntiles), dim3(256), 0, s, P, S, a->v_des);
     oc_timer_end(h, "gcfm_pair", s);
     OC_HIP_CHECK(hipMemsetAsync(force_out, 0, sizeof(double) * 2 * (size_t)a->N, s));
     hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_pair, S.pidx, S.Np,
@@ -722,7 +763,7 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     dim3 g256((S.Np + 255) / 256);
     hipLaunchKernelGGL(k_lookup, g256, dim3(256), 0, s, P, S, kd, a->key, a->v_des, simu_step, S.counters + 1);
     oc_timer_begin(h, "gcfm_pair", s);
-    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, a->v_des);
+    hipLaunchKernelGGL(k_pair, dim3(S.ntiles), dim3(256), 0, s, P, S, a->v_des);
     oc_timer_end(h, "gcfm_pair", s);
     oc_timer_begin(h, "gcfm_wall", s);
     hipLaunchKernelGGL(k_wall, dim3(S.ntiles), dim3(64), 0, s, P, S, kd, a->key, a->v_des, h->X0, h->Y0);

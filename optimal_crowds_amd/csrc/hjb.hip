@@ -237,6 +237,224 @@ __global__ void k_vels(const TI* __restrict__ phi, TO* __restrict__ vx, TO* __re
     vy[o] = (TO)oy;
 }
 
+// ------------------------------------------------------------------------------------------ fused kernels
+// One RK stage in one pass: ytmp = y + sum_j c_j K_j is formed on a 64 x 16 tile (+1 halo, mirrored at the room
+// border like the reference's ghost rows) in LDS and the 5-point RHS is applied from LDS.  The FINAL variant forms
+// y_new, writes it, evaluates K6 = f(y_new) and accumulates the step's error norm (scipy rk.py:146-147).
+#define HT_X 64
+#define HT_Y 16
+#define HT_LW (HT_X + 2)
+#define HT_LH (HT_Y + 2)
+#define HT_HALO (2 * HT_LW + 2 * HT_Y)
+
+template <typename T>
+struct StageArgs {
+    const T* y;
+    const T* k[6];
+    T c[6];
+    const T* coef;
+    T* out;         // K_s (or K6)
+    T* ynew;        // FINAL only
+    T he[6];        // FINAL: h*E_j for the arrays in k[] (same order) ...
+    T he6;          // ... and h*E_6 for the new K6
+    T atol, rtol, a_lap;
+    double* partial;
+    int Ny, Nx;
+};
+
+__device__ __forceinline__ int mirror_index(int g, int n) {
+    if (g < 0) g = -g;                      // -1 -> 1   (ghost = second line, optimals.py:149-152)
+    if (g >= n) g = 2 * (n - 1) - g;        // n  -> n-2
+    return g < 0 ? 0 : (g >= n ? n - 1 : g);
+}
+
+template <typename T, int S, bool FINAL>
+__global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
+    __shared__ T tile[HT_LH][HT_LW];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * HT_X, i0 = blockIdx.y * HT_Y;
+    const int Ny = A.Ny, Nx = A.Nx;
+    T kreg[4][S];
+    T yreg[4], vreg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int li = ty + 4 * r, gi = i0 + li, gj = j0 + tx;
+        const bool valid = gi < Ny && gj < Nx;
+        const int64_t idx = (int64_t)(valid ? gi : 0) * Nx + (valid ? gj : 0);
+        T yv = A.y[idx], acc = (T)0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            T kv = A.k[j][idx];
+            kreg[r][j] = kv;
+            acc += A.c[j] * kv;
+        }
+        T v = yv + acc;
+        yreg[r] = yv;
+        vreg[r] = v;
+        tile[li + 1][tx + 1] = v;
+        if (FINAL && valid) A.ynew[idx] = v;
+    }
+    if (threadIdx.x < HT_HALO) {
+        int q = threadIdx.x, li, lj;
+        if (q < HT_LW) { li = 0; lj = q; }
+        else if (q < 2 * HT_LW) { li = HT_LH - 1; lj = q - HT_LW; }
+        else if (q < 2 * HT_LW + HT_Y) { li = q - 2 * HT_LW + 1; lj = 0; }
+        else { li = q - 2 * HT_LW - HT_Y + 1; lj = HT_LW - 1; }
+        const int gi = mirror_index(i0 + li - 1, Ny), gj = mirror_index(j0 + lj - 1, Nx);
+        const int64_t idx = (int64_t)gi * Nx + gj;
+        T acc = (T)0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) acc += A.c[j] * A.k[j][idx];
+        tile[li][lj] = A.y[idx] + acc;
+    }
+    __syncthreads();
+    double esum = 0.0, ymax = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int li = ty + 4 * r, gi = i0 + li, gj = j0 + tx;
+        if (gi >= Ny || gj >= Nx) continue;
+        const int64_t idx = (int64_t)gi * Nx + gj;
+        // mirror inside the tile when the neighbour is a ghost of the room border
+        const int lu = (gi == 0) ? li + 2 : li, ld = (gi == Ny - 1) ? li : li + 2;
+        const int ll = (gj == 0) ? tx + 2 : tx, lr = (gj == Nx - 1) ? tx : tx + 2;
+        const T C = tile[li + 1][tx + 1];
+        const T sum = tile[lu][tx + 1] + tile[ld][tx + 1] + tile[li + 1][ll] + tile[li + 1][lr] - (T)4 * C;
+        const T cf = A.coef[idx];
+        const T f = (cf != cf) ? (T)0 : A.a_lap * sum - cf * C;
+        A.out[idx] = f;
+        if (FINAL) {
+            T e = A.he6 * f;
+#pragma unroll
+            for (int j = 0; j < S; ++j) e += A.he[j] * kreg[r][j];
+            const T sc = A.atol + fmax(fabs(yreg[r]), fabs(vreg[r])) * A.rtol;
+            const T q = e / sc;
+            esum += (double)q * (double)q;
+            ymax = fmax(ymax, (double)fabs(vreg[r]));
+        }
+    }
+    if (FINAL) {
+        __shared__ double ls[4], lm[4];
+        esum = wave_sum(esum);
+        ymax = wave_max(ymax);
+        if (tx == 0) {
+            ls[ty] = esum;
+            lm[ty] = ymax;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int b = blockIdx.y * gridDim.x + blockIdx.x;
+            A.partial[2 * b] = ls[0] + ls[1] + ls[2] + ls[3];
+            A.partial[2 * b + 1] = fmax(fmax(lm[0], lm[1]), fmax(lm[2], lm[3]));
+        }
+    }
+}
+
+// Dense output + direction field for every t_eval point of one accepted step, in one pass: the quartic
+// interpolant's coefficients Q = K^T P (scipy rk.py:178-180) stay in registers, each slice's phi goes through a
+// double-buffered LDS tile, and vels (optimals.py:168-186) writes the slice of vx_opt / vy_opt.
+#define OUT_MAXS 16
+template <typename T>
+struct OutArgs {
+    const T* y;
+    const T* k[6];          // K0, K2, K3, K4, K5, K6 (row 1 of P is zero)
+    T p[6][4];              // the matching rows of P
+    T hx[OUT_MAXS][4];      // h*x, h*x^2, h*x^3, h*x^4 per slice
+    T* vx[OUT_MAXS];
+    T* vy[OUT_MAXS];
+    double* keep[OUT_MAXS];
+    double unscale;
+    T lim_s, lim, mu, inv2dx, inv2dy;
+    int ns, Ny, Nx;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
+    __shared__ T tile[2][HT_LH][HT_LW];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * HT_X, i0 = blockIdx.y * HT_Y;
+    const int Ny = A.Ny, Nx = A.Nx;
+    T yq[5], Q[5][4];
+    int hli = 0, hlj = 0;
+    const bool has_halo = threadIdx.x < HT_HALO;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        int gi, gj;
+        if (r < 4) {
+            gi = i0 + ty + 4 * r;
+            gj = j0 + tx;
+        } else {
+            int q = threadIdx.x;
+            if (q < HT_LW) { hli = 0; hlj = q; }
+            else if (q < 2 * HT_LW) { hli = HT_LH - 1; hlj = q - HT_LW; }
+            else if (q < 2 * HT_LW + HT_Y) { hli = q - 2 * HT_LW + 1; hlj = 0; }
+            else { hli = q - 2 * HT_LW - HT_Y + 1; hlj = HT_LW - 1; }
+            gi = i0 + hli - 1;
+            gj = j0 + hlj - 1;
+        }
+        gi = gi < 0 ? 0 : (gi >= Ny ? Ny - 1 : gi);      // values outside the grid are never used by vels
+        gj = gj < 0 ? 0 : (gj >= Nx ? Nx - 1 : gj);
+        if (r == 4 && !has_halo) continue;
+        const int64_t idx = (int64_t)gi * Nx + gj;
+        yq[r] = A.y[idx];
+        T kk[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) kk[j] = A.k[j][idx];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            T acc = (T)0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc += kk[j] * A.p[j][pp];
+            Q[r][pp] = acc;
+        }
+    }
+    auto clip = [&](T v) { return (v > A.lim_s) ? v : ((v < A.lim_s) ? A.lim_s : (T)0); };
+    for (int s = 0; s < A.ns; ++s) {
+        const int buf = s & 1;
+        const T h1 = A.hx[s][0], h2 = A.hx[s][1], h3 = A.hx[s][2], h4 = A.hx[s][3];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            if (r == 4 && !has_halo) continue;
+            const T phi = yq[r] + (((Q[r][0] * h1 + Q[r][1] * h2) + Q[r][2] * h3) + Q[r][3] * h4);
+            if (r < 4) {
+                const int li = ty + 4 * r;
+                tile[buf][li + 1][tx + 1] = phi;
+                const int gi = i0 + li, gj = j0 + tx;
+                if (A.keep[s] && gi < Ny && gj < Nx) A.keep[s][(int64_t)gi * Nx + gj] = (double)phi * A.unscale;
+            } else {
+                tile[buf][hli][hlj] = phi;
+            }
+        }
+        __syncthreads();
+        if (A.vx[s]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int li = ty + 4 * r, gi = i0 + li, gj = j0 + tx;
+                if (gi < 1 || gi >= Ny - 1 || gj < 1 || gj >= Nx - 1) continue;
+                const T pe = clip(tile[buf][li + 1][tx + 2]), pw = clip(tile[buf][li + 1][tx]);
+                const T pn = clip(tile[buf][li + 2][tx + 1]), ps = clip(tile[buf][li][tx + 1]);
+                const T pc = clip(clip(tile[buf][li + 1][tx + 1]));
+                const T gx = (pe - pw) * A.inv2dx, gy = (pn - ps) * A.inv2dy;
+                const T ux = gx / (A.mu * pc), uy = gy / (A.mu * pc);
+                const T norm = sqrt(ux * ux + uy * uy);
+                T ox, oy;
+                if (norm > A.lim) {
+                    ox = ux / norm;
+                    oy = uy / norm;
+                } else if (norm < A.lim) {
+                    ox = (T)0;
+                    oy = (T)0;
+                } else {
+                    ox = (T)NAN;
+                    oy = (T)NAN;
+                }
+                const int64_t o = (int64_t)(gi - 1) * (Nx - 2) + (gj - 1);
+                __builtin_nontemporal_store(ox, A.vx[s] + o);
+                __builtin_nontemporal_store(oy, A.vy[s] + o);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 template <typename T>
 struct Solver {
@@ -273,8 +491,9 @@ struct Solver {
         hipLaunchKernelGGL(k_rhs<T>, g2(Nx, Ny), b2(), 0, s, p, coef, out, Ny, Nx, a_lap);
         ++nfev;
     }
-    int reduce(double* sum, double* mx) {   // partials already written by a 1024-block kernel
-        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, h->red_partial, 1024, h->red_out);
+    int fused_blocks() const { return ((Nx + HT_X - 1) / HT_X) * ((Ny + HT_Y - 1) / HT_Y); }
+    int reduce(double* sum, double* mx, int nblocks = 1024) {   // partials written by the preceding kernel
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, h->red_partial, nblocks, h->red_out);
         OC_HIP_CHECK(hipMemcpyAsync(h->red_host, h->red_out, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
         OC_HIP_CHECK(hipStreamSynchronize(s));
         *sum = h->red_host[0];
@@ -282,6 +501,108 @@ struct Solver {
         return OC_OK;
     }
 };
+
+template <typename T, int SG>
+void launch_stage(Solver<T>& S, StageArgs<T>& A) {
+    dim3 g((S.Nx + HT_X - 1) / HT_X, (S.Ny + HT_Y - 1) / HT_Y);
+    hipLaunchKernelGGL((k_stage<T, SG, false>), g, dim3(256), 0, S.s, A);
+}
+
+// the six RHS evaluations of one RK attempt as six fused launches (stages 1..5 + y_new/K6/error)
+template <typename T>
+void launch_stages_fused(Solver<T>& S, double hh, T atol_s, T rtol) {
+    StageArgs<T> A;
+    memset(&A, 0, sizeof(A));
+    A.y = S.y;
+    A.coef = S.coef;
+    A.Ny = S.Ny;
+    A.Nx = S.Nx;
+    A.a_lap = S.a_lap;
+    A.atol = atol_s;
+    A.rtol = rtol;
+    A.partial = S.h->red_partial;
+    for (int sg = 1; sg < 6; ++sg) {
+        for (int j = 0; j < 6; ++j) {
+            A.k[j] = S.K[j < sg ? j : 0];
+            A.c[j] = j < sg ? (T)(RK_A[sg][j] * hh) : (T)0;
+        }
+        A.out = S.K[sg];
+        switch (sg) {
+            case 1: launch_stage<T, 1>(S, A); break;
+            case 2: launch_stage<T, 2>(S, A); break;
+            case 3: launch_stage<T, 3>(S, A); break;
+            case 4: launch_stage<T, 4>(S, A); break;
+            default: launch_stage<T, 5>(S, A); break;
+        }
+    }
+    const int nz[5] = {0, 2, 3, 4, 5};                 // B_1 = E_1 = 0
+    for (int q = 0; q < 5; ++q) {
+        A.k[q] = S.K[nz[q]];
+        A.c[q] = (T)(RK_B[nz[q]] * hh);
+        A.he[q] = (T)(RK_E[nz[q]] * hh);
+    }
+    A.he6 = (T)(RK_E[6] * hh);
+    A.out = S.K[6];
+    A.ynew = S.ynew;
+    dim3 g((S.Nx + HT_X - 1) / HT_X, (S.Ny + HT_Y - 1) / HT_Y);
+    hipLaunchKernelGGL((k_stage<T, 5, true>), g, dim3(256), 0, S.s, A);
+}
+
+// dense output of every t_eval point in (t_new, t] + direction field slices, <= OUT_MAXS slices per launch
+template <typename T>
+int emit_slices_fused(Solver<T>& S, const std::vector<double>& te, int nt, int& k_next, double t, double t_new,
+                      double hh, const std::vector<int>& keep_slot, double* phi_keep, void* vx_out, void* vy_out,
+                      size_t slice_elems, int expo, oc_hjb_stats& stats) {
+    const oc_config& c = S.h->cfg;
+    const int64_t n = S.n;
+    while (k_next < nt && te[k_next] >= t_new) {
+        OutArgs<T> A;
+        memset(&A, 0, sizeof(A));
+        A.y = S.y;
+        const int rows[6] = {0, 2, 3, 4, 5, 6};
+        for (int q = 0; q < 6; ++q) {
+            A.k[q] = S.K[rows[q]];
+            for (int p = 0; p < 4; ++p) A.p[q][p] = (T)RK_P[rows[q]][p];
+        }
+        A.unscale = std::ldexp(1.0, expo);
+        A.lim_s = (T)(c.lim * std::ldexp(1.0, -expo));
+        A.lim = (T)c.lim;
+        A.mu = (T)c.mu;
+        A.inv2dx = (T)(1.0 / (2 * c.dx));
+        A.inv2dy = (T)(1.0 / (2 * c.dy));
+        A.Ny = c.Ny;
+        A.Nx = c.Nx;
+        int ns = 0, nv = 0;
+        while (ns < OUT_MAXS && k_next < nt && te[k_next] >= t_new) {
+            int k = k_next++;
+            bool want_v = (k >= 1), want_keep = keep_slot[k] >= 0;
+            if (!want_v && !want_keep) continue;
+            double x = (te[k] - t) / hh;
+            double xp = x;
+            for (int p = 0; p < 4; ++p) {
+                A.hx[ns][p] = (T)(hh * xp);
+                xp *= x;
+            }
+            A.keep[ns] = want_keep ? phi_keep + (size_t)keep_slot[k] * n : nullptr;
+            if (want_v) {
+                int sidx = nt - 1 - k;
+                A.vx[ns] = (T*)vx_out + (size_t)sidx * slice_elems;
+                A.vy[ns] = (T*)vy_out + (size_t)sidx * slice_elems;
+                ++nv;
+            }
+            ++ns;
+        }
+        if (ns == 0) continue;
+        A.ns = ns;
+        dim3 g((S.Nx + HT_X - 1) / HT_X, (S.Ny + HT_Y - 1) / HT_Y);
+        oc_timer_begin(S.h, "hjb_out", S.s);
+        hipLaunchKernelGGL(k_out<T>, g, dim3(256), 0, S.s, A);
+        // algorithmic bytes: read y_old + 6 stage arrays once, write 2 field components per slice
+        oc_timer_end(S.h, "hjb_out", S.s, sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)slice_elems));
+        stats.n_slices_written += nv;
+    }
+    return OC_OK;
+}
 
 template <typename T>
 int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, void* vx_out, void* vy_out,
@@ -386,37 +707,48 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
             hh = t_new - t;
             h_abs = std::fabs(hh);
             ++stats.n_attempt;
-            for (int sg = 1; sg < 6; ++sg) {
-                Lin8<T> L;
-                L.n = sg;
-                for (int j = 0; j < sg; ++j) {
-                    L.k[j] = S.K[j];
-                    L.c[j] = (T)(RK_A[sg][j] * hh);
-                }
-                hipLaunchKernelGGL(k_lincomb<T>, S.g1(), dim3(256), 0, s, S.y, L, S.ytmp, n);
-                S.rhs(S.ytmp, S.K[sg]);
-            }
-            {
-                Lin8<T> L;
-                L.n = 6;
-                for (int j = 0; j < 6; ++j) {
-                    L.k[j] = S.K[j];
-                    L.c[j] = (T)(RK_B[j] * hh);
-                }
-                hipLaunchKernelGGL(k_lincomb<T>, S.g1(), dim3(256), 0, s, S.y, L, S.ynew, n);
-                S.rhs(S.ynew, S.K[6]);
-            }
-            Lin8<T> E;
-            E.n = 7;
-            for (int j = 0; j < 7; ++j) {
-                E.k[j] = S.K[j];
-                E.c[j] = (T)(RK_E[j] * hh);
-            }
+            int nred = RB;
             double atol_s = atol0 * scale_of();
-            hipLaunchKernelGGL(k_err_norm<T>, dim3(RB), dim3(256), 0, s, S.y, S.ynew, E, (T)atol_s, (T)rtol, n,
-                               h->red_partial);
+            oc_timer_begin(h, "hjb_stage", s);
+            if (h->hjb_variant == 0) {
+                launch_stages_fused(S, hh, (T)atol_s, (T)rtol);
+                S.nfev += 6;
+                nred = S.fused_blocks();
+            } else {
+                for (int sg = 1; sg < 6; ++sg) {
+                    Lin8<T> L;
+                    L.n = sg;
+                    for (int j = 0; j < sg; ++j) {
+                        L.k[j] = S.K[j];
+                        L.c[j] = (T)(RK_A[sg][j] * hh);
+                    }
+                    hipLaunchKernelGGL(k_lincomb<T>, S.g1(), dim3(256), 0, s, S.y, L, S.ytmp, n);
+                    S.rhs(S.ytmp, S.K[sg]);
+                }
+                {
+                    Lin8<T> L;
+                    L.n = 6;
+                    for (int j = 0; j < 6; ++j) {
+                        L.k[j] = S.K[j];
+                        L.c[j] = (T)(RK_B[j] * hh);
+                    }
+                    hipLaunchKernelGGL(k_lincomb<T>, S.g1(), dim3(256), 0, s, S.y, L, S.ynew, n);
+                    S.rhs(S.ynew, S.K[6]);
+                }
+                Lin8<T> E;
+                E.n = 7;
+                for (int j = 0; j < 7; ++j) {
+                    E.k[j] = S.K[j];
+                    E.c[j] = (T)(RK_E[j] * hh);
+                }
+                hipLaunchKernelGGL(k_err_norm<T>, dim3(RB), dim3(256), 0, s, S.y, S.ynew, E, (T)atol_s, (T)rtol, n,
+                                   h->red_partial);
+                nred = RB;
+            }
+            // algorithmic bytes of one attempt: 39 array passes
+            oc_timer_end(h, "hjb_stage", s, 39.0 * sizeof(T) * (double)n);
             double esum, ymax;
-            if ((rc = S.reduce(&esum, &ymax))) return rc;
+            if ((rc = S.reduce(&esum, &ymax, nred))) return rc;
             double err = std::sqrt(esum) / std::sqrt((double)n);
             if (!(err == err)) {
                 oc_set_error("RK45: NaN error norm at t=%g (state overflow?)", t);
@@ -430,32 +762,38 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                 stats.h_min = std::min(stats.h_min, std::fabs(hh));
                 stats.h_max = std::max(stats.h_max, std::fabs(hh));
                 // ---- dense output for t_eval points in (t_new, t]  (scipy ivp.py:706-723)
-                while (k_next < nt && te[k_next] >= t_new) {
-                    int k = k_next++;
-                    bool want_v = (k >= 1);
-                    bool want_keep = keep_slot[k] >= 0;
-                    if (!want_v && !want_keep) continue;
-                    double x = (te[k] - t) / hh;
-                    double xp[4] = {x, x * x, x * x * x, x * x * x * x};
-                    Lin8<T> W;
-                    W.n = 7;
-                    for (int j = 0; j < 7; ++j) {
-                        double w = 0;
-                        for (int p = 0; p < 4; ++p) w += RK_P[j][p] * xp[p];
-                        W.k[j] = S.K[j];
-                        W.c[j] = (T)(hh * w);
-                    }
-                    double* kp = want_keep ? phi_keep + (size_t)keep_slot[k] * n : nullptr;
-                    hipLaunchKernelGGL(k_dense<T>, S.g1(), dim3(256), 0, s, S.y, W, S.phi_tmp, kp,
-                                       std::ldexp(1.0, expo), n);
-                    if (want_v) {
-                        int sidx = nt - 1 - k;
-                        T* vx = (T*)vx_out + (size_t)sidx * slice_elems;
-                        T* vy = (T*)vy_out + (size_t)sidx * slice_elems;
-                        hipLaunchKernelGGL((k_vels<T, T>), S.g2(c.Nx - 2, c.Ny - 2), S.b2(), 0, s, S.phi_tmp, vx, vy,
-                                           c.Ny, c.Nx, (T)(c.lim * scale_of()), (T)c.lim, (T)c.mu,
-                                           (T)(1.0 / (2 * c.dx)), (T)(1.0 / (2 * c.dy)));
-                        ++stats.n_slices_written;
+                if (h->hjb_variant == 0) {
+                    if ((rc = emit_slices_fused(S, te, nt, k_next, t, t_new, hh, keep_slot, phi_keep, vx_out, vy_out,
+                                                slice_elems, expo, stats)))
+                        return rc;
+                } else {
+                    while (k_next < nt && te[k_next] >= t_new) {
+                        int k = k_next++;
+                        bool want_v = (k >= 1);
+                        bool want_keep = keep_slot[k] >= 0;
+                        if (!want_v && !want_keep) continue;
+                        double x = (te[k] - t) / hh;
+                        double xp[4] = {x, x * x, x * x * x, x * x * x * x};
+                        Lin8<T> W;
+                        W.n = 7;
+                        for (int j = 0; j < 7; ++j) {
+                            double w = 0;
+                            for (int p = 0; p < 4; ++p) w += RK_P[j][p] * xp[p];
+                            W.k[j] = S.K[j];
+                            W.c[j] = (T)(hh * w);
+                        }
+                        double* kp = want_keep ? phi_keep + (size_t)keep_slot[k] * n : nullptr;
+                        hipLaunchKernelGGL(k_dense<T>, S.g1(), dim3(256), 0, s, S.y, W, S.phi_tmp, kp,
+                                           std::ldexp(1.0, expo), n);
+                        if (want_v) {
+                            int sidx = nt - 1 - k;
+                            T* vx = (T*)vx_out + (size_t)sidx * slice_elems;
+                            T* vy = (T*)vy_out + (size_t)sidx * slice_elems;
+                            hipLaunchKernelGGL((k_vels<T, T>), S.g2(c.Nx - 2, c.Ny - 2), S.b2(), 0, s, S.phi_tmp, vx,
+                                               vy, c.Ny, c.Nx, (T)(c.lim * scale_of()), (T)c.lim, (T)c.mu,
+                                               (T)(1.0 / (2 * c.dx)), (T)(1.0 / (2 * c.dy)));
+                            ++stats.n_slices_written;
+                        }
                     }
                 }
                 // ---- advance

@@ -1,6 +1,7 @@
 // Handle lifetime, error reporting and kernel timers of liboc_hip.so.
 #include "oc_internal.h"
 #include <cstdarg>
+#include <algorithm>
 
 static thread_local char g_err[1024] = "";
 
@@ -40,8 +41,8 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
     OC_HIP_CHECK(hipMalloc(&h->Y0, sizeof(double) * cfg->Ny));
     OC_HIP_CHECK(hipMemcpy(h->X0, X0_host, sizeof(double) * cfg->Nx, hipMemcpyHostToDevice));
     OC_HIP_CHECK(hipMemcpy(h->Y0, Y0_host, sizeof(double) * cfg->Ny, hipMemcpyHostToDevice));
-    h->red_blocks = 4096;
-    OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * 4 * h->red_blocks));
+    h->red_blocks = std::max(1024, ((cfg->Nx + 63) / 64) * ((cfg->Ny + 15) / 16));
+    OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * 2 * h->red_blocks));
     OC_HIP_CHECK(hipMalloc(&h->red_out, sizeof(double) * 16));
     OC_HIP_CHECK(hipHostMalloc(&h->red_host, sizeof(double) * 16));
     *out = h;
@@ -65,10 +66,8 @@ extern "C" int oc_destroy(oc_handle* h) {
     (void)hipFree(h->key_tables_dev);
     (void)hipFree(h->gcfm_buf);
     (void)hipFree(h->sort_tmp);
-    for (auto& kv : h->timers) {
-        if (kv.second.a) (void)hipEventDestroy(kv.second.a);
-        if (kv.second.b) (void)hipEventDestroy(kv.second.b);
-    }
+    for (auto& kv : h->timers)
+        for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
     delete h;
     return OC_OK;
 }
@@ -82,28 +81,61 @@ extern "C" int oc_set_profiling(oc_handle* h, int enabled) {
 void oc_timer_begin(oc_handle* h, const char* name, hipStream_t s) {
     if (!h->profiling) return;
     oc_timer& t = h->timers[name];
-    if (!t.a) {
-        (void)hipEventCreate(&t.a);
-        (void)hipEventCreate(&t.b);
+    if (t.used + 2 > t.ev.size()) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        t.ev.push_back(a);
+        t.ev.push_back(b);
     }
-    (void)hipEventRecord(t.a, s);
+    (void)hipEventRecord(t.ev[t.used], s);
 }
 
-void oc_timer_end(oc_handle* h, const char* name, hipStream_t s) {
+void oc_timer_end(oc_handle* h, const char* name, hipStream_t s, double bytes) {
     if (!h->profiling) return;
     oc_timer& t = h->timers[name];
-    (void)hipEventRecord(t.b, s);
-    t.valid = true;
+    if (t.used + 2 > t.ev.size()) return;
+    (void)hipEventRecord(t.ev[t.used + 1], s);
+    t.used += 2;
+    t.bytes += bytes;
 }
 
-extern "C" double oc_last_kernel_ms(oc_handle* h, const char* name) {
-    if (!h || !name) return -1.0;
+extern "C" int oc_kernel_stats(oc_handle* h, const char* name, int64_t* launches, double* total_ms,
+                               double* total_bytes) {
+    OC_REQUIRE(h && name, "null argument");
     auto it = h->timers.find(name);
-    if (it == h->timers.end() || !it->second.valid) return -1.0;
-    if (hipEventSynchronize(it->second.b) != hipSuccess) return -1.0;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, it->second.a, it->second.b) != hipSuccess) return -1.0;
-    return (double)ms;
+    int64_t n = 0;
+    double ms = 0.0, bytes = 0.0;
+    if (it != h->timers.end()) {
+        oc_timer& t = it->second;
+        for (size_t q = 0; q + 1 < t.used; q += 2) {
+            OC_HIP_CHECK(hipEventSynchronize(t.ev[q + 1]));
+            float e = 0.f;
+            OC_HIP_CHECK(hipEventElapsedTime(&e, t.ev[q], t.ev[q + 1]));
+            ms += e;
+            ++n;
+        }
+        bytes = t.bytes;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (total_bytes) *total_bytes = bytes;
+    return OC_OK;
+}
+
+extern "C" int oc_reset_kernel_stats(oc_handle* h) {
+    OC_REQUIRE(h, "null handle");
+    for (auto& kv : h->timers) {
+        kv.second.used = 0;
+        kv.second.bytes = 0.0;
+    }
+    return OC_OK;
+}
+
+extern "C" int oc_set_hjb_variant(oc_handle* h, int variant) {
+    OC_REQUIRE(h && (variant == 0 || variant == 1), "bad argument");
+    h->hjb_variant = variant;
+    return OC_OK;
 }
 
 extern "C" int oc_set_field(oc_handle* h, int key, int dtype, const void* vx, const void* vy, int32_t nslice_alloc,

@@ -52,8 +52,9 @@ struct oc_key_rects {
 };
 
 struct oc_timer {
-    hipEvent_t a = nullptr, b = nullptr;
-    bool valid = false;
+    std::vector<hipEvent_t> ev;   // pairs (begin, end), reused after a reset
+    size_t used = 0;
+    double bytes = 0.0;
 };
 
 struct oc_handle {
@@ -85,12 +86,13 @@ struct oc_handle {
     size_t sort_tmp_bytes = 0;
     // ---- profiling
     bool profiling = false;
+    int hjb_variant = 0;
     std::map<std::string, oc_timer> timers;
 };
 
 // timers (oc_api.hip)
 void oc_timer_begin(oc_handle* h, const char* name, hipStream_t s);
-void oc_timer_end(oc_handle* h, const char* name, hipStream_t s);
+void oc_timer_end(oc_handle* h, const char* name, hipStream_t s, double bytes = 0.0);
 
 // sort.hip: order[] = agent indices sorted by (cellkey, index); keys/vals scratch live in the handle
 int oc_sort_pairs(oc_handle* h, uint32_t* keys_in, uint32_t* keys_out, int32_t* vals_in, int32_t* vals_out,

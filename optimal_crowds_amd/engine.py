@@ -81,8 +81,17 @@ class Engine:
     def set_profiling(self, on=True):
         check(self.lib.oc_set_profiling(self.h, int(on)))
 
-    def last_kernel_ms(self, name):
-        return self.lib.oc_last_kernel_ms(self.h, name.encode())
+    def kernel_stats(self, name):
+        """(launches, total_ms, total_algorithmic_bytes) of a kernel class since the last reset."""
+        n, ms, by = C.c_int64(), C.c_double(), C.c_double()
+        check(self.lib.oc_kernel_stats(self.h, name.encode(), C.byref(n), C.byref(ms), C.byref(by)))
+        return n.value, ms.value, by.value
+
+    def reset_kernel_stats(self):
+        check(self.lib.oc_reset_kernel_stats(self.h))
+
+    def set_hjb_variant(self, variant):
+        check(self.lib.oc_set_hjb_variant(self.h, int(variant)))
 
     # ------------------------------------------------------------------ per-key data
     def set_potential(self, key, V_host, rects):

@@ -116,7 +116,7 @@ class simulation:
         nt0 = round(self.T / self.dt)
         self._nt0 = nt0
         if wall_search_radius is None:
-            wall_search_radius = 0.0
+            wall_search_radius = -1.0          # per-agent radius beyond which the wall force is < 1e-12 m/s
         self._engine = Engine(var_config, self.room_length, self.room_height, self.Nx, self.Ny, self._X0, self._Y0,
                               len(key_names), self.N, device=device, dtype=dtype,
                               wall_search_radius=wall_search_radius)

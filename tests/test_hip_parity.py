@@ -266,3 +266,39 @@ def test_trajectories_vs_oracle_synchronous(golden):
     assert np.array_equal(st["status"].astype(bool), sim.status)
     assert np.abs(st["x"] - sim.x).max() <= 1e-3 and np.abs(st["y"] - sim.y).max() <= 1e-3
     eng.close()
+
+
+def test_fused_and_simple_hjb_kernels_agree(golden):
+    """The fused stage/output kernels and the one-array-per-pass kernels implement the same arithmetic."""
+    import torch
+    g = golden("G3_solve_gold_a_T4.npz")
+    out = []
+    for variant in (0, 1):
+        eng, room, cfg, X0, Y0 = _engine("gold_a", "float64")
+        eng.set_hjb_variant(variant)
+        T, nt = float(g["T"]), int(g["nt"])
+        eng.set_potential(0, g["V"], _rects(room, str(g["key"])))
+        eng.alloc_field(0, nt - 1)
+        st, phi = eng.solve(0, T, nt, m=torch.as_tensor(g["m"]), keep=g["slices"])
+        out.append((st, phi.cpu().numpy(), eng.fields[0][0].cpu().numpy(), eng.fields[0][1].cpu().numpy()))
+        eng.close()
+    assert out[0][0]["nfev"] == out[1][0]["nfev"] == int(g["nfev"])
+    assert np.allclose(out[0][1], out[1][1], rtol=1e-11, atol=0)
+    assert np.allclose(out[0][1], g["phi"], rtol=1e-9, atol=0)
+    assert np.allclose(out[0][2], out[1][2], atol=1e-8) and np.allclose(out[0][3], out[1][3], atol=1e-8)
+
+
+def test_wall_auto_radius_drops_only_negligible_forces(golden):
+    """wall_search_radius < 0: agents search only as far as their wall force can exceed 1e-12 m/s."""
+    g = golden("G6_forces.npz")
+    eng, room, cfg, X0, Y0 = _engine("gold_b", "float32", n_keys=1, wall_search_radius=-1.0)
+    eng.set_potential(0, g["V_0"], np.zeros((0, 4)))
+    n = len(g["wp"])
+    eng.set_agents(g["wp"][:, 0], g["wp"][:, 1], g["wv"][:, 0], g["wv"][:, 1], g["wvdes"], np.zeros(n, dtype=np.int32))
+    idx, f = eng.wall_force()
+    f = f.cpu().numpy()
+    nan = np.isnan(g["wforce"][0]).any(axis=1)
+    assert np.abs(f[~nan] - g["wforce"][0][~nan]).max() <= 1e-12
+    found = idx.cpu().numpy() >= 0
+    assert np.array_equal(idx.cpu().numpy()[found], g["windex"][0][found])
+    eng.close()
