@@ -77,7 +77,9 @@ typedef struct oc_hjb_stats {
 /* Replaces compute_optimal_velocity's solve_ivp(RK45, t_eval=linspace(T,0,nt)) + vels() fill loop,
  * optimals.py:193-204 (+ SciPy RK45 rk.py:14-180, 552-575; common.py:63-134; ivp.py:598-723).
  *   nt        = round((T - t_now)/dt)   (optimals.py:139-142); slices s = 0..nt-2 of vx_out/vy_out are written:
- *               vx_out[s] = direction field of phi(t = s*T/(nt-1)), layout (nslice, Ny-2, Nx-2) of `dtype`.
+ *               vx_out[s] = direction field of phi(t = s*T/(nt-1)).  Layout: (nslice, Ny, Nx) of `dtype`, i.e. each
+ *               slice padded to the full grid so rows are 16-byte aligned; the reference's vx_opt[s] (Ny-2, Nx-2)
+ *               is the interior block [1:-1, 1:-1], the border ring is written as 0.
  *   keep_idx  : optional HOST list of n_keep t_eval indices k whose phi(t_eval[k]) is stored unscaled as
  *               float64 (n_keep, Ny, Nx) in phi_keep (device) -- audit/tests only.
  *   t_steps   : optional HOST buffer (cap t_steps_cap) receiving accepted step end times.
@@ -88,7 +90,7 @@ int oc_hjb_solve(oc_handle* h, int dtype, const void* coef, double T, int32_t nt
                  double* t_steps, int32_t t_steps_cap,
                  oc_hjb_stats* stats, void* stream);
 
-/* Direction field of one phi (float64 input, dtype output (Ny-2, Nx-2)): replaces `vels`, optimals.py:168-186. */
+/* Direction field of one phi (float64 input (Ny,Nx), dtype output padded (Ny,Nx)): replaces `vels`, optimals.py:168-186. */
 int oc_hjb_vels(oc_handle* h, int dtype, const void* phi, double scale, void* vx, void* vy, void* stream);
 
 /* ---- per-key data used by the agent step ------------------------------------------------------------------ */

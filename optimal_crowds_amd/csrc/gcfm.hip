@@ -14,15 +14,17 @@
 // Per-agent work (lookup, wall search + force, integration, exit test) is float64.
 #include "oc_internal.h"
 #include <cmath>
+#include <algorithm>
 
 namespace {
 
 struct KeyDev {
     const void* vx;
     const void* vy;
-    const int32_t* left;
-    const int32_t* right;
+    const int2* lr;        // [Nx][Ny]: (nearest site column <= j or -1, nearest site column >= j+1 or Nx) of row r
+    const float* edt;      // (Ny,Nx) distance from each grid node to the nearest site, capped at edt_cap (lower bound)
     double off;
+    double edt_cap;
     int32_t dtype, nslice_alloc, nt_opt, nrect;
     double rect[OC_MAX_TARGET_RECTS][4];
 };
@@ -262,6 +264,59 @@ __device__ __forceinline__ double wall_radius_of(const GcfmParams& P, double s) 
 }
 
 #define WALL_UNROLL 4
+// Scan grid rows outward from the row nearest to py; per row the two candidates bracketing px come from the
+// transposed table lr[jx][row] (rows contiguous: 4 rows = 32 bytes per lane and direction).  Rows stop when
+// their |dy| alone exceeds the best distance (+ tie slack), the search radius, or a known upper bound ub2.
+__device__ __forceinline__ void wall_scan(double px, double py, const int2* __restrict__ lr, int Nx, int Ny, double hx,
+                                          double hy, const double* __restrict__ X0, const double* __restrict__ Y0,
+                                          double off, double rad2, double ub2, long long& best_flat, double& best_d2) {
+    int jx = (int)floor(px / hx);
+    jx = jx < 0 ? 0 : (jx > Nx - 1 ? Nx - 1 : jx);
+    while (jx > 0 && X0[jx] > px) --jx;
+    while (jx < Nx - 1 && X0[jx + 1] <= px) ++jx;
+    int r0 = (int)floor(py / hy + 0.5);
+    r0 = r0 < 0 ? 0 : (r0 > Ny - 1 ? Ny - 1 : r0);
+    const int2* __restrict__ col = lr + (size_t)jx * Ny;
+    double thr = INFINITY, best_f = INFINITY;
+    best_d2 = INFINITY;
+    best_flat = -1;
+    const double lim2 = fmin(rad2, ub2);
+    bool up = true, dn = true;
+    for (int o = 0; up || dn; o += WALL_UNROLL) {
+        int rows[2 * WALL_UNROLL];
+        int2 cand[2 * WALL_UNROLL];
+        double yr[2 * WALL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < WALL_UNROLL; ++u) {
+            int ru = r0 + o + u, rd = r0 - o - u;
+            rows[2 * u] = (up && ru < Ny) ? ru : -1;
+            rows[2 * u + 1] = (dn && rd >= 0 && (o + u) > 0) ? rd : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * WALL_UNROLL; ++q) {
+            int rr = rows[q] >= 0 ? rows[q] : 0;
+            yr[q] = Y0[rr];
+            cand[q] = col[rr];
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * WALL_UNROLL; ++q) {
+            int r = rows[q];
+            if (r < 0) continue;
+            double ady = fabs(yr[q] - py), ady2 = ady * ady;
+            if (ady2 > thr || ady2 > lim2) {
+                // rows only get farther in this direction once they are past the query point
+                if ((q & 1) == 0) { if (yr[q] > py) up = false; }
+                else { if (yr[q] < py) dn = false; }
+                continue;
+            }
+            wall_try(px, py, r, cand[q].x, Nx, X0, yr[q], off, best_d2, thr, best_f, best_flat);
+            wall_try(px, py, r, cand[q].y, Nx, X0, yr[q], off, best_d2, thr, best_f, best_flat);
+        }
+        if (r0 + o + WALL_UNROLL >= Ny) up = false;
+        if (r0 - o - WALL_UNROLL < 0) dn = false;
+    }
+}
+
 __global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
                                              const int32_t* __restrict__ key_of, const double* __restrict__ v_des,
                                              const double* __restrict__ X0, const double* __restrict__ Y0) {
@@ -274,57 +329,41 @@ __global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyD
         const double2 p = S.ppos[k];
         const int Nx = P.Nx, Ny = P.Ny;
         const double hx = P.L / (Nx - 1), hy = P.H / (Ny - 1);
-        // column bracket: X0[jx] <= px < X0[jx+1], clipped
-        int jx = (int)floor(p.x / hx);
-        jx = jx < 0 ? 0 : (jx > Nx - 1 ? Nx - 1 : jx);
-        while (jx > 0 && X0[jx] > p.x) --jx;
-        while (jx < Nx - 1 && X0[jx + 1] <= p.x) ++jx;
-        const int jr = (jx + 1 < Nx) ? jx + 1 : -1;
-        int r0 = (int)floor(p.y / hy + 0.5);
-        r0 = r0 < 0 ? 0 : (r0 > Ny - 1 ? Ny - 1 : r0);
-        double best_d2 = INFINITY, thr = INFINITY, best_f = INFINITY;
         const double rad = wall_radius_of(P, (double)S.pvel[k].z);
         const double rad2 = rad > 0 ? rad * rad : INFINITY;
-        // rows r0, r0+1, r0-1, r0+2, ... in groups: all loads of a group are issued before they are used
-        bool up = true, dn = true;
-        for (int o = 0; up || dn; o += WALL_UNROLL) {
-            int rows[2 * WALL_UNROLL], cl[2 * WALL_UNROLL], cr[2 * WALL_UNROLL];
-            double yr[2 * WALL_UNROLL];
-#pragma unroll
-            for (int u = 0; u < WALL_UNROLL; ++u) {
-                int ru = r0 + o + u, rd = r0 - o - u;
-                bool vu = up && ru < Ny, vd = dn && rd >= 0 && (o + u) > 0;
-                rows[2 * u] = vu ? ru : -1;
-                rows[2 * u + 1] = vd ? rd : -1;
+        // distance bound from the capped EDT at the nearest grid node: d(node) - |p-node| <= d*(p) <= d(node) + |p-node|
+        int jn = (int)floor(p.x / hx + 0.5), in = (int)floor(p.y / hy + 0.5);
+        jn = jn < 0 ? 0 : (jn > Nx - 1 ? Nx - 1 : jn);
+        in = in < 0 ? 0 : (in > Ny - 1 ? Ny - 1 : in);
+        const double ex = X0[jn] - p.x, ey = Y0[in] - p.y;
+        const double delta = sqrt(ex * ex + ey * ey) * (1.0 + 1e-12) + 1e-12;
+        const double dn = (double)kd.edt[(size_t)in * Nx + jn];
+        bool skip = (rad > 0) && (dn * (1.0 - 1e-6) - delta > rad);   // provably beyond the radius: force < 1e-12
+        if (!skip) {
+            double ub2 = INFINITY;
+            if (dn < kd.edt_cap) {
+                double ub = dn * (1.0 + 1e-6) + delta + 1e-9;
+                ub2 = ub * ub;
             }
-#pragma unroll
-            for (int q = 0; q < 2 * WALL_UNROLL; ++q) {
-                int r = rows[q];
-                bool v = r >= 0;
-                int rr = v ? r : 0;
-                yr[q] = Y0[rr];
-                cl[q] = v ? kd.left[(long long)rr * Nx + jx] : -1;
-                cr[q] = (v && jr >= 0) ? kd.right[(long long)rr * Nx + jr] : -1;
-            }
-#pragma unroll
-            for (int q = 0; q < 2 * WALL_UNROLL; ++q) {
-                int r = rows[q];
-                if (r < 0) continue;
-                double ady = fabs(yr[q] - p.y), ady2 = ady * ady;
-                if (ady2 > thr || ady2 > rad2) {
-                    // rows only get farther in this direction once they are past the agent
-                    if ((q & 1) == 0) { if (yr[q] > p.y) up = false; }
-                    else { if (yr[q] < p.y) dn = false; }
-                    continue;
-                }
-                wall_try(p.x, p.y, r, cl[q], Nx, X0, yr[q], kd.off, best_d2, thr, best_f, best_flat);
-                wall_try(p.x, p.y, r, cr[q], Nx, X0, yr[q], kd.off, best_d2, thr, best_f, best_flat);
-            }
-            if (r0 + o + WALL_UNROLL >= Ny) up = false;
-            if (r0 - o - WALL_UNROLL < 0) dn = false;
+            double bd2;
+            wall_scan(p.x, p.y, kd.lr, Nx, Ny, hx, hy, X0, Y0, kd.off, rad2, ub2, best_flat, bd2);
         }
     }
     S.widx[k] = best_flat;
+}
+
+// capped exact distance transform of the site set on the grid nodes (init-time, one thread per node)
+__global__ void __launch_bounds__(256) k_edt(const int2* __restrict__ lr, int Nx, int Ny, double hx, double hy,
+                                             const double* __restrict__ X0, const double* __restrict__ Y0, double cap,
+                                             float* __restrict__ edt) {
+    int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= Ny || j >= Nx) return;
+    long long flat;
+    double d2;
+    wall_scan(X0[j], Y0[i], lr, Nx, Ny, hx, hy, X0, Y0, 0.0, cap * cap, INFINITY, flat, d2);
+    double d = (flat >= 0) ? sqrt(d2) : cap;
+    edt[(size_t)i * Nx + j] = (float)fmin(d, cap);
 }
 
 // wall force from the selected cell, float64 (pedestrians.py:317-334)
@@ -383,9 +422,10 @@ __device__ __forceinline__ double py_floordiv(double vx, double wx) {
 template <typename T>
 __device__ __forceinline__ double2 field_fetch(const KeyDev& kd, int step, int i0, int i1, int j0, int j1, int Nx,
                                                int Ny) {
-    const size_t W = (size_t)(Nx - 2), Hh = (size_t)(Ny - 2);
-    const T* fx = (const T*)kd.vx + (size_t)step * W * Hh;
-    const T* fy = (const T*)kd.vy + (size_t)step * W * Hh;
+    // slices are stored padded as (Ny, Nx); the reference's (Ny-2, Nx-2) array is the interior block
+    const size_t W = (size_t)Nx;
+    const T* fx = (const T*)kd.vx + (size_t)step * W * Ny + W + 1;
+    const T* fy = (const T*)kd.vy + (size_t)step * W * Ny + W + 1;
     double ax = (double)fx[(size_t)i0 * W + j0], bx = (double)fx[(size_t)i1 * W + j1];
     double ay = (double)fy[(size_t)i0 * W + j0], by = (double)fy[(size_t)i1 * W + j1];
     return make_double2((ax + bx) / 2, (ay + by) / 2);
@@ -523,21 +563,20 @@ __global__ void k_scatter(const TV* __restrict__ src, const int32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------- wall map build
-// left[i][j] = largest site column <= j (or -1); right[i][j] = smallest site column >= j (or Nx).  One thread per row.
-__global__ void k_wallmap(const float* __restrict__ V, float vmin, int Ny, int Nx, int32_t* __restrict__ left,
-                          int32_t* __restrict__ right) {
+// lr[j][r] = (largest site column <= j or -1, smallest site column >= j+1 or Nx) of grid row r.  One thread per row.
+__global__ void k_wallmap(const float* __restrict__ V, float vmin, int Ny, int Nx, int2* __restrict__ lr) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= Ny) return;
     const float* row = V + (size_t)r * Nx;
     int last = -1;
     for (int j = 0; j < Nx; ++j) {
         if (row[j] == vmin) last = j;
-        left[(size_t)r * Nx + j] = last;
+        lr[(size_t)j * Ny + r].x = last;
     }
     last = Nx;
     for (int j = Nx - 1; j >= 0; --j) {
+        lr[(size_t)j * Ny + r].y = last;          // nearest site at a column >= j+1
         if (row[j] == vmin) last = j;
-        right[(size_t)r * Nx + j] = last;
     }
 }
 
@@ -607,9 +646,10 @@ int upload_keys(oc_handle* h, hipStream_t s) {
         d.dtype = h->fields[k].dtype;
         d.nslice_alloc = h->fields[k].nslice_alloc;
         d.nt_opt = h->fields[k].vx ? h->fields[k].nt_opt : 0;
-        d.left = h->wallmaps[k].left;
-        d.right = h->wallmaps[k].right;
+        d.lr = (const int2*)h->wallmaps[k].left;
+        d.edt = (const float*)h->wallmaps[k].right;
         d.off = h->wallmaps[k].off;
+        d.edt_cap = h->wallmaps[k].edt_cap;
         d.nrect = h->rects[k].n;
         memcpy(d.rect, h->rects[k].r, sizeof(d.rect));
     }
@@ -657,11 +697,17 @@ extern "C" int oc_wallmap_build(oc_handle* h, int key, const float* V, float vmi
     OC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     oc_wallmap& w = h->wallmaps[key];
-    size_t bytes = sizeof(int32_t) * (size_t)h->ncell;
-    if (!w.left) OC_HIP_CHECK(hipMalloc(&w.left, bytes));
-    if (!w.right) OC_HIP_CHECK(hipMalloc(&w.right, bytes));
-    hipLaunchKernelGGL(k_wallmap, dim3((h->cfg.Ny + 63) / 64), dim3(64), 0, s, V, vmin, h->cfg.Ny, h->cfg.Nx, w.left,
-                       w.right);
+    if (!w.left) OC_HIP_CHECK(hipMalloc((void**)&w.left, sizeof(int2) * (size_t)h->ncell));
+    if (!w.right) OC_HIP_CHECK(hipMalloc((void**)&w.right, sizeof(float) * (size_t)h->ncell));
+    const oc_config& c = h->cfg;
+    hipLaunchKernelGGL(k_wallmap, dim3((c.Ny + 63) / 64), dim3(64), 0, s, V, vmin, c.Ny, c.Nx, (int2*)w.left);
+    // cap: no per-agent search radius exceeds a(v_max)^2 + eta_w (1 + v_max) * 33 (wall_radius_of)
+    double amax = c.a_min + c.tau_a * c.v_max;
+    w.edt_cap = amax * amax + c.eta_walls * (1.0 + c.v_max) * 33.0 + 1.0;
+    if (c.wall_search_radius > 0) w.edt_cap = std::max(w.edt_cap, c.wall_search_radius + 1.0);
+    hipLaunchKernelGGL(k_edt, dim3((c.Nx + 63) / 64, (c.Ny + 3) / 4), dim3(256), 0, s, (const int2*)w.left, c.Nx, c.Ny,
+                       c.room_length / (c.Nx - 1), c.room_height / (c.Ny - 1), h->X0, h->Y0, w.edt_cap,
+                       (float*)w.right);
     OC_HIP_CHECK(hipGetLastError());
     w.off = (double)vmin * 10e3;
     w.built = true;

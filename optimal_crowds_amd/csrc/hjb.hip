@@ -232,20 +232,30 @@ __global__ void k_vels(const TI* __restrict__ phi, TO* __restrict__ vx, TO* __re
         ox = (TI)NAN;
         oy = (TI)NAN;
     }
-    int64_t o = (int64_t)(i - 1) * (Nx - 2) + (j - 1);
+    int64_t o = (int64_t)i * Nx + j;                 // padded (Ny, Nx) slice
     vx[o] = (TO)ox;
     vy[o] = (TO)oy;
 }
 
 // ------------------------------------------------------------------------------------------ fused kernels
-// One RK stage in one pass: ytmp = y + sum_j c_j K_j is formed on a 64 x 16 tile (+1 halo, mirrored at the room
-// border like the reference's ghost rows) in LDS and the 5-point RHS is applied from LDS.  The FINAL variant forms
-// y_new, writes it, evaluates K6 = f(y_new) and accumulates the step's error norm (scipy rk.py:146-147).
+// Tile = 64 columns x 16 rows per 256-thread block; thread (cx, ry) owns 4 consecutive cells of one row, so every
+// global access is one aligned 16-byte (float) / 32-byte (double) vector per lane.  The stage's working value on the
+// tile (+ a 1-cell halo: top/bottom rows, left/right columns; corners are not needed by the 5-point stencil) goes
+// through LDS with a 72-element row stride (interior starts at element 4 -> b128-aligned, conflict-free b128 rows).
 #define HT_X 64
 #define HT_Y 16
-#define HT_LW (HT_X + 2)
+#define HT_LS 72                 // LDS row stride (elements)
 #define HT_LH (HT_Y + 2)
-#define HT_HALO (2 * HT_LW + 2 * HT_Y)
+
+template <typename T>
+struct alignas(16) V4 {
+    T v[4];
+};
+
+template <typename T>
+__device__ __forceinline__ V4<T> ld4(const T* p) { return *reinterpret_cast<const V4<T>*>(p); }
+template <typename T>
+__device__ __forceinline__ void st4(T* p, const V4<T>& x) { *reinterpret_cast<V4<T>*>(p) = x; }
 
 template <typename T>
 struct StageArgs {
@@ -262,83 +272,116 @@ struct StageArgs {
     int Ny, Nx;
 };
 
-__device__ __forceinline__ int mirror_index(int g, int n) {
-    if (g < 0) g = -g;                      // -1 -> 1   (ghost = second line, optimals.py:149-152)
-    if (g >= n) g = 2 * (n - 1) - g;        // n  -> n-2
-    return g < 0 ? 0 : (g >= n ? n - 1 : g);
+// halo role of a thread: wave 0 lanes 0-15 top row, wave 1 lanes 0-15 bottom row (4 cells each),
+// wave 2 lanes 0-15 left column, wave 3 lanes 0-15 right column (1 cell each)
+struct HaloRole {
+    int kind;      // 0 none, 1 top, 2 bottom, 3 left, 4 right
+    int gi, gj;    // global cell (first of 4 for top/bottom), clamped into the grid
+    int li, lj;    // LDS row / element
+};
+
+__device__ __forceinline__ HaloRole halo_role(int i0, int j0, int Ny, int Nx) {
+    HaloRole r;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    r.kind = 0;
+    r.gi = r.gj = r.li = r.lj = 0;
+    if (l >= 16) return r;
+    if (w == 0) { r.kind = 1; r.gi = i0 - 1; r.gj = j0 + 4 * l; r.li = 0; r.lj = 4 + 4 * l; }
+    else if (w == 1) { r.kind = 2; r.gi = i0 + HT_Y; r.gj = j0 + 4 * l; r.li = HT_LH - 1; r.lj = 4 + 4 * l; }
+    else if (w == 2) { r.kind = 3; r.gi = i0 + l; r.gj = j0 - 1; r.li = l + 1; r.lj = 3; }
+    else { r.kind = 4; r.gi = i0 + l; r.gj = j0 + HT_X; r.li = l + 1; r.lj = 4 + HT_X; }
+    // cells outside the grid are never used (the stencil mirrors inside the tile, vels skips the border)
+    bool ok = r.gi >= 0 && r.gi < Ny && r.gj >= 0 && r.gj < Nx;
+    if (!ok) r.kind = 0;
+    return r;
 }
 
 template <typename T, int S, bool FINAL>
 __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
-    __shared__ T tile[HT_LH][HT_LW];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    __shared__ alignas(16) T tile[HT_LH][HT_LS];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int j0 = blockIdx.x * HT_X, i0 = blockIdx.y * HT_Y;
     const int Ny = A.Ny, Nx = A.Nx;
-    T kreg[4][S];
-    T yreg[4], vreg[4];
+    const int gi = i0 + ry, gj = j0 + 4 * cx;
+    const bool valid = gi < Ny && gj < Nx;             // Nx % 4 == 0: a vector is inside or outside as a whole
+    const int64_t idx = (int64_t)gi * Nx + gj;
+    V4<T> kreg[S];
+    V4<T> yv, tv;
+    if (valid) {
+        yv = ld4(A.y + idx);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int li = ty + 4 * r, gi = i0 + li, gj = j0 + tx;
-        const bool valid = gi < Ny && gj < Nx;
-        const int64_t idx = (int64_t)(valid ? gi : 0) * Nx + (valid ? gj : 0);
-        T yv = A.y[idx], acc = (T)0;
+        for (int q = 0; q < 4; ++q) tv.v[q] = (T)0;
 #pragma unroll
         for (int j = 0; j < S; ++j) {
-            T kv = A.k[j][idx];
-            kreg[r][j] = kv;
-            acc += A.c[j] * kv;
+            kreg[j] = ld4(A.k[j] + idx);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tv.v[q] += A.c[j] * kreg[j].v[q];
         }
-        T v = yv + acc;
-        yreg[r] = yv;
-        vreg[r] = v;
-        tile[li + 1][tx + 1] = v;
-        if (FINAL && valid) A.ynew[idx] = v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tv.v[q] = yv.v[q] + tv.v[q];
+        st4(&tile[ry + 1][4 + 4 * cx], tv);
+        if (FINAL) st4(A.ynew + idx, tv);
     }
-    if (threadIdx.x < HT_HALO) {
-        int q = threadIdx.x, li, lj;
-        if (q < HT_LW) { li = 0; lj = q; }
-        else if (q < 2 * HT_LW) { li = HT_LH - 1; lj = q - HT_LW; }
-        else if (q < 2 * HT_LW + HT_Y) { li = q - 2 * HT_LW + 1; lj = 0; }
-        else { li = q - 2 * HT_LW - HT_Y + 1; lj = HT_LW - 1; }
-        const int gi = mirror_index(i0 + li - 1, Ny), gj = mirror_index(j0 + lj - 1, Nx);
-        const int64_t idx = (int64_t)gi * Nx + gj;
+    const HaloRole hr = halo_role(i0, j0, Ny, Nx);
+    if (hr.kind == 1 || hr.kind == 2) {
+        const int64_t hidx = (int64_t)hr.gi * Nx + hr.gj;
+        V4<T> hv = ld4(A.y + hidx), acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc.v[q] = (T)0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            V4<T> kv = ld4(A.k[j] + hidx);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc.v[q] += A.c[j] * kv.v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv.v[q] = hv.v[q] + acc.v[q];
+        st4(&tile[hr.li][hr.lj], hv);
+    } else if (hr.kind >= 3) {
+        const int64_t hidx = (int64_t)hr.gi * Nx + hr.gj;
         T acc = (T)0;
 #pragma unroll
-        for (int j = 0; j < S; ++j) acc += A.c[j] * A.k[j][idx];
-        tile[li][lj] = A.y[idx] + acc;
+        for (int j = 0; j < S; ++j) acc += A.c[j] * A.k[j][hidx];
+        tile[hr.li][hr.lj] = A.y[hidx] + acc;
     }
     __syncthreads();
     double esum = 0.0, ymax = 0.0;
+    if (valid) {
+        // mirror ghosts of the room border (optimals.py:149-152) are taken from inside the tile
+        const int lu = (gi == 0) ? ry + 2 : ry, ld = (gi == Ny - 1) ? ry : ry + 2;
+        const V4<T> up = ld4(&tile[lu][4 + 4 * cx]), dn = ld4(&tile[ld][4 + 4 * cx]);
+        const T lft = (gj == 0) ? tv.v[1] : tile[ry + 1][3 + 4 * cx];
+        const T rgt = (gj + 3 == Nx - 1) ? tv.v[2] : tile[ry + 1][8 + 4 * cx];
+        const V4<T> cf = ld4(A.coef + idx);
+        V4<T> f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int li = ty + 4 * r, gi = i0 + li, gj = j0 + tx;
-        if (gi >= Ny || gj >= Nx) continue;
-        const int64_t idx = (int64_t)gi * Nx + gj;
-        // mirror inside the tile when the neighbour is a ghost of the room border
-        const int lu = (gi == 0) ? li + 2 : li, ld = (gi == Ny - 1) ? li : li + 2;
-        const int ll = (gj == 0) ? tx + 2 : tx, lr = (gj == Nx - 1) ? tx : tx + 2;
-        const T C = tile[li + 1][tx + 1];
-        const T sum = tile[lu][tx + 1] + tile[ld][tx + 1] + tile[li + 1][ll] + tile[li + 1][lr] - (T)4 * C;
-        const T cf = A.coef[idx];
-        const T f = (cf != cf) ? (T)0 : A.a_lap * sum - cf * C;
-        A.out[idx] = f;
+        for (int q = 0; q < 4; ++q) {
+            const T C = tv.v[q];
+            const T l = (q == 0) ? lft : tv.v[q - 1], r = (q == 3) ? rgt : tv.v[q + 1];
+            const T sum = up.v[q] + dn.v[q] + l + r - (T)4 * C;
+            f.v[q] = (cf.v[q] != cf.v[q]) ? (T)0 : A.a_lap * sum - cf.v[q] * C;
+        }
+        st4(A.out + idx, f);
         if (FINAL) {
-            T e = A.he6 * f;
 #pragma unroll
-            for (int j = 0; j < S; ++j) e += A.he[j] * kreg[r][j];
-            const T sc = A.atol + fmax(fabs(yreg[r]), fabs(vreg[r])) * A.rtol;
-            const T q = e / sc;
-            esum += (double)q * (double)q;
-            ymax = fmax(ymax, (double)fabs(vreg[r]));
+            for (int q = 0; q < 4; ++q) {
+                T e = A.he6 * f.v[q];
+#pragma unroll
+                for (int j = 0; j < S; ++j) e += A.he[j] * kreg[j].v[q];
+                const T sc = A.atol + fmax(fabs(yv.v[q]), fabs(tv.v[q])) * A.rtol;
+                const T qq = e / sc;
+                esum += (double)qq * (double)qq;
+                ymax = fmax(ymax, (double)fabs(tv.v[q]));
+            }
         }
     }
     if (FINAL) {
         __shared__ double ls[4], lm[4];
         esum = wave_sum(esum);
         ymax = wave_max(ymax);
-        if (tx == 0) {
-            ls[ty] = esum;
-            lm[ty] = ymax;
+        if ((threadIdx.x & 63) == 0) {
+            ls[threadIdx.x >> 6] = esum;
+            lm[threadIdx.x >> 6] = ymax;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -349,9 +392,14 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
     }
 }
 
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double fast_rsq(double x) { return 1.0 / sqrt(x); }
+
 // Dense output + direction field for every t_eval point of one accepted step, in one pass: the quartic
 // interpolant's coefficients Q = K^T P (scipy rk.py:178-180) stay in registers, each slice's phi goes through a
-// double-buffered LDS tile, and vels (optimals.py:168-186) writes the slice of vx_opt / vy_opt.
+// double-buffered LDS tile, and vels (optimals.py:168-186) writes the slice of the (padded) direction field.
 #define OUT_MAXS 16
 template <typename T>
 struct OutArgs {
@@ -368,34 +416,25 @@ struct OutArgs {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
-    __shared__ T tile[2][HT_LH][HT_LW];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int j0 = blockIdx.x * HT_X, i0 = blockIdx.y * HT_Y;
-    const int Ny = A.Ny, Nx = A.Nx;
-    T yq[5], Q[5][4];
-    int hli = 0, hlj = 0;
-    const bool has_halo = threadIdx.x < HT_HALO;
+__device__ __forceinline__ void interp_coeffs(const OutArgs<T>& A, int64_t idx, int n, T* yq, T (*Q)[4]) {
+    // n = 4: one vector of cells, n = 1: a single cell
+    if (n == 4) {
+        V4<T> yv = ld4(A.y + idx), kk[6];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        int gi, gj;
-        if (r < 4) {
-            gi = i0 + ty + 4 * r;
-            gj = j0 + tx;
-        } else {
-            int q = threadIdx.x;
-            if (q < HT_LW) { hli = 0; hlj = q; }
-            else if (q < 2 * HT_LW) { hli = HT_LH - 1; hlj = q - HT_LW; }
-            else if (q < 2 * HT_LW + HT_Y) { hli = q - 2 * HT_LW + 1; hlj = 0; }
-            else { hli = q - 2 * HT_LW - HT_Y + 1; hlj = HT_LW - 1; }
-            gi = i0 + hli - 1;
-            gj = j0 + hlj - 1;
+        for (int j = 0; j < 6; ++j) kk[j] = ld4(A.k[j] + idx);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            yq[q] = yv.v[q];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                T acc = (T)0;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc += kk[j].v[q] * A.p[j][pp];
+                Q[q][pp] = acc;
+            }
         }
-        gi = gi < 0 ? 0 : (gi >= Ny ? Ny - 1 : gi);      // values outside the grid are never used by vels
-        gj = gj < 0 ? 0 : (gj >= Nx ? Nx - 1 : gj);
-        if (r == 4 && !has_halo) continue;
-        const int64_t idx = (int64_t)gi * Nx + gj;
-        yq[r] = A.y[idx];
+    } else {
+        yq[0] = A.y[idx];
         T kk[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) kk[j] = A.k[j][idx];
@@ -404,53 +443,83 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
             T acc = (T)0;
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc += kk[j] * A.p[j][pp];
-            Q[r][pp] = acc;
+            Q[0][pp] = acc;
         }
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
+    __shared__ alignas(16) T tile[2][HT_LH][HT_LS];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int j0 = blockIdx.x * HT_X, i0 = blockIdx.y * HT_Y;
+    const int Ny = A.Ny, Nx = A.Nx;
+    const int gi = i0 + ry, gj = j0 + 4 * cx;
+    const bool valid = gi < Ny && gj < Nx;
+    const int64_t idx = (int64_t)gi * Nx + gj;
+    T yq[4], Q[4][4], hy[4], hQ[4][4];
+    if (valid) interp_coeffs(A, idx, 4, yq, Q);
+    const HaloRole hr = halo_role(i0, j0, Ny, Nx);
+    const int hn = (hr.kind == 1 || hr.kind == 2) ? 4 : (hr.kind >= 3 ? 1 : 0);
+    if (hn) interp_coeffs(A, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
     auto clip = [&](T v) { return (v > A.lim_s) ? v : ((v < A.lim_s) ? A.lim_s : (T)0); };
+    const T lim2 = A.lim * A.lim;
     for (int s = 0; s < A.ns; ++s) {
         const int buf = s & 1;
         const T h1 = A.hx[s][0], h2 = A.hx[s][1], h3 = A.hx[s][2], h4 = A.hx[s][3];
+        V4<T> ph;
+        if (valid) {
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            if (r == 4 && !has_halo) continue;
-            const T phi = yq[r] + (((Q[r][0] * h1 + Q[r][1] * h2) + Q[r][2] * h3) + Q[r][3] * h4);
-            if (r < 4) {
-                const int li = ty + 4 * r;
-                tile[buf][li + 1][tx + 1] = phi;
-                const int gi = i0 + li, gj = j0 + tx;
-                if (A.keep[s] && gi < Ny && gj < Nx) A.keep[s][(int64_t)gi * Nx + gj] = (double)phi * A.unscale;
-            } else {
-                tile[buf][hli][hlj] = phi;
+            for (int q = 0; q < 4; ++q)
+                ph.v[q] = yq[q] + (((Q[q][0] * h1 + Q[q][1] * h2) + Q[q][2] * h3) + Q[q][3] * h4);
+            st4(&tile[buf][ry + 1][4 + 4 * cx], ph);
+            if (A.keep[s]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) A.keep[s][idx + q] = (double)ph.v[q] * A.unscale;
             }
         }
-        __syncthreads();
-        if (A.vx[s]) {
+        if (hn == 4) {
+            V4<T> hp;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int li = ty + 4 * r, gi = i0 + li, gj = j0 + tx;
-                if (gi < 1 || gi >= Ny - 1 || gj < 1 || gj >= Nx - 1) continue;
-                const T pe = clip(tile[buf][li + 1][tx + 2]), pw = clip(tile[buf][li + 1][tx]);
-                const T pn = clip(tile[buf][li + 2][tx + 1]), ps = clip(tile[buf][li][tx + 1]);
-                const T pc = clip(clip(tile[buf][li + 1][tx + 1]));
+            for (int q = 0; q < 4; ++q)
+                hp.v[q] = hy[q] + (((hQ[q][0] * h1 + hQ[q][1] * h2) + hQ[q][2] * h3) + hQ[q][3] * h4);
+            st4(&tile[buf][hr.li][hr.lj], hp);
+        } else if (hn == 1) {
+            tile[buf][hr.li][hr.lj] = hy[0] + (((hQ[0][0] * h1 + hQ[0][1] * h2) + hQ[0][2] * h3) + hQ[0][3] * h4);
+        }
+        __syncthreads();
+        if (A.vx[s] && valid) {
+            const V4<T> up = ld4(&tile[buf][ry][4 + 4 * cx]), dn = ld4(&tile[buf][ry + 2][4 + 4 * cx]);
+            const T lft = tile[buf][ry + 1][3 + 4 * cx], rgt = tile[buf][ry + 1][8 + 4 * cx];
+            V4<T> ox, oy;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // central differences of the clipped phi (optimals.py:172-180); "north" = row i+1
+                const T pw = clip((q == 0) ? lft : ph.v[q - 1]), pe = clip((q == 3) ? rgt : ph.v[q + 1]);
+                const T ps = clip(up.v[q]), pn = clip(dn.v[q]);
+                const T pc = clip(clip(ph.v[q]));
                 const T gx = (pe - pw) * A.inv2dx, gy = (pn - ps) * A.inv2dy;
-                const T ux = gx / (A.mu * pc), uy = gy / (A.mu * pc);
-                const T norm = sqrt(ux * ux + uy * uy);
-                T ox, oy;
-                if (norm > A.lim) {
-                    ox = ux / norm;
-                    oy = uy / norm;
-                } else if (norm < A.lim) {
-                    ox = (T)0;
-                    oy = (T)0;
-                } else {
-                    ox = (T)NAN;
-                    oy = (T)NAN;
+                const T rden = fast_rcp(A.mu * pc);
+                const T ux = gx * rden, uy = gy * rden;
+                const T n2 = ux * ux + uy * uy;
+                T vxo, vyo;
+                if (n2 > lim2) {                       // |v| > lim  ->  unit vector
+                    const T rn = fast_rsq(n2);
+                    vxo = ux * rn;
+                    vyo = uy * rn;
+                } else if (n2 < lim2) {
+                    vxo = (T)0;
+                    vyo = (T)0;
+                } else {                               // |v| == lim (0/0 in the reference) or NaN
+                    vxo = (T)NAN;
+                    vyo = (T)NAN;
                 }
-                const int64_t o = (int64_t)(gi - 1) * (Nx - 2) + (gj - 1);
-                __builtin_nontemporal_store(ox, A.vx[s] + o);
-                __builtin_nontemporal_store(oy, A.vy[s] + o);
+                const bool border = gi < 1 || gi >= Ny - 1 || gj + q < 1 || gj + q >= Nx - 1;
+                ox.v[q] = border ? (T)0 : vxo;
+                oy.v[q] = border ? (T)0 : vyo;
             }
+            st4(A.vx[s] + idx, ox);
+            st4(A.vy[s] + idx, oy);
         }
     }
 }
@@ -598,7 +667,7 @@ int emit_slices_fused(Solver<T>& S, const std::vector<double>& te, int nt, int& 
         oc_timer_begin(S.h, "hjb_out", S.s);
         hipLaunchKernelGGL(k_out<T>, g, dim3(256), 0, S.s, A);
         // algorithmic bytes: read y_old + 6 stage arrays once, write 2 field components per slice
-        oc_timer_end(S.h, "hjb_out", S.s, sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)slice_elems));
+        oc_timer_end(S.h, "hjb_out", S.s, sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(c.Ny - 2) * (c.Nx - 2)));
         stats.n_slices_written += nv;
     }
     return OC_OK;
@@ -622,6 +691,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
     const int64_t n = S.n;
     const double rtol = c.rtol, atol0 = c.atol;
     const int RB = 1024;
+    const bool use_fused = (h->hjb_variant == 0) && (c.Nx % 4 == 0);   // vector kernels need 16-byte rows
 
     oc_hjb_stats stats;
     memset(&stats, 0, sizeof(stats));
@@ -686,7 +756,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
     if (t_steps && t_steps_cap > 0) t_steps[n_steps_rec++] = t;
 
     int k_next = 0;                     // next t_eval index to emit
-    const size_t slice_elems = (size_t)(c.Ny - 2) * (c.Nx - 2);
+    const size_t slice_elems = (size_t)c.Ny * c.Nx;     // padded slices: the reference's array is [1:-1, 1:-1]
     const double err_exp = -1.0 / 5.0;
 
     while (t != tf) {
@@ -710,7 +780,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
             int nred = RB;
             double atol_s = atol0 * scale_of();
             oc_timer_begin(h, "hjb_stage", s);
-            if (h->hjb_variant == 0) {
+            if (use_fused) {
                 launch_stages_fused(S, hh, (T)atol_s, (T)rtol);
                 S.nfev += 6;
                 nred = S.fused_blocks();
@@ -762,7 +832,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                 stats.h_min = std::min(stats.h_min, std::fabs(hh));
                 stats.h_max = std::max(stats.h_max, std::fabs(hh));
                 // ---- dense output for t_eval points in (t_new, t]  (scipy ivp.py:706-723)
-                if (h->hjb_variant == 0) {
+                if (use_fused) {
                     if ((rc = emit_slices_fused(S, te, nt, k_next, t, t_new, hh, keep_slot, phi_keep, vx_out, vy_out,
                                                 slice_elems, expo, stats)))
                         return rc;

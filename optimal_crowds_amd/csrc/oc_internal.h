@@ -38,8 +38,9 @@ struct oc_field_desc {
 };
 
 struct oc_wallmap {
-    int32_t* left = nullptr;    // (Ny, Nx): largest site column <= j, or -1
-    int32_t* right = nullptr;   // (Ny, Nx): smallest site column >= j, or Nx
+    void* left = nullptr;       // int2 [Nx][Ny]: (nearest site column <= j or -1, nearest site column >= j+1 or Nx)
+    void* right = nullptr;      // float (Ny,Nx): capped distance from each grid node to the nearest site
+    double edt_cap = 0.0;
     double off = 0.0;           // vmin * 10e3 (the reference adds V*10e3 before the argmin)
     bool built = false;
 };

@@ -4,7 +4,8 @@ memory + stream plumbing) for one simulation.  Everything numerical happens in t
 Buffers in HBM (row-major, N agents, K keys, grid Ny x Nx, nt0 = round(T/dt)):
   V[k]      float32 (Ny,Nx)      finalised potential of key k ({-100,0,1})
   coef      dtype   (Ny,Nx)      (V + g m)/(mu sigma^2), NaN on walls
-  vx[k],vy[k] dtype (nt0-1, Ny-2, Nx-2)   direction field of key k  (the big one: 33.5 GB/key at 2048^2 fp32)
+  vx[k],vy[k] dtype (nt0-1, Ny, Nx)   direction field of key k, padded rows (33.5 GB/key at 2048^2 fp32);
+                                      the reference's (nt0-1, Ny-2, Nx-2) arrays are the interior [:, 1:-1, 1:-1]
   x,y,vx,vy,v_des,agent_time float64 (N);  status uint8 (N);  key int32 (N)
 """
 import ctypes as C
@@ -103,11 +104,18 @@ class Engine:
         check(self.lib.oc_set_key_targets(self.h, key, r.ctypes.data_as(C.c_void_p), len(r)))
 
     def alloc_field(self, key, nslice):
-        shape = (max(nslice, 0), self.Ny - 2, self.Nx - 2)
+        # slices are stored padded as (Ny, Nx) so that every row is 16-byte aligned for the vector kernels;
+        # the reference's (Ny-2, Nx-2) array is the interior block [1:-1, 1:-1] (see field_interior)
+        shape = (max(nslice, 0), self.Ny, self.Nx)
         vx = torch.zeros(shape, dtype=self.tdtype, device=self.device)
         vy = torch.zeros(shape, dtype=self.tdtype, device=self.device)
         self.fields[key] = [vx, vy, nslice, 0]
         return vx, vy
+
+    def field_interior(self, key):
+        """(vx_opt, vy_opt) views of shape (nslice, Ny-2, Nx-2), the reference's arrays (optimals.py:80-81)."""
+        vx, vy = self.fields[key][0], self.fields[key][1]
+        return vx[:, 1:-1, 1:-1], vy[:, 1:-1, 1:-1]
 
     def make_coef(self, key, m=None, out=None):
         out = self.coef if out is None else out
@@ -123,8 +131,8 @@ class Engine:
         return out
 
     def vels(self, phi64, scale=1.0):
-        vx = torch.empty((self.Ny - 2, self.Nx - 2), dtype=self.tdtype, device=self.device)
-        vy = torch.empty_like(vx)
+        vx = torch.zeros((self.Ny, self.Nx), dtype=self.tdtype, device=self.device)
+        vy = torch.zeros_like(vx)
         check(self.lib.oc_hjb_vels(self.h, self.dtype, _ptr(phi64), float(scale), _ptr(vx), _ptr(vy), self.stream()))
         return vx, vy
 

@@ -80,11 +80,11 @@ class optimals:
 
     @property
     def vx_opt(self):
-        return DeviceField(self._engine.fields[self._k][0])
+        return DeviceField(self._engine.field_interior(self._k)[0])
 
     @property
     def vy_opt(self):
-        return DeviceField(self._engine.fields[self._k][1])
+        return DeviceField(self._engine.field_interior(self._k)[1])
 
     def compute_optimal_velocity(self, t, m):
         """reference optimals.py:124-206.  m: (Ny,Nx) density (NumPy array or device tensor) or None/0."""

@@ -59,7 +59,7 @@ def test_solve_fp64_follows_scipy(golden, name):
     assert np.allclose(st["t_steps"], g["t_steps"], rtol=0, atol=1e-8)
     phi = phi.cpu().numpy()
     assert np.allclose(phi, g["phi"], rtol=1e-9, atol=0)
-    vx, vy = eng.fields[0][0].cpu().numpy(), eng.fields[0][1].cpu().numpy()
+    vx, vy = (t.cpu().numpy() for t in eng.field_interior(0))
     for s, gx, gy in zip(g["v_slices"], g["vx"], g["vy"]):
         assert np.allclose(vx[s], gx, rtol=0, atol=1e-7)
         assert np.allclose(vy[s], gy, rtol=0, atol=1e-7)
@@ -82,7 +82,7 @@ def test_solve_fp32_within_tolerance(golden, name):
     phi = phi.cpu().numpy()
     rel = np.abs(phi - g["phi"]) / np.abs(g["phi"])
     assert rel.max() <= 5e-3
-    vx, vy = eng.fields[0][0].double().cpu().numpy(), eng.fields[0][1].double().cpu().numpy()
+    vx, vy = (t.double().cpu().numpy() for t in eng.field_interior(0))
     hp = cfg["hjb_params"]
     Ny, Nx = g["V"].shape
     for s, gx, gy in zip(g["v_slices"], g["vx"], g["vy"]):
@@ -280,7 +280,7 @@ def test_fused_and_simple_hjb_kernels_agree(golden):
         eng.set_potential(0, g["V"], _rects(room, str(g["key"])))
         eng.alloc_field(0, nt - 1)
         st, phi = eng.solve(0, T, nt, m=torch.as_tensor(g["m"]), keep=g["slices"])
-        out.append((st, phi.cpu().numpy(), eng.fields[0][0].cpu().numpy(), eng.fields[0][1].cpu().numpy()))
+        out.append((st, phi.cpu().numpy(), eng.field_interior(0)[0].cpu().numpy(), eng.field_interior(0)[1].cpu().numpy()))
         eng.close()
     assert out[0][0]["nfev"] == out[1][0]["nfev"] == int(g["nfev"])
     assert np.allclose(out[0][1], out[1][1], rtol=1e-11, atol=0)
