@@ -126,12 +126,15 @@ int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out, void* str
 
 /* One synchronous (frozen-snapshot) step of every active agent, in place: simulations.py:277-332.
  *   noise : float64 (N,2) standard normals (noise[i] = agent i's draw) or NULL -> device Philox(seed, step).
- *   counters (device int32[4], zeroed by the call): [0] number of agents that exited this step,
+ *   counters (device int32[4], reset by the call): [0] number of agents that exited this step,
  *            [1] 1+index of an agent in the IndexError band (0 = none), [2] active agents after the step.
  * Rebuilds the spatial order every `resort_every` steps (0 = library default). */
 int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise, uint64_t seed,
                  int32_t* counters, void* stream);
 int oc_set_resort_every(oc_handle* h, int32_t steps);
+/* Between consecutive oc_gcfm_step calls the library reuses the packed snapshot it wrote itself; call this after
+ * modifying the state arrays in place from outside (new array pointers are detected automatically). */
+int oc_agents_changed(oc_handle* h);
 
 /* d = sum over active agents of exp(-r^2/(2 sigma^2)) / (2 pi sigma), zero where V_all < 0:
  * simulations.py:453-487.  out: dtype (Ny,Nx); V_all float32 (Ny,Nx) (simulation.V) or NULL.

@@ -3,15 +3,19 @@
 // pedestrians.py:282-334 (wall_repulsion), optimals.py:212-250 (choose_optimal_velocity).
 //
 // Layout: caller-owned SoA state in agent order (float64 x,y,vx,vy,v_des; uint8 status; int32 key).
-// Each step the state is gathered through `order` (agents sorted by 4 m coarse cell) into a packed snapshot
-// in SLOT order (tiles of 64 slots = one wavefront):
-//   ppos  double2 (x,y)            pvel  float4 (vx,vy,|v|,1/a^2)     phead float2 (unit heading, (1,0) if v=0)
-//   tile_box double4 (minx,miny,maxx,maxy) of the active agents of a tile
-// Pair forces: one wavefront per i-tile; j-tiles whose box is farther than the cutoff are skipped (ballot over
-// 64 tile tests), surviving j-tiles are staged in LDS and broadcast-read.  The distance/cutoff test is float64
-// on absolute positions (same decision as the reference's sqrt(dx^2+dy^2) < cutoff), the force arithmetic is
-// float32 on the float64-differenced relative vector, the per-agent sum is float64.
-// Per-agent work (lookup, wall search + force, integration, exit test) is float64.
+// The library keeps a packed snapshot in SLOT order (agents sorted by 4 m coarse cell; a tile = 64 slots =
+// one wavefront):
+//   ppos  double2 (x,y)      pvel  float4 (vx,vy,|v|,1/a^2)     phead float2 (unit heading, (1,0) if v=0)
+//   tile_box double4 (minx,miny,maxx,maxy) of a tile's active agents;  nb_list: tiles that can come within the
+//   cutoff before the next re-sort (boxes at sort time, cutoff + 2D margin; validity is re-checked every step)
+// One step = 3 launches:
+//   k_pair   one block (4 wavefronts) per i-tile; candidate j-tiles (neighbour list + live box test) are split over
+//            the wavefronts, staged 4 at a time in LDS; phase 1 builds per-lane 64-bit candidate masks with a
+//            conservative float32 test, phase 2 walks each lane's candidates of the whole batch: exact float64
+//            cutoff decision (the reference's sqrt(dx^2+dy^2) < cutoff), float32 force, float64 sum.
+//   k_wall   exact nearest-wall-cell search (float64) for the compacted list of agents that can feel a wall.
+//   k_finish per agent, float64: floor-field lookup, wall force, noisy relaxation step, speed clamp, exit test;
+//            then writes the NEXT step's packed record, tile box and wall work-list.
 #include "oc_internal.h"
 #include <cmath>
 #include <algorithm>
@@ -35,8 +39,18 @@ struct GcfmParams {
     double a_min, tau_a, b_min, b_max, eta, eta_walls, cutoff, v_max, relaxation, noise_amp;
     double wall_radius;
     double cell;        // coarse cell size for ordering
+    double drift;       // D: how far a tile box may grow beyond its sort-time box before the lists are invalid
     int32_t ncx, ncy;
 };
+
+#define NB_MAX 63
+// ctrl words
+#define C_EXIT 0
+#define C_ERR 1
+#define C_ACTIVE 2
+#define C_WCOUNT 4      // [4], [5]: wall work-list lengths (ping-pong)
+#define C_INVALID 6     // neighbour lists no longer cover the tile boxes -> full tile scan
+#define C_QUEUE 7       // next i-tile of k_pair's work queue (reset by k_finish / repack)
 
 struct Scratch {
     uint32_t *keys_a, *keys_b;
@@ -45,10 +59,12 @@ struct Scratch {
     float4* pvel;
     float2* phead;
     int32_t* pidx;
-    double4* tile_box;
+    double4 *tile_box, *tile_box0;
+    int32_t* nb_list;       // [ntiles][NB_MAX + 1]: count (or -1 = overflow) then tile ids
     double2 *f_pair, *f_wall, *des;
     long long* widx;
-    int32_t* counters;
+    int32_t* wall_list[2];
+    int32_t* ctrl;
     int32_t Np, ntiles;
 };
 
@@ -80,159 +96,6 @@ __global__ void k_cell_keys(const double* __restrict__ x, const double* __restri
     vals[i] = i;
 }
 
-// one wavefront per tile of 64 slots
-__global__ void __launch_bounds__(64) k_pack(const double* __restrict__ x, const double* __restrict__ y,
-                                             const double* __restrict__ vx, const double* __restrict__ vy,
-                                             const uint8_t* __restrict__ status, const int32_t* __restrict__ order,
-                                             int N, GcfmParams P, Scratch S) {
-    int k = blockIdx.x * 64 + threadIdx.x;
-    int i = (k < N) ? order[k] : -1;
-    bool act = (i >= 0) && status[i];
-    double px = 1e300, py = 1e300;
-    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-    float2 ph = make_float2(1.f, 0.f);
-    if (act) {
-        px = x[i];
-        py = y[i];
-        double vxd = vx[i], vyd = vy[i];
-        double s = sqrt(vxd * vxd + vyd * vyd);
-        double a = P.a_min + P.tau_a * s;
-        pv = make_float4((float)vxd, (float)vyd, (float)s, (float)(1.0 / (a * a)));
-        if (s > 0) ph = make_float2((float)(vxd / s), (float)(vyd / s));
-    }
-    S.ppos[k] = make_double2(px, py);
-    S.pvel[k] = pv;
-    S.phead[k] = ph;
-    S.pidx[k] = act ? i : -1;
-    double mnx = wmin(act ? px : INFINITY), mny = wmin(act ? py : INFINITY);
-    double mxx = wmax(act ? px : -INFINITY), mxy = wmax(act ? py : -INFINITY);
-    if (threadIdx.x == 0) S.tile_box[blockIdx.x] = make_double4(mnx, mny, mxx, mxy);
-}
-
-// ---------------------------------------------------------------------------------- pair forces
-#define COS_VISION (-0.58778525229247312917f)   // cos(0.7 pi), pedestrians.py:262
-
-// force of j on i (pedestrians.py:242-280) in trig-free form: cos(alpha-beta) = e.h, sin = h x e.
-// float32 with hardware rcp/rsq/exp2 (1 ulp); R is the float64-differenced relative vector rounded to float32.
-__device__ __forceinline__ void pair_term(float Rx, float Ry, float vxi, float vyi, float si, float hxi, float hyi,
-                                          float ia2_i, float ib2_i, float inv_vdes_i, float4 vj, float2 hj,
-                                          float b_max, float db, float neg_inv_eta_log2e, double& fx, double& fy) {
-    float r2 = __builtin_fmaf(Rx, Rx, Ry * Ry);
-    float inv_r = __builtin_amdgcn_rsqf(r2);
-    float r = r2 * inv_r;
-    float ex = Rx * inv_r, ey = Ry * inv_r;
-    // closing speed (pedestrians.py:254-255)
-    float vrel = fmaxf(__builtin_fmaf(vxi - vj.x, ex, (vyi - vj.y) * ey), 0.f);
-    // ellipse radii along the centre line (pedestrians.py:266-271)
-    float ci = __builtin_fmaf(ex, hxi, ey * hyi), sn_i = __builtin_fmaf(hxi, ey, -hyi * ex);
-    // vision factor (pedestrians.py:259-262): v_i.e/|v_i| = h_i.e when |v_i| > 0
-    float k = (si > 0.f) ? fmaxf(ci - COS_VISION, 0.f) * (1.f / (1.f - COS_VISION)) : 0.f;
-    float q_i = __builtin_amdgcn_rsqf(__builtin_fmaf(ci * ci, ia2_i, sn_i * sn_i * ib2_i));
-    float b_j = __builtin_fmaf(-db, fminf(vj.z * inv_vdes_i, 1.f), b_max);          // Q6: i's v_des
-    float ib2_j = __builtin_amdgcn_rcpf(b_j * b_j);
-    float cj = __builtin_fmaf(ex, hj.x, ey * hj.y), sn_j = __builtin_fmaf(hj.x, ey, -hj.y * ex);
-    float q_j = __builtin_amdgcn_rsqf(__builtin_fmaf(cj * cj, vj.w, sn_j * sn_j * ib2_j));
-    float dist = r - q_i - q_j;
-    float rep = fminf(k * __builtin_amdgcn_exp2f(dist * neg_inv_eta_log2e * __builtin_amdgcn_rcpf(1.f + vrel)), 1.f);
-    fx += (double)(-rep * Rx);
-    fy += (double)(-rep * Ry);
-}
-
-// One block (4 wavefronts) per i-tile: lane <-> agent slot, the wavefronts split the surviving j-tiles.
-// Per j-tile: phase 1 builds, per lane, a 64-bit mask of candidate j (float32 test on box-relative coordinates,
-// conservative); phase 2 walks each lane's own mask: exact float64 cutoff decision, then the float32 force.
-__global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const double* __restrict__ v_des) {
-    __shared__ double2 l_pos[4][64];
-    __shared__ float4 l_vel[4][64];
-    __shared__ float2 l_head[4][64];
-    __shared__ float2 l_rel[4][64];
-    __shared__ double2 l_red[4][64];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int it = blockIdx.x;
-    const int k = it * 64 + lane;
-    const int i = S.pidx[k];
-    const double2 pi = S.ppos[k];
-    const float4 vi = S.pvel[k];
-    const float2 hi = S.phead[k];
-    float inv_vdes = 0.f, ib2_i = 0.f;
-    const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
-    const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
-    if (i >= 0) {
-        double vd = v_des[i];
-        inv_vdes = (float)(1.0 / vd);
-        double b = P.b_max - (P.b_max - P.b_min) * fmin((double)vi.z / vd, 1.0);
-        ib2_i = (float)(1.0 / (b * b));
-    }
-    const double4 bi = S.tile_box[it];
-    const double c = P.cutoff;
-    const double c2 = c * c, c2_lo = c2 * (1.0 - 1e-15), c2_hi = c2 * (1.0 + 1e-15);
-    const double ox = bi.x, oy = bi.y;                 // origin of the box-relative float32 coordinates
-    const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
-    double fx = 0.0, fy = 0.0;
-    int ord = 0;
-    for (int tb = 0; tb < S.ntiles; tb += 64) {
-        int t = tb + lane;
-        bool hit = false;
-        if (t < S.ntiles) {
-            double4 bj = S.tile_box[t];
-            hit = !(bj.x > bi.z + c || bj.z < bi.x - c || bj.y > bi.w + c || bj.w < bi.y - c);
-        }
-        unsigned long long tmask = __ballot(hit);
-        while (tmask) {
-            int b = __ffsll((long long)tmask) - 1;
-            tmask &= tmask - 1;
-            if (((ord++) & 3) != w) continue;           // this hit belongs to another wavefront of the block
-            int jt = tb + b;
-            // stage tile jt in this wavefront's LDS area (LDS ops of one wavefront complete in order)
-            __builtin_amdgcn_wave_barrier();
-            double2 pj_own = S.ppos[jt * 64 + lane];
-            l_pos[w][lane] = pj_own;
-            l_rel[w][lane] = make_float2((float)(pj_own.x - ox), (float)(pj_own.y - oy));
-            l_vel[w][lane] = S.pvel[jt * 64 + lane];
-            l_head[w][lane] = S.phead[jt * 64 + lane];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // conservative float32 bound: rounding of the relative coordinates scales with the two boxes' extent
-            double4 bj = S.tile_box[jt];
-            float ext = (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
-                                fmax(fmax(bi.w, bj.w) - oy, oy - fmin(bi.y, bj.y)));
-            const float c2f = (float)c2 * 1.00001f + 1e-6f * ext * (ext + (float)c);
-            // phase 1: candidate mask of this lane's agent
-            unsigned long long m = 0ull;
-#pragma unroll 8
-            for (int jj = 0; jj < 64; ++jj) {
-                float2 q = l_rel[w][jj];
-                float ddx = q.x - xi_f, ddy = q.y - yi_f;
-                float d2 = __builtin_fmaf(ddx, ddx, ddy * ddy);
-                m |= (d2 < c2f) ? (1ull << jj) : 0ull;
-            }
-            if (jt == it) m &= ~(1ull << lane);        // j != i
-            if (i < 0) m = 0ull;
-            // phase 2: this lane's candidates
-            while (m) {
-                int jj = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                double2 pj = l_pos[w][jj];
-                double ddx = pj.x - pi.x, ddy = pj.y - pi.y;
-                double d2 = ddx * ddx + ddy * ddy;
-                // the reference's decision: sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291)
-                bool nearp = (d2 < c2_lo) || (d2 < c2_hi && sqrt(d2) < c);
-                if (nearp)
-                    pair_term((float)ddx, (float)ddy, vi.x, vi.y, vi.z, hi.x, hi.y, vi.w, ib2_i, inv_vdes,
-                              l_vel[w][jj], l_head[w][jj], b_max, db, neg_inv_eta_log2e, fx, fy);
-            }
-        }
-    }
-    l_red[w][lane] = make_double2(fx, fy);
-    __syncthreads();
-    if (w == 0) {
-        double2 a0 = l_red[0][lane], a1 = l_red[1][lane], a2 = l_red[2][lane], a3 = l_red[3][lane];
-        S.f_pair[k] = make_double2((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
-    }
-}
-
-// ---------------------------------------------------------------------------------- wall search + force
 // Exact nearest-site query (same cell as numpy's argmin over the full grid, see oracle WallMap for the proof
 // sketch): per grid row only the nearest site left and right of the agent's column can be the row minimum.
 __device__ __forceinline__ void wall_try(double px, double py, int r, int cnd, int Nx, const double* __restrict__ X0,
@@ -317,39 +180,392 @@ __device__ __forceinline__ void wall_scan(double px, double py, const int2* __re
     }
 }
 
-__global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
-                                             const int32_t* __restrict__ key_of, const double* __restrict__ v_des,
-                                             const double* __restrict__ X0, const double* __restrict__ Y0) {
+
+// Can this agent feel a wall?  Uses the capped distance transform at the nearest grid node:
+// d(node) - |p - node| <= d*(p) <= d(node) + |p - node|.  Returns false when d*(p) provably exceeds the agent's
+// search radius (force < 1e-12 m/s); ub2 = squared upper bound on d*(p) (or inf).
+__device__ __forceinline__ bool wall_needed(const GcfmParams& P, const KeyDev& kd, const double* __restrict__ X0,
+                                            const double* __restrict__ Y0, double px, double py, double speed,
+                                            double& rad2, double& ub2) {
+    const int Nx = P.Nx, Ny = P.Ny;
+    const double hx = P.L / (Nx - 1), hy = P.H / (Ny - 1);
+    const double rad = wall_radius_of(P, speed);
+    rad2 = rad > 0 ? rad * rad : INFINITY;
+    int jn = (int)floor(px / hx + 0.5), in = (int)floor(py / hy + 0.5);
+    jn = jn < 0 ? 0 : (jn > Nx - 1 ? Nx - 1 : jn);
+    in = in < 0 ? 0 : (in > Ny - 1 ? Ny - 1 : in);
+    const double ex = X0[jn] - px, ey = Y0[in] - py;
+    const double delta = sqrt(ex * ex + ey * ey) * (1.0 + 1e-12) + 1e-12;
+    const double dn = (double)kd.edt[(size_t)in * Nx + jn];
+    ub2 = INFINITY;
+    if ((rad > 0) && (dn * (1.0 - 1e-6) - delta > rad)) return false;
+    if (dn < kd.edt_cap) {
+        double ub = dn * (1.0 + 1e-6) + delta + 1e-9;
+        ub2 = ub * ub;
+    }
+    return true;
+}
+
+// wall force from the selected cell, float64 (pedestrians.py:317-334); zero if no cell was selected.
+// R = 0 (agent exactly on a wall node) gives NaN in the reference; here the force is 0 (deviation D1).
+__device__ __forceinline__ double2 wall_force_of(const GcfmParams& P, long long flat, double px, double py, double vxd,
+                                                 double vyd, double vdes, const double* __restrict__ X0,
+                                                 const double* __restrict__ Y0) {
+    if (flat < 0) return make_double2(0.0, 0.0);
+    int r = (int)(flat / P.Nx), cc = (int)(flat % P.Nx);
+    double Rx = X0[cc] - px, Ry = Y0[r] - py;
+    double rr = sqrt(Rx * Rx + Ry * Ry);
+    double ex = Rx / rr, ey = Ry / rr;
+    double d = vxd * ex + vyd * ey;
+    double vrel = 0.5 * (d + fabs(d));
+    double s = sqrt(vxd * vxd + vyd * vyd);
+    double hx = 1.0, hy = 0.0;
+    if (s > 0) {
+        hx = vxd / s;
+        hy = vyd / s;
+    }
+    double a = P.a_min + P.tau_a * s;
+    double b = P.b_max - (P.b_max - P.b_min) * fmin(s / vdes, 1.0);
+    double ca = (ex * hx + ey * hy) / a, sb = (hx * ey - hy * ex) / b;
+    double q = 1.0 / (ca * ca + sb * sb);                 // Q12: no square root
+    double dist = rr - q;
+    double rep = fmin(exp(-dist / (P.eta_walls * (1.0 + vrel))), 1.0);
+    return make_double2(-3.0 * rep * Rx, -3.0 * rep * Ry);
+}
+
+// packed record of one agent
+__device__ __forceinline__ void make_record(const GcfmParams& P, double vxd, double vyd, float4& pv, float2& ph) {
+    double s = sqrt(vxd * vxd + vyd * vyd);
+    double a = P.a_min + P.tau_a * s;
+    pv = make_float4((float)vxd, (float)vyd, (float)s, (float)(1.0 / (a * a)));
+    ph = (s > 0) ? make_float2((float)(vxd / s), (float)(vyd / s)) : make_float2(1.f, 0.f);
+}
+
+// append the lanes with `need` to the wall work-list (one atomic per wavefront)
+__device__ __forceinline__ void wall_list_push(bool need, int k, int32_t* __restrict__ list, int32_t* count) {
+    unsigned long long m = __ballot(need);
+    if (!m) return;
+    int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (need) list[base + __popcll(m & ((1ull << lane) - 1))] = k;
+}
+
+// full pack from the state arrays (after a re-sort): one wavefront per tile
+__global__ void __launch_bounds__(64) k_pack(const double* __restrict__ x, const double* __restrict__ y,
+                                             const double* __restrict__ vx, const double* __restrict__ vy,
+                                             const uint8_t* __restrict__ status, const int32_t* __restrict__ key_of,
+                                             const int32_t* __restrict__ order, int N, GcfmParams P, Scratch S,
+                                             const KeyDev* __restrict__ keys, const double* __restrict__ X0,
+                                             const double* __restrict__ Y0, int cur) {
     int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= S.Np) return;
-    int i = S.pidx[k];
-    long long best_flat = -1;
-    if (i >= 0) {
-        const KeyDev& kd = keys[key_of[i]];
-        const double2 p = S.ppos[k];
-        const int Nx = P.Nx, Ny = P.Ny;
-        const double hx = P.L / (Nx - 1), hy = P.H / (Ny - 1);
-        const double rad = wall_radius_of(P, (double)S.pvel[k].z);
-        const double rad2 = rad > 0 ? rad * rad : INFINITY;
-        // distance bound from the capped EDT at the nearest grid node: d(node) - |p-node| <= d*(p) <= d(node) + |p-node|
-        int jn = (int)floor(p.x / hx + 0.5), in = (int)floor(p.y / hy + 0.5);
-        jn = jn < 0 ? 0 : (jn > Nx - 1 ? Nx - 1 : jn);
-        in = in < 0 ? 0 : (in > Ny - 1 ? Ny - 1 : in);
-        const double ex = X0[jn] - p.x, ey = Y0[in] - p.y;
-        const double delta = sqrt(ex * ex + ey * ey) * (1.0 + 1e-12) + 1e-12;
-        const double dn = (double)kd.edt[(size_t)in * Nx + jn];
-        bool skip = (rad > 0) && (dn * (1.0 - 1e-6) - delta > rad);   // provably beyond the radius: force < 1e-12
-        if (!skip) {
-            double ub2 = INFINITY;
-            if (dn < kd.edt_cap) {
-                double ub = dn * (1.0 + 1e-6) + delta + 1e-9;
-                ub2 = ub * ub;
-            }
-            double bd2;
-            wall_scan(p.x, p.y, kd.lr, Nx, Ny, hx, hy, X0, Y0, kd.off, rad2, ub2, best_flat, bd2);
+    int i = (k < N) ? order[k] : -1;
+    bool act = (i >= 0) && status[i];
+    double px = 1e300, py = 1e300;
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 ph = make_float2(1.f, 0.f);
+    bool need = false;
+    if (act) {
+        px = x[i];
+        py = y[i];
+        make_record(P, vx[i], vy[i], pv, ph);
+        if (keys) {
+            double r2, u2;
+            need = wall_needed(P, keys[key_of[i]], X0, Y0, px, py, (double)pv.z, r2, u2);
         }
     }
-    S.widx[k] = best_flat;
+    S.ppos[k] = make_double2(px, py);
+    S.pvel[k] = pv;
+    S.phead[k] = ph;
+    S.pidx[k] = act ? i : -1;
+    S.widx[k] = -1;
+    wall_list_push(need, k, S.wall_list[cur], &S.ctrl[C_WCOUNT + cur]);
+    double mnx = wmin(act ? px : INFINITY), mny = wmin(act ? py : INFINITY);
+    double mxx = wmax(act ? px : -INFINITY), mxy = wmax(act ? py : -INFINITY);
+    if (threadIdx.x == 0) {
+        S.tile_box[blockIdx.x] = make_double4(mnx, mny, mxx, mxy);
+        S.tile_box0[blockIdx.x] = make_double4(mnx, mny, mxx, mxy);
+    }
+}
+
+__device__ __forceinline__ bool box_hit(const double4& a, const double4& b, double c) {
+    return !(b.x > a.z + c || b.z < a.x - c || b.y > a.w + c || b.w < a.y - c);
+}
+
+// neighbour-tile lists from the sort-time boxes: one wavefront per tile
+__global__ void __launch_bounds__(64) k_tile_lists(GcfmParams P, Scratch S) {
+    const int it = blockIdx.x, lane = threadIdx.x;
+    const double4 bi = S.tile_box0[it];
+    const double c = P.cutoff + 2.0 * P.drift;
+    int32_t* out = S.nb_list + (size_t)it * (NB_MAX + 1);
+    int cnt = 0;
+    for (int tb = 0; tb < S.ntiles; tb += 64) {
+        int t = tb + lane;
+        bool hit = (t < S.ntiles) && box_hit(bi, S.tile_box0[t], c);
+        unsigned long long m = __ballot(hit);
+        int pos = cnt + __popcll(m & ((1ull << lane) - 1));
+        if (hit && pos < NB_MAX) out[1 + pos] = t;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) out[0] = (cnt <= NB_MAX) ? cnt : -1;
+}
+
+// ---------------------------------------------------------------------------------- pair forces
+#define COS_VISION (-0.58778525229247312917f)   // cos(0.7 pi), pedestrians.py:262
+
+// force of j on i (pedestrians.py:242-280) in trig-free form: cos(alpha-beta) = e.h, sin = h x e.
+// float32 with hardware rcp/rsq/exp2 (1 ulp); R is the float64-differenced relative vector rounded to float32.
+__device__ __forceinline__ void pair_term(float Rx, float Ry, float vxi, float vyi, float si, float hxi, float hyi,
+                                          float ia2_i, float ib2_i, float inv_vdes_i, float4 vj, float2 hj,
+                                          float b_max, float db, float neg_inv_eta_log2e, double& fx, double& fy) {
+    float r2 = __builtin_fmaf(Rx, Rx, Ry * Ry);
+    float inv_r = __builtin_amdgcn_rsqf(r2);
+    float r = r2 * inv_r;
+    float ex = Rx * inv_r, ey = Ry * inv_r;
+    // closing speed (pedestrians.py:254-255)
+    float vrel = fmaxf(__builtin_fmaf(vxi - vj.x, ex, (vyi - vj.y) * ey), 0.f);
+    // ellipse radii along the centre line (pedestrians.py:266-271)
+    float ci = __builtin_fmaf(ex, hxi, ey * hyi), sn_i = __builtin_fmaf(hxi, ey, -hyi * ex);
+    // vision factor (pedestrians.py:259-262): v_i.e/|v_i| = h_i.e when |v_i| > 0
+    float k = (si > 0.f) ? fmaxf(ci - COS_VISION, 0.f) * (1.f / (1.f - COS_VISION)) : 0.f;
+    float q_i = __builtin_amdgcn_rsqf(__builtin_fmaf(ci * ci, ia2_i, sn_i * sn_i * ib2_i));
+    float b_j = __builtin_fmaf(-db, fminf(vj.z * inv_vdes_i, 1.f), b_max);          // Q6: i's v_des
+    float ib2_j = __builtin_amdgcn_rcpf(b_j * b_j);
+    float cj = __builtin_fmaf(ex, hj.x, ey * hj.y), sn_j = __builtin_fmaf(hj.x, ey, -hj.y * ex);
+    float q_j = __builtin_amdgcn_rsqf(__builtin_fmaf(cj * cj, vj.w, sn_j * sn_j * ib2_j));
+    float dist = r - q_i - q_j;
+    float rep = fminf(k * __builtin_amdgcn_exp2f(dist * neg_inv_eta_log2e * __builtin_amdgcn_rcpf(1.f + vrel)), 1.f);
+    fx += (double)(-rep * Rx);
+    fy += (double)(-rep * Ry);
+}
+
+#define PB 4     // j-tiles staged per batch and wavefront
+
+__global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const double* __restrict__ v_des, int nxt,
+                                              int32_t* __restrict__ cnt_out) {
+    __shared__ double2 l_pos[4][PB][64];
+    __shared__ float4 l_vel[4][PB][64];
+    __shared__ float2 l_head[4][PB][64];
+    __shared__ float2 l_rel[4][PB][64];
+    __shared__ double2 l_red[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ int l_it;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // this step's counters (k_finish adds to them later in the stream)
+        cnt_out[0] = cnt_out[1] = cnt_out[2] = cnt_out[3] = 0;
+        S.ctrl[C_WCOUNT + nxt] = 0;
+    }
+    // i-tiles are pulled from a queue: a tile costs 20-50 us and there are only a few per resident block, so a
+    // static assignment would quantise badly.  Every block leaves as soon as the queue is empty.
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) l_it = atomicAdd(&S.ctrl[C_QUEUE], 1);
+    __syncthreads();
+    const int it = l_it;
+    if (it >= S.ntiles) break;
+    const int k = it * 64 + lane;
+    const int i = S.pidx[k];
+    const double2 pi = S.ppos[k];
+    const float4 vi = S.pvel[k];
+    const float2 hi = S.phead[k];
+    float inv_vdes = 0.f, ib2_i = 0.f;
+    const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
+    const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
+    if (i >= 0) {
+        double vd = v_des[i];
+        inv_vdes = (float)(1.0 / vd);
+        double b = P.b_max - (P.b_max - P.b_min) * fmin((double)vi.z / vd, 1.0);
+        ib2_i = (float)(1.0 / (b * b));
+    }
+    const double4 bi = S.tile_box[it];
+    const double c = P.cutoff;
+    const double c2 = c * c, c2_lo = c2 * (1.0 - 1e-15), c2_hi = c2 * (1.0 + 1e-15);
+    const double ox = bi.x, oy = bi.y;                 // origin of the box-relative float32 coordinates
+    const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
+    double fx = 0.0, fy = 0.0;
+
+    // candidate tiles: the neighbour list (if valid) or every tile, filtered by the live boxes
+    const int32_t* nb = S.nb_list + (size_t)it * (NB_MAX + 1);
+    const int nb_cnt = nb[0];
+    const bool use_list = (nb_cnt >= 0) && (S.ctrl[C_INVALID] == 0);
+    const int nchunk = use_list ? 1 : (S.ntiles + 63) / 64;
+    int ord = 0, nq = 0;
+    int q[PB];
+
+    auto process = [&](int n) {
+        // ---- stage n tiles in this wavefront's LDS area
+        __builtin_amdgcn_wave_barrier();
+        float c2f[PB];
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            if (b < n) {
+                const int jt = q[b];
+                double2 pj_own = S.ppos[jt * 64 + lane];
+                l_pos[w][b][lane] = pj_own;
+                l_rel[w][b][lane] = make_float2((float)(pj_own.x - ox), (float)(pj_own.y - oy));
+                l_vel[w][b][lane] = S.pvel[jt * 64 + lane];
+                l_head[w][b][lane] = S.phead[jt * 64 + lane];
+                // conservative float32 bound: rounding of the relative coordinates scales with the boxes' extent
+                double4 bj = S.tile_box[jt];
+                float ext = (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
+                                    fmax(fmax(bi.w, bj.w) - oy, oy - fmin(bi.y, bj.y)));
+                c2f[b] = (float)c2 * 1.00001f + 1e-6f * ext * (ext + (float)c);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- phase 1: candidate masks of this lane's agent, one per staged tile
+        unsigned long long m[PB];
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            m[b] = 0ull;
+            if (b < n) {
+#pragma unroll 8
+                for (int jj = 0; jj < 64; ++jj) {
+                    float2 qq = l_rel[w][b][jj];
+                    float ddx = qq.x - xi_f, ddy = qq.y - yi_f;
+                    float d2 = __builtin_fmaf(ddx, ddx, ddy * ddy);
+                    m[b] |= (d2 < c2f[b]) ? (1ull << jj) : 0ull;
+                }
+                if (q[b] == it) m[b] &= ~(1ull << lane);        // j != i
+                if (i < 0) m[b] = 0ull;
+            }
+        }
+        // ---- phase 2: walk the candidates of the whole batch
+        while (m[0] | m[1] | m[2] | m[3]) {
+            int b;
+            unsigned long long cur;
+            if (m[0]) { b = 0; cur = m[0]; m[0] &= m[0] - 1; }
+            else if (m[1]) { b = 1; cur = m[1]; m[1] &= m[1] - 1; }
+            else if (m[2]) { b = 2; cur = m[2]; m[2] &= m[2] - 1; }
+            else { b = 3; cur = m[3]; m[3] &= m[3] - 1; }
+            const int jj = __ffsll((long long)cur) - 1;
+            const double2 pj = l_pos[w][b][jj];
+            const double ddx = pj.x - pi.x, ddy = pj.y - pi.y;
+            const double d2 = ddx * ddx + ddy * ddy;
+            // the reference's decision: sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291)
+            const bool nearp = (d2 < c2_lo) || (d2 < c2_hi && sqrt(d2) < c);
+            if (nearp)
+                pair_term((float)ddx, (float)ddy, vi.x, vi.y, vi.z, hi.x, hi.y, vi.w, ib2_i, inv_vdes,
+                          l_vel[w][b][jj], l_head[w][b][jj], b_max, db, neg_inv_eta_log2e, fx, fy);
+        }
+    };
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        int t;
+        if (use_list) t = (lane < nb_cnt) ? nb[1 + lane] : -1;
+        else t = (ch * 64 + lane < S.ntiles) ? ch * 64 + lane : -1;
+        bool hit = (t >= 0) && box_hit(bi, S.tile_box[t], c);
+        unsigned long long tmask = __ballot(hit);
+        while (tmask) {
+            int b = __ffsll((long long)tmask) - 1;
+            tmask &= tmask - 1;
+            if (((ord++) & 3) != w) continue;           // this hit belongs to another wavefront of the block
+            q[nq++] = __builtin_amdgcn_readlane(t, b);
+            if (nq == PB) {
+                process(PB);
+                nq = 0;
+            }
+        }
+    }
+    if (nq) process(nq);
+    l_red[w][lane] = make_double2(fx, fy);
+    __syncthreads();
+    if (w == 0) {
+        double2 a0 = l_red[0][lane], a1 = l_red[1][lane], a2 = l_red[2][lane], a3 = l_red[3][lane];
+        S.f_pair[k] = make_double2((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- wall search over the work-list
+// WG lanes cooperate on one agent: in round o lane `sub` takes row r0 + WG*o + sub upwards and r0 - 1 - WG*o - sub
+// downwards, then the group min-reduces (objective, flat index) so every lane prunes with the group's best.  The
+// serial row chain of the one-lane version (latency-bound, up to ~60 dependent rounds) becomes ~8x shorter.
+#define WG 8
+__global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
+                                             const int32_t* __restrict__ key_of, const double* __restrict__ X0,
+                                             const double* __restrict__ Y0, int cur) {
+    const int t = (blockIdx.x * 64 + threadIdx.x) / WG, sub = threadIdx.x & (WG - 1);
+    const int count = S.ctrl[C_WCOUNT + cur];
+    const bool live = t < count;
+    const int k = live ? S.wall_list[cur][t] : 0;
+    const int i = live ? S.pidx[k] : -1;
+    // (all lanes of a group share t, so `live`/`i` are uniform inside the group; idle groups still shuffle)
+    const int ii = i >= 0 ? i : 0;
+    const KeyDev& kd = keys[i >= 0 ? key_of[ii] : 0];
+    const double2 p = S.ppos[k];
+    const int Nx = P.Nx, Ny = P.Ny;
+    const double hx = P.L / (Nx - 1), hy = P.H / (Ny - 1);
+    double rad2 = 0, ub2 = 0;
+    bool go = (i >= 0) && wall_needed(P, kd, X0, Y0, p.x, p.y, (double)S.pvel[k].z, rad2, ub2);
+    double best_f = INFINITY, best_d2 = INFINITY, thr = INFINITY;
+    long long best_flat = -1;
+    int jx = 0, r0 = 0;
+    if (go) {
+        jx = (int)floor(p.x / hx);
+        jx = jx < 0 ? 0 : (jx > Nx - 1 ? Nx - 1 : jx);
+        while (jx > 0 && X0[jx] > p.x) --jx;
+        while (jx < Nx - 1 && X0[jx + 1] <= p.x) ++jx;
+        r0 = (int)floor(p.y / hy + 0.5);
+        r0 = r0 < 0 ? 0 : (r0 > Ny - 1 ? Ny - 1 : r0);
+    }
+    const int2* __restrict__ col = kd.lr + (size_t)jx * Ny;
+    const double lim2 = fmin(rad2, ub2);
+    bool up = go, dn = go;
+    for (int o = 0; __any(up || dn); ++o) {
+        if (up || dn) {
+            const int ru = r0 + WG * o + sub, rd = r0 - 1 - WG * o - sub;
+            const bool vu = up && ru < Ny, vd = dn && rd >= 0;
+            const int ruc = vu ? ru : 0, rdc = vd ? rd : 0;
+            const double yu = Y0[ruc], yd = Y0[rdc];
+            const int2 cu = col[ruc], cd = col[rdc];
+            if (vu) {
+                const double ady = fabs(yu - p.y), ady2 = ady * ady;
+                if (!(ady2 > thr || ady2 > lim2)) {
+                    wall_try(p.x, p.y, ru, cu.x, Nx, X0, yu, kd.off, best_d2, thr, best_f, best_flat);
+                    wall_try(p.x, p.y, ru, cu.y, Nx, X0, yu, kd.off, best_d2, thr, best_f, best_flat);
+                }
+            }
+            if (vd) {
+                const double ady = fabs(yd - p.y), ady2 = ady * ady;
+                if (!(ady2 > thr || ady2 > lim2)) {
+                    wall_try(p.x, p.y, rd, cd.x, Nx, X0, yd, kd.off, best_d2, thr, best_f, best_flat);
+                    wall_try(p.x, p.y, rd, cd.y, Nx, X0, yd, kd.off, best_d2, thr, best_f, best_flat);
+                }
+            }
+        }
+        // group reduction: minimum objective, ties -> lowest flat index (numpy's first minimum)
+#pragma unroll
+        for (int m = 1; m < WG; m <<= 1) {
+            const double of = __shfl_xor(best_f, m, 64), od2 = __shfl_xor(best_d2, m, 64);
+            const long long ofl = __shfl_xor(best_flat, m, 64);
+            if (of < best_f || (of == best_f && ofl >= 0 && (best_flat < 0 || ofl < best_flat))) {
+                best_f = of;
+                best_flat = ofl;
+            }
+            best_d2 = fmin(best_d2, od2);
+        }
+        if (best_d2 < INFINITY) thr = best_d2 + 4.8e-10 * sqrt(best_d2) + 1e-19;
+        // next round's nearest rows (group-uniform): stop a direction once its rows cannot matter any more
+        const int nu = r0 + WG * (o + 1), nd = r0 - 1 - WG * (o + 1);
+        if (up) {
+            if (nu >= Ny) up = false;
+            else {
+                const double yy = Y0[nu], a2 = (yy - p.y) * (yy - p.y);
+                if (yy > p.y && (a2 > thr || a2 > lim2)) up = false;
+            }
+        }
+        if (dn) {
+            if (nd < 0) dn = false;
+            else {
+                const double yy = Y0[nd], a2 = (yy - p.y) * (yy - p.y);
+                if (yy < p.y && (a2 > thr || a2 > lim2)) dn = false;
+            }
+        }
+    }
+    if (i >= 0 && sub == 0) S.widx[k] = best_flat;
 }
 
 // capped exact distance transform of the site set on the grid nodes (init-time, one thread per node)
@@ -364,41 +580,6 @@ __global__ void __launch_bounds__(256) k_edt(const int2* __restrict__ lr, int Nx
     wall_scan(X0[j], Y0[i], lr, Nx, Ny, hx, hy, X0, Y0, 0.0, cap * cap, INFINITY, flat, d2);
     double d = (flat >= 0) ? sqrt(d2) : cap;
     edt[(size_t)i * Nx + j] = (float)fmin(d, cap);
-}
-
-// wall force from the selected cell, float64 (pedestrians.py:317-334)
-__global__ void k_wall_force(GcfmParams P, Scratch S, const double* __restrict__ vx, const double* __restrict__ vy,
-                             const double* __restrict__ v_des, const double* __restrict__ X0,
-                             const double* __restrict__ Y0) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= S.Np) return;
-    int i = S.pidx[k];
-    long long flat = S.widx[k];
-    double2 out = make_double2(0.0, 0.0);
-    if (i >= 0 && flat >= 0) {
-        int r = (int)(flat / P.Nx), cc = (int)(flat % P.Nx);
-        double2 p = S.ppos[k];
-        double Rx = X0[cc] - p.x, Ry = Y0[r] - p.y;
-        double rr = sqrt(Rx * Rx + Ry * Ry);
-        double ex = Rx / rr, ey = Ry / rr;
-        double vxd = vx[i], vyd = vy[i];
-        double d = vxd * ex + vyd * ey;
-        double vrel = 0.5 * (d + fabs(d));
-        double s = sqrt(vxd * vxd + vyd * vyd);
-        double hx = 1.0, hy = 0.0;
-        if (s > 0) {
-            hx = vxd / s;
-            hy = vyd / s;
-        }
-        double a = P.a_min + P.tau_a * s;
-        double b = P.b_max - (P.b_max - P.b_min) * fmin(s / v_des[i], 1.0);
-        double ca = (ex * hx + ey * hy) / a, sb = (hx * ey - hy * ex) / b;
-        double q = 1.0 / (ca * ca + sb * sb);                 // Q12: no square root
-        double dist = rr - q;
-        double rep = fmin(exp(-dist / (P.eta_walls * (1.0 + vrel))), 1.0);
-        out = make_double2(-3.0 * rep * Rx, -3.0 * rep * Ry);
-    }
-    S.f_wall[k] = out;
 }
 
 // ---------------------------------------------------------------------------------- lookup
@@ -469,20 +650,6 @@ __device__ __forceinline__ double2 lookup(const GcfmParams& P, const KeyDev& kd,
     return make_double2(vdes * d.x, vdes * d.y);
 }
 
-__global__ void k_lookup(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
-                         const int32_t* __restrict__ key_of, const double* __restrict__ v_des, int step,
-                         int32_t* err) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= S.Np) return;
-    int i = S.pidx[k];
-    double2 d = make_double2(0.0, 0.0);
-    if (i >= 0) {
-        double2 p = S.ppos[k];
-        d = lookup(P, keys[key_of[i]], p.x, p.y, v_des[i], step, i, err);
-    }
-    S.des[k] = d;
-}
-
 // ---------------------------------------------------------------------------------- noise (Philox4x32-10)
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t out[4]) {
@@ -498,60 +665,129 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// ---------------------------------------------------------------------------------- integrate
-// simulations.py:303-332 for every active agent, in place (forces were computed from the packed snapshot)
-__global__ void k_integrate(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
-                            const int32_t* __restrict__ key_of, double* __restrict__ x, double* __restrict__ y,
-                            double* __restrict__ vx, double* __restrict__ vy, uint8_t* __restrict__ status,
-                            double* __restrict__ agent_time, const double* __restrict__ noise, uint64_t seed,
-                            int step) {
+// ---------------------------------------------------------------------------------- finish
+// simulations.py:277-332 for every active agent (one wavefront per tile), then the next step's packed snapshot.
+__global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
+                                               const int32_t* __restrict__ key_of, double* __restrict__ x,
+                                               double* __restrict__ y, double* __restrict__ vx,
+                                               double* __restrict__ vy, const double* __restrict__ v_des,
+                                               uint8_t* __restrict__ status, double* __restrict__ agent_time,
+                                               const double* __restrict__ noise, uint64_t seed, int step,
+                                               const double* __restrict__ X0, const double* __restrict__ Y0, int nxt,
+                                               int32_t* __restrict__ cnt_out) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int i = S.pidx[k];
+    bool act = i >= 0, out = false, need = false;
+    double nx = 1e300, ny = 1e300;
+    if (act) {
+        const KeyDev& kd = keys[key_of[i]];
+        const double2 p = S.ppos[k];
+        const double vxd = vx[i], vyd = vy[i], vd = v_des[i];
+        // desired velocity, repulsions
+        const double2 ds = lookup(P, kd, p.x, p.y, vd, step, i, &cnt_out[C_ERR]);
+        const double2 fp = S.f_pair[k];
+        const double2 fw = wall_force_of(P, S.widx[k], p.x, p.y, vxd, vyd, vd, X0, Y0);
+        // noise: caller's standard normals, or Philox4x32-10 + Box-Muller (float32)
+        double n0, n1;
+        if (noise) {
+            n0 = noise[2 * (size_t)i];
+            n1 = noise[2 * (size_t)i + 1];
+        } else {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)i, (uint32_t)step, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            float u1 = ((float)(r[0] >> 8) + 0.5f) * 0x1p-24f, u2 = ((float)(r[1] >> 8) + 0.5f) * 0x1p-24f;
+            float rad = sqrtf(-2.0f * __logf(u1));
+            n0 = (double)(rad * __cosf(6.2831853f * u2));
+            n1 = (double)(rad * __sinf(6.2831853f * u2));
+        }
+        // simulations.py:303-326
+        const double cvx = vxd + P.noise_amp * n0 + fp.x + fw.x;
+        const double cvy = vyd + P.noise_amp * n1 + fp.y + fw.y;
+        const double ax = (ds.x - cvx) / P.relaxation, ay = (ds.y - cvy) / P.relaxation;
+        const double dt = P.dt, dt2 = dt * dt;
+        nx = p.x + cvx * dt + 0.5 * ax * dt2;
+        ny = p.y + cvy * dt + 0.5 * ay * dt2;
+        double nvx = cvx + ax * dt, nvy = cvy + ay * dt;
+        const double nrm = sqrt(nvx * nvx + nvy * nvy);
+        if (!(nrm < P.v_max)) {
+            const double sc = P.v_max / nrm;
+            nvx *= sc;
+            nvy *= sc;
+        }
+        x[i] = nx;
+        y[i] = ny;
+        vx[i] = nvx;
+        vy[i] = nvy;
+        if (agent_time) agent_time[i] += dt;
+        // exit test against the agent's own targets, strict (pedestrians.py:132-136)
+        for (int q = 0; q < kd.nrect; ++q)
+            if (fabs(nx - kd.rect[q][0]) < kd.rect[q][2] * 0.5 && fabs(ny - kd.rect[q][1]) < kd.rect[q][3] * 0.5)
+                out = true;
+        // next step's packed record
+        float4 pv;
+        float2 ph;
+        if (out) {
+            status[i] = 0;
+            S.ppos[k] = make_double2(1e300, 1e300);
+            S.pvel[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            S.phead[k] = make_float2(1.f, 0.f);
+            S.pidx[k] = -1;
+        } else {
+            make_record(P, nvx, nvy, pv, ph);
+            S.ppos[k] = make_double2(nx, ny);
+            S.pvel[k] = pv;
+            S.phead[k] = ph;
+            double r2, u2;
+            need = wall_needed(P, kd, X0, Y0, nx, ny, (double)pv.z, r2, u2);
+        }
+        S.widx[k] = -1;
+    }
+    const bool stay = act && !out;
+    if (blockIdx.x == 0 && threadIdx.x == 0) S.ctrl[C_QUEUE] = 0;      // k_pair's queue for the next step
+    // counters: one atomic per wavefront (100k same-address atomics cost > 1 ms)
+    unsigned long long m_out = __ballot(out), m_in = __ballot(stay);
+    const int lane = threadIdx.x;
+    if (m_out && lane == __ffsll((long long)m_out) - 1) atomicAdd(&cnt_out[C_EXIT], __popcll(m_out));
+    if (m_in && lane == __ffsll((long long)m_in) - 1) atomicAdd(&cnt_out[C_ACTIVE], __popcll(m_in));
+    wall_list_push(need, k, S.wall_list[nxt], &S.ctrl[C_WCOUNT + nxt]);
+    // tile box of the new positions + validity of the neighbour lists
+    double mnx = wmin(stay ? nx : INFINITY), mny = wmin(stay ? ny : INFINITY);
+    double mxx = wmax(stay ? nx : -INFINITY), mxy = wmax(stay ? ny : -INFINITY);
+    if (lane == 0) {
+        S.tile_box[blockIdx.x] = make_double4(mnx, mny, mxx, mxy);
+        const double4 b0 = S.tile_box0[blockIdx.x];
+        const double D = P.drift;
+        if (mnx <= mxx && (mnx < b0.x - D || mny < b0.y - D || mxx > b0.z + D || mxy > b0.w + D)) S.ctrl[C_INVALID] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------- diagnostics (single-shot exports)
+__global__ void k_lookup_diag(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
+                              const int32_t* __restrict__ key_of, const double* __restrict__ v_des, int step,
+                              int32_t* err) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= S.Np) return;
     int i = S.pidx[k];
-    if (i < 0) return;
-    double n0, n1;
-    if (noise) {
-        n0 = noise[2 * (size_t)i];
-        n1 = noise[2 * (size_t)i + 1];
-    } else {
-        uint32_t r[4];
-        philox4x32_10((uint32_t)i, (uint32_t)step, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-        double u1 = ((double)r[0] + 0.5) * 0x1p-32, u2 = ((double)r[1] + 0.5) * 0x1p-32;
-        double rad = sqrt(-2.0 * log(u1));
-        n0 = rad * cos(6.283185307179586 * u2);
-        n1 = rad * sin(6.283185307179586 * u2);
+    double2 d = make_double2(0.0, 0.0);
+    if (i >= 0) {
+        double2 p = S.ppos[k];
+        d = lookup(P, keys[key_of[i]], p.x, p.y, v_des[i], step, i, err);
     }
-    double2 p = S.ppos[k], fp = S.f_pair[k], fw = S.f_wall[k], ds = S.des[k];
-    double vxd = vx[i], vyd = vy[i];
-    double cvx = vxd + P.noise_amp * n0 + fp.x + fw.x;
-    double cvy = vyd + P.noise_amp * n1 + fp.y + fw.y;
-    double ax = (ds.x - cvx) / P.relaxation, ay = (ds.y - cvy) / P.relaxation;
-    double dt = P.dt, dt2 = dt * dt;
-    double nx = p.x + cvx * dt + 0.5 * ax * dt2;
-    double ny = p.y + cvy * dt + 0.5 * ay * dt2;
-    double nvx = cvx + ax * dt, nvy = cvy + ay * dt;
-    double nrm = sqrt(nvx * nvx + nvy * nvy);
-    if (!(nrm < P.v_max)) {
-        double sc = P.v_max / nrm;
-        nvx *= sc;
-        nvy *= sc;
+    S.des[k] = d;
+}
+
+__global__ void k_wall_force_diag(GcfmParams P, Scratch S, const double* __restrict__ vx, const double* __restrict__ vy,
+                                  const double* __restrict__ v_des, const double* __restrict__ X0,
+                                  const double* __restrict__ Y0) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S.Np) return;
+    int i = S.pidx[k];
+    double2 out = make_double2(0.0, 0.0);
+    if (i >= 0) {
+        double2 p = S.ppos[k];
+        out = wall_force_of(P, S.widx[k], p.x, p.y, vx[i], vy[i], v_des[i], X0, Y0);
     }
-    x[i] = nx;
-    y[i] = ny;
-    vx[i] = nvx;
-    vy[i] = nvy;
-    if (agent_time) agent_time[i] += dt;
-    // exit test against the agent's own targets, strict (pedestrians.py:132-136)
-    const KeyDev& kd = keys[key_of[i]];
-    bool out = false;
-    for (int q = 0; q < kd.nrect; ++q)
-        if (fabs(nx - kd.rect[q][0]) < kd.rect[q][2] * 0.5 && fabs(ny - kd.rect[q][1]) < kd.rect[q][3] * 0.5)
-            out = true;
-    if (out) status[i] = 0;
-    // one atomic per wavefront and counter (100k same-address atomics cost > 1 ms)
-    unsigned long long m_out = __ballot(out), m_in = __ballot(!out);
-    if (m_out && (threadIdx.x & 63) == __ffsll((long long)m_out) - 1) atomicAdd(&S.counters[0], __popcll(m_out));
-    if (m_in && (threadIdx.x & 63) == __ffsll((long long)m_in) - 1) atomicAdd(&S.counters[2], __popcll(m_in));
+    S.f_wall[k] = out;
 }
 
 template <typename TV>
@@ -592,21 +828,23 @@ GcfmParams make_params(const oc_handle* h) {
     P.cell = c.repulsion_cutoff > 0 ? c.repulsion_cutoff : 4.0;
     P.ncx = (int)(c.room_length / P.cell) + 1;
     P.ncy = (int)(c.room_height / P.cell) + 1;
+    P.drift = 1.5 * c.v_max * c.dt * h->resort_every + 0.1;
     return P;
 }
 
 int carve(oc_handle* h, int N, Scratch* S) {
     int Np = ((N + 63) / 64) * 64;
     if (Np == 0) Np = 64;
+    const int nt = Np / 64;
     size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + sizeof(double2) + sizeof(float4) + sizeof(float2) +
-                 sizeof(int32_t) + 3 * sizeof(double2) + sizeof(long long);
-    size_t need = per * (size_t)Np + sizeof(double4) * (size_t)(Np / 64) + 64 + 4096;
+                 sizeof(int32_t) + 3 * sizeof(double2) + sizeof(long long) + 2 * sizeof(int32_t);
+    size_t need = per * (size_t)Np + (2 * sizeof(double4) + (NB_MAX + 1) * sizeof(int32_t)) * (size_t)nt + 64 + 8192;
     if (need > h->gcfm_bytes) {
         if (h->gcfm_buf) OC_HIP_CHECK(hipFree(h->gcfm_buf));
         h->gcfm_buf = nullptr;
         OC_HIP_CHECK(hipMalloc(&h->gcfm_buf, need));
         h->gcfm_bytes = need;
-        h->sorted_N = -1;
+        h->packed_valid = false;
     }
     char* p = (char*)h->gcfm_buf;
     auto take = [&](size_t bytes) {
@@ -614,13 +852,13 @@ int carve(oc_handle* h, int N, Scratch* S) {
         p += (bytes + 255) & ~(size_t)255;
         return (void*)q;
     };
-    // carve order: 16-byte aligned types first
     S->ppos = (double2*)take(sizeof(double2) * Np);
     S->pvel = (float4*)take(sizeof(float4) * Np);
     S->f_pair = (double2*)take(sizeof(double2) * Np);
     S->f_wall = (double2*)take(sizeof(double2) * Np);
     S->des = (double2*)take(sizeof(double2) * Np);
-    S->tile_box = (double4*)take(sizeof(double4) * (Np / 64));
+    S->tile_box = (double4*)take(sizeof(double4) * nt);
+    S->tile_box0 = (double4*)take(sizeof(double4) * nt);
     S->widx = (long long*)take(sizeof(long long) * Np);
     S->phead = (float2*)take(sizeof(float2) * Np);
     S->keys_a = (uint32_t*)take(sizeof(uint32_t) * Np);
@@ -628,9 +866,12 @@ int carve(oc_handle* h, int N, Scratch* S) {
     S->vals_a = (int32_t*)take(sizeof(int32_t) * Np);
     S->vals_b = (int32_t*)take(sizeof(int32_t) * Np);
     S->pidx = (int32_t*)take(sizeof(int32_t) * Np);
-    S->counters = (int32_t*)take(64);
+    S->wall_list[0] = (int32_t*)take(sizeof(int32_t) * Np);
+    S->wall_list[1] = (int32_t*)take(sizeof(int32_t) * Np);
+    S->nb_list = (int32_t*)take(sizeof(int32_t) * (NB_MAX + 1) * (size_t)nt);
+    S->ctrl = (int32_t*)take(64);
     S->Np = Np;
-    S->ntiles = Np / 64;
+    S->ntiles = nt;
     return OC_OK;
 }
 
@@ -668,25 +909,38 @@ int check_agents(const oc_handle* h, const oc_agents* a) {
     return OC_OK;
 }
 
-// order + packed snapshot of the current state
-int prepare(oc_handle* h, const oc_agents* a, bool force_sort, Scratch* S, GcfmParams* P, hipStream_t s) {
+bool wallmaps_ready(const oc_handle* h) {
+    for (const auto& w : h->wallmaps)
+        if (!w.built) return false;
+    return true;
+}
+
+// re-sort + full pack of the current state + neighbour lists + wall work-list
+int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hipStream_t s) {
+    const int N = a->N;
+    OC_HIP_CHECK(hipMemsetAsync(S->ctrl, 0, 64, s));
+    if (N > 0) {
+        hipLaunchKernelGGL(k_cell_keys, dim3((N + 255) / 256), dim3(256), 0, s, a->x, a->y, a->status, N, P, S->keys_a,
+                           S->vals_a);
+        int rc = oc_sort_pairs(h, S->keys_a, S->keys_b, S->vals_a, S->vals_b, N, 30, s);
+        if (rc) return rc;
+    }
+    const KeyDev* kd = wallmaps_ready(h) ? (const KeyDev*)h->key_tables_dev : nullptr;
+    hipLaunchKernelGGL(k_pack, dim3(S->ntiles), dim3(64), 0, s, a->x, a->y, a->vx, a->vy, a->status, a->key, S->vals_b, N,
+                       P, *S, kd, h->X0, h->Y0, h->wl_parity);
+    hipLaunchKernelGGL(k_tile_lists, dim3(S->ntiles), dim3(64), 0, s, P, *S);
+    h->steps_since_sort = 0;
+    h->packed_x = a->x;
+    h->packed_N = N;
+    return OC_OK;
+}
+
+int prepare(oc_handle* h, const oc_agents* a, Scratch* S, GcfmParams* P, hipStream_t s) {
     int rc = carve(h, a->N, S);
     if (rc) return rc;
     *P = make_params(h);
-    const int N = a->N;
-    if (force_sort || h->sorted_N != N || h->steps_since_sort >= h->resort_every) {
-        if (N > 0) {
-            hipLaunchKernelGGL(k_cell_keys, dim3((N + 255) / 256), dim3(256), 0, s, a->x, a->y, a->status, N, *P,
-                               S->keys_a, S->vals_a);
-            rc = oc_sort_pairs(h, S->keys_a, S->keys_b, S->vals_a, S->vals_b, N, 30, s);
-            if (rc) return rc;
-        }
-        h->sorted_N = N;
-        h->steps_since_sort = 0;
-    }
-    hipLaunchKernelGGL(k_pack, dim3(S->ntiles), dim3(64), 0, s, a->x, a->y, a->vx, a->vy, a->status, S->vals_b, N, *P,
-                       *S);
-    return OC_OK;
+    if ((rc = upload_keys(h, s))) return rc;
+    return repack(h, a, S, *P, s);
 }
 
 }   // namespace
@@ -712,6 +966,7 @@ extern "C" int oc_wallmap_build(oc_handle* h, int key, const float* V, float vmi
     w.off = (double)vmin * 10e3;
     w.built = true;
     h->key_tables_dirty = true;
+    h->packed_valid = false;
     return OC_OK;
 }
 
@@ -724,6 +979,12 @@ static int require_wallmaps(oc_handle* h) {
     return OC_OK;
 }
 
+extern "C" int oc_agents_changed(oc_handle* h) {
+    OC_REQUIRE(h, "null handle");
+    h->packed_valid = false;
+    return OC_OK;
+}
+
 extern "C" int oc_field_lookup(oc_handle* h, const oc_agents* a, int32_t simu_step, double* des, int32_t* err_flag,
                                void* stream) {
     int rc = check_agents(h, a);
@@ -733,11 +994,11 @@ extern "C" int oc_field_lookup(oc_handle* h, const oc_agents* a, int32_t simu_st
     hipStream_t s = (hipStream_t)stream;
     Scratch S;
     GcfmParams P;
-    if ((rc = upload_keys(h, s))) return rc;
-    if ((rc = prepare(h, a, false, &S, &P, s))) return rc;
+    if ((rc = prepare(h, a, &S, &P, s))) return rc;
+    h->packed_valid = false;
     OC_HIP_CHECK(hipMemsetAsync(des, 0, sizeof(double) * 2 * (size_t)a->N, s));
     if (err_flag) OC_HIP_CHECK(hipMemsetAsync(err_flag, 0, sizeof(int32_t) * 2, s));
-    hipLaunchKernelGGL(k_lookup, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, (const KeyDev*)h->key_tables_dev,
+    hipLaunchKernelGGL(k_lookup_diag, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, (const KeyDev*)h->key_tables_dev,
                        a->key, a->v_des, simu_step, err_flag);
     hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.des, S.pidx, S.Np,
                        (double2*)des);
@@ -753,12 +1014,12 @@ extern "C" int oc_wall_force(oc_handle* h, const oc_agents* a, int64_t* index_ou
     hipStream_t s = (hipStream_t)stream;
     Scratch S;
     GcfmParams P;
-    if ((rc = upload_keys(h, s))) return rc;
-    if ((rc = prepare(h, a, false, &S, &P, s))) return rc;
-    hipLaunchKernelGGL(k_wall, dim3(S.ntiles), dim3(64), 0, s, P, S, (const KeyDev*)h->key_tables_dev, a->key, a->v_des,
+    if ((rc = prepare(h, a, &S, &P, s))) return rc;
+    h->packed_valid = false;
+    hipLaunchKernelGGL(k_wall, dim3(S.ntiles * WG), dim3(64), 0, s, P, S, (const KeyDev*)h->key_tables_dev, a->key,
+                       h->X0, h->Y0, h->wl_parity);
+    hipLaunchKernelGGL(k_wall_force_diag, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, a->vx, a->vy, a->v_des,
                        h->X0, h->Y0);
-    hipLaunchKernelGGL(k_wall_force, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, a->vx, a->vy, a->v_des, h->X0,
-                       h->Y0);
     if (index_out) {
         OC_HIP_CHECK(hipMemsetAsync(index_out, 0xFF, sizeof(int64_t) * (size_t)a->N, s));
         hipLaunchKernelGGL(k_scatter<long long>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.widx, S.pidx, S.Np,
@@ -781,9 +1042,11 @@ extern "C" int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out
     hipStream_t s = (hipStream_t)stream;
     Scratch S;
     GcfmParams P;
-    if ((rc = prepare(h, a, false, &S, &P, s))) return rc;
+    if ((rc = prepare(h, a, &S, &P, s))) return rc;
+    h->packed_valid = false;
     oc_timer_begin(h, "gcfm_pair", s);
-    hipLaunchKernelGGL(k_pair, dim3(S.ntiles), dim3(256), 0, s, P, S, a->v_des);
+    hipLaunchKernelGGL(k_pair, dim3(std::min(S.ntiles, h->pair_grid)), dim3(256), 0, s, P, S, a->v_des, 1 - h->wl_parity, S.ctrl);
+    OC_HIP_CHECK(hipMemsetAsync(S.ctrl + C_QUEUE, 0, sizeof(int32_t), s));
     oc_timer_end(h, "gcfm_pair", s);
     OC_HIP_CHECK(hipMemsetAsync(force_out, 0, sizeof(double) * 2 * (size_t)a->N, s));
     hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_pair, S.pidx, S.Np,
@@ -800,25 +1063,29 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     OC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     Scratch S;
-    GcfmParams P;
+    if ((rc = carve(h, a->N, &S))) return rc;
+    GcfmParams P = make_params(h);
     if ((rc = upload_keys(h, s))) return rc;
-    if ((rc = prepare(h, a, false, &S, &P, s))) return rc;
-    ++h->steps_since_sort;
-    OC_HIP_CHECK(hipMemsetAsync(S.counters, 0, 64, s));
+    // the packed snapshot written by the previous step is reused unless the caller's arrays changed
+    if (!h->packed_valid || h->packed_x != a->x || h->packed_N != a->N || h->steps_since_sort >= h->resort_every) {
+        if ((rc = repack(h, a, &S, P, s))) return rc;
+    }
     const KeyDev* kd = (const KeyDev*)h->key_tables_dev;
-    dim3 g256((S.Np + 255) / 256);
-    hipLaunchKernelGGL(k_lookup, g256, dim3(256), 0, s, P, S, kd, a->key, a->v_des, simu_step, S.counters + 1);
+    const int cur = h->wl_parity, nxt = 1 - cur;
+    int32_t* cnt = counters ? counters : S.ctrl;
     oc_timer_begin(h, "gcfm_pair", s);
-    hipLaunchKernelGGL(k_pair, dim3(S.ntiles), dim3(256), 0, s, P, S, a->v_des);
+    hipLaunchKernelGGL(k_pair, dim3(std::min(S.ntiles, h->pair_grid)), dim3(256), 0, s, P, S, a->v_des, nxt, cnt);
     oc_timer_end(h, "gcfm_pair", s);
     oc_timer_begin(h, "gcfm_wall", s);
-    hipLaunchKernelGGL(k_wall, dim3(S.ntiles), dim3(64), 0, s, P, S, kd, a->key, a->v_des, h->X0, h->Y0);
-    hipLaunchKernelGGL(k_wall_force, g256, dim3(256), 0, s, P, S, a->vx, a->vy, a->v_des, h->X0, h->Y0);
+    hipLaunchKernelGGL(k_wall, dim3(S.ntiles * WG), dim3(64), 0, s, P, S, kd, a->key, h->X0, h->Y0, cur);
     oc_timer_end(h, "gcfm_wall", s);
-    hipLaunchKernelGGL(k_integrate, g256, dim3(256), 0, s, P, S, kd, a->key, a->x, a->y, a->vx, a->vy, a->status,
-                       a->agent_time, noise, seed, simu_step);
-    if (counters)
-        OC_HIP_CHECK(hipMemcpyAsync(counters, S.counters, sizeof(int32_t) * 4, hipMemcpyDeviceToDevice, s));
+    oc_timer_begin(h, "gcfm_finish", s);
+    hipLaunchKernelGGL(k_finish, dim3(S.ntiles), dim3(64), 0, s, P, S, kd, a->key, a->x, a->y, a->vx, a->vy, a->v_des,
+                       a->status, a->agent_time, noise, seed, simu_step, h->X0, h->Y0, nxt, cnt);
+    oc_timer_end(h, "gcfm_finish", s);
     OC_HIP_CHECK(hipGetLastError());
+    h->wl_parity = nxt;
+    h->packed_valid = true;
+    ++h->steps_since_sort;
     return OC_OK;
 }
