@@ -38,6 +38,7 @@ struct GcfmParams {
     double dx, dy, L, H, dt;
     double a_min, tau_a, b_min, b_max, eta, eta_walls, cutoff, v_max, relaxation, noise_amp;
     double wall_radius;
+    double cut_d2max;   // largest double d2 with sqrt(d2) < cutoff: `d2 <= cut_d2max` IS the reference's decision
     double cell;        // coarse cell size for ordering
     double drift;       // D: how far a tile box may grow beyond its sort-time box before the lists are invalid
     int32_t ncx, ncy;
@@ -340,14 +341,13 @@ __device__ __forceinline__ void pair_term(float Rx, float Ry, float vxi, float v
     fy += (double)(-rep * Ry);
 }
 
-#define PB 4     // j-tiles staged per batch and wavefront
-
 __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const double* __restrict__ v_des, int nxt,
                                               int32_t* __restrict__ cnt_out) {
-    __shared__ double2 l_pos[4][PB][64];
-    __shared__ float4 l_vel[4][PB][64];
-    __shared__ float2 l_head[4][PB][64];
-    __shared__ float2 l_rel[4][PB][64];
+    __shared__ double2 l_pos[4][64];
+    __shared__ float4 l_vel[4][64];
+    __shared__ float2 l_head[4][64];
+    __shared__ alignas(16) float l_rx[4][64];
+    __shared__ alignas(16) float l_ry[4][64];
     __shared__ double2 l_red[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __shared__ int l_it;
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const dou
     }
     const double4 bi = S.tile_box[it];
     const double c = P.cutoff;
-    const double c2 = c * c, c2_lo = c2 * (1.0 - 1e-15), c2_hi = c2 * (1.0 + 1e-15);
+    const double c2 = c * c;
     const double ox = bi.x, oy = bi.y;                 // origin of the box-relative float32 coordinates
     const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
     double fx = 0.0, fy = 0.0;
@@ -389,66 +389,57 @@ __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const dou
     const int nb_cnt = nb[0];
     const bool use_list = (nb_cnt >= 0) && (S.ctrl[C_INVALID] == 0);
     const int nchunk = use_list ? 1 : (S.ntiles + 63) / 64;
-    int ord = 0, nq = 0;
-    int q[PB];
+    int ord = 0;
 
-    auto process = [&](int n) {
-        // ---- stage n tiles in this wavefront's LDS area
+    auto process = [&](int jt) {
+        // ---- stage tile jt in this wavefront's LDS area (LDS ops of one wavefront complete in order)
         __builtin_amdgcn_wave_barrier();
-        float c2f[PB];
-#pragma unroll
-        for (int b = 0; b < PB; ++b) {
-            if (b < n) {
-                const int jt = q[b];
-                double2 pj_own = S.ppos[jt * 64 + lane];
-                l_pos[w][b][lane] = pj_own;
-                l_rel[w][b][lane] = make_float2((float)(pj_own.x - ox), (float)(pj_own.y - oy));
-                l_vel[w][b][lane] = S.pvel[jt * 64 + lane];
-                l_head[w][b][lane] = S.phead[jt * 64 + lane];
-                // conservative float32 bound: rounding of the relative coordinates scales with the boxes' extent
-                double4 bj = S.tile_box[jt];
-                float ext = (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
-                                    fmax(fmax(bi.w, bj.w) - oy, oy - fmin(bi.y, bj.y)));
-                c2f[b] = (float)c2 * 1.00001f + 1e-6f * ext * (ext + (float)c);
-            }
-        }
+        const double2 pj_own = S.ppos[jt * 64 + lane];
+        l_pos[w][lane] = pj_own;
+        l_rx[w][lane] = (float)(pj_own.x - ox);
+        l_ry[w][lane] = (float)(pj_own.y - oy);
+        l_vel[w][lane] = S.pvel[jt * 64 + lane];
+        l_head[w][lane] = S.phead[jt * 64 + lane];
+        // conservative float32 bound: rounding of the relative coordinates scales with the boxes' extent
+        const double4 bj = S.tile_box[jt];
+        const float ext = (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
+                                  fmax(fmax(bi.w, bj.w) - oy, oy - fmin(bi.y, bj.y)));
+        const float c2f = (float)c2 * 1.00001f + 1e-6f * ext * (ext + (float)c);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- phase 1: candidate masks of this lane's agent, one per staged tile
-        unsigned long long m[PB];
+        // ---- phase 1: 64 candidate bits of this lane's agent (broadcast float4 LDS reads)
+        uint32_t mw[2];
 #pragma unroll
-        for (int b = 0; b < PB; ++b) {
-            m[b] = 0ull;
-            if (b < n) {
-#pragma unroll 8
-                for (int jj = 0; jj < 64; ++jj) {
-                    float2 qq = l_rel[w][b][jj];
-                    float ddx = qq.x - xi_f, ddy = qq.y - yi_f;
-                    float d2 = __builtin_fmaf(ddx, ddx, ddy * ddy);
-                    m[b] |= (d2 < c2f[b]) ? (1ull << jj) : 0ull;
-                }
-                if (q[b] == it) m[b] &= ~(1ull << lane);        // j != i
-                if (i < 0) m[b] = 0ull;
+        for (int half = 0; half < 2; ++half) {
+            uint32_t acc = 0u;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 xs = *reinterpret_cast<const float4*>(&l_rx[w][32 * half + 4 * g]);
+                const float4 ys = *reinterpret_cast<const float4*>(&l_ry[w][32 * half + 4 * g]);
+                const float dx0 = xs.x - xi_f, dx1 = xs.y - xi_f, dx2 = xs.z - xi_f, dx3 = xs.w - xi_f;
+                const float dy0 = ys.x - yi_f, dy1 = ys.y - yi_f, dy2 = ys.z - yi_f, dy3 = ys.w - yi_f;
+                const float e0 = __builtin_fmaf(dx0, dx0, dy0 * dy0), e1 = __builtin_fmaf(dx1, dx1, dy1 * dy1);
+                const float e2 = __builtin_fmaf(dx2, dx2, dy2 * dy2), e3 = __builtin_fmaf(dx3, dx3, dy3 * dy3);
+                acc |= ((e0 < c2f ? 1u : 0u) | (e1 < c2f ? 2u : 0u) | (e2 < c2f ? 4u : 0u) | (e3 < c2f ? 8u : 0u))
+                       << (4 * g);
             }
+            mw[half] = acc;
         }
-        // ---- phase 2: walk the candidates of the whole batch
-        while (m[0] | m[1] | m[2] | m[3]) {
-            int b;
-            unsigned long long cur;
-            if (m[0]) { b = 0; cur = m[0]; m[0] &= m[0] - 1; }
-            else if (m[1]) { b = 1; cur = m[1]; m[1] &= m[1] - 1; }
-            else if (m[2]) { b = 2; cur = m[2]; m[2] &= m[2] - 1; }
-            else { b = 3; cur = m[3]; m[3] &= m[3] - 1; }
-            const int jj = __ffsll((long long)cur) - 1;
-            const double2 pj = l_pos[w][b][jj];
+        unsigned long long m = (unsigned long long)mw[0] | ((unsigned long long)mw[1] << 32);
+        if (jt == it) m &= ~(1ull << lane);        // j != i
+        if (i < 0) m = 0ull;
+        // ---- phase 2: this lane's candidates
+        while (m) {
+            const int jj = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const double2 pj = l_pos[w][jj];
             const double ddx = pj.x - pi.x, ddy = pj.y - pi.y;
             const double d2 = ddx * ddx + ddy * ddy;
-            // the reference's decision: sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291)
-            const bool nearp = (d2 < c2_lo) || (d2 < c2_hi && sqrt(d2) < c);
-            if (nearp)
-                pair_term((float)ddx, (float)ddy, vi.x, vi.y, vi.z, hi.x, hi.y, vi.w, ib2_i, inv_vdes,
-                          l_vel[w][b][jj], l_head[w][b][jj], b_max, db, neg_inv_eta_log2e, fx, fy);
+            // the reference's decision sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291), as d2 <= d2max
+            if (d2 <= P.cut_d2max)
+                pair_term((float)ddx, (float)ddy, vi.x, vi.y, vi.z, hi.x, hi.y, vi.w, ib2_i, inv_vdes, l_vel[w][jj],
+                          l_head[w][jj], b_max, db, neg_inv_eta_log2e, fx, fy);
         }
     };
 
@@ -462,14 +453,9 @@ __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const dou
             int b = __ffsll((long long)tmask) - 1;
             tmask &= tmask - 1;
             if (((ord++) & 3) != w) continue;           // this hit belongs to another wavefront of the block
-            q[nq++] = __builtin_amdgcn_readlane(t, b);
-            if (nq == PB) {
-                process(PB);
-                nq = 0;
-            }
+            process(__builtin_amdgcn_readlane(t, b));
         }
     }
-    if (nq) process(nq);
     l_red[w][lane] = make_double2(fx, fy);
     __syncthreads();
     if (w == 0) {
@@ -829,6 +815,12 @@ GcfmParams make_params(const oc_handle* h) {
     P.ncx = (int)(c.room_length / P.cell) + 1;
     P.ncy = (int)(c.room_height / P.cell) + 1;
     P.drift = 1.5 * c.v_max * c.dt * h->resort_every + 0.1;
+    {   // sqrt is correctly rounded and monotone: walk down from c^2 to the first d2 whose root is below the cutoff
+        double t = P.cutoff * P.cutoff;
+        for (int q = 0; q < 8; ++q) t = std::nextafter(t, INFINITY);
+        while (!(std::sqrt(t) < P.cutoff)) t = std::nextafter(t, 0.0);
+        P.cut_d2max = t;
+    }
     return P;
 }
 

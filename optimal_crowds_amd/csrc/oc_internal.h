@@ -84,7 +84,7 @@ struct oc_handle {
     bool packed_valid = false;  // the packed snapshot matches the caller's state arrays
     const void* packed_x = nullptr;
     int32_t packed_N = -1;
-    int pair_grid = 768;        // resident k_pair blocks (3 per CU x 256 CUs); tiles are pulled from a queue
+    int pair_grid = 2048;       // k_pair blocks (8 per CU x 256 CUs at most resident); tiles are pulled from a queue
     int wl_parity = 0;          // which wall work-list the next step consumes
     void* gcfm_buf = nullptr;   // carved in gcfm.hip
     size_t gcfm_bytes = 0;
