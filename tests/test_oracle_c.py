@@ -1,0 +1,58 @@
+"""The C restatement (oracle/liboc_oracle.so, used as bench.py's cpu_baseline) against the reference fixtures."""
+import copy
+
+import numpy as np
+
+from oracle import oc_oracle as oc
+from oracle import oc_oracle_c as occ
+from optimal_crowds_amd import room_library
+
+
+def _P(room_name):
+    cfg = copy.deepcopy(oc.DEFAULT_CONFIG)
+    room = room_library.ROOMS[room_name]()
+    Nx, Ny = oc.grid_dims(room["room_length"], room["room_height"], cfg["grid_step"])
+    return occ.params(cfg, room["room_length"], room["room_height"], Nx, Ny), cfg, room
+
+
+def test_c_rhs_and_vels(golden):
+    g = golden("G2_rhs.npz")
+    P, cfg, room = _P("gold_a")
+    for phi, want in zip(g["phi"], g["rhs_m"]):
+        assert np.allclose(occ.hjb_rhs(P, phi, g["V"], g["m"]), want, rtol=1e-15, atol=0)   # <= 1 ulp
+    g3 = golden("G3_solve_gold_a_T4.npz")
+    nt = int(g3["nt"])
+    for s, gx, gy in zip(g3["v_slices"], g3["vx"], g3["vy"]):
+        k = nt - 1 - int(s)
+        if k in set(int(q) for q in g3["slices"]):
+            phi = g3["phi"][list(g3["slices"]).index(k)]
+            vx, vy = occ.vels(P, phi.ravel())
+            assert np.allclose(vx, gx, atol=1e-12) and np.allclose(vy, gy, atol=1e-12)
+
+
+def test_c_pair_and_wall(golden):
+    g = golden("G6_forces.npz")
+    P, cfg, room = _P("gold_b")
+    f = occ.pair_forces(P, g["pi"], g["vi"], g["vdes"], g["pj"], g["vj"])
+    assert np.allclose(f, g["force"], rtol=1e-12, atol=1e-15)
+    for k in range(2):
+        wm = occ.WallMap(g["X0"], g["Y0"], g["V_%d" % k])
+        assert np.array_equal(wm.query(g["wp"][:, 0], g["wp"][:, 1]), g["windex"][k])
+
+
+def test_c_step_sync_g7(golden):
+    g = golden("G7_step.npz")
+    P, cfg, room = _P("gold_b")
+    np.random.seed(int(g["seed"]))
+    sim = oc.Simulation(room, float(g["T"]), cfg=cfg, mode="synchronous")
+    for k in sim.key_names:
+        sim.targets[k].compute_optimal_velocity(0.0, np.zeros_like(sim.V))
+    step = int(g["simu_step"])
+    fields = [(sim.targets[k].vx_opt[step], sim.targets[k].vy_opt[step]) for k in sim.key_names]
+    wms = [occ.WallMap(sim.X0, sim.Y0, sim.Vs[k]) for k in sim.key_names]
+    rects = [[room["targets"][t] for t in k.split(" or ")] for k in sim.key_names]
+    nx, ny, nvx, nvy, nst = occ.step_sync(P, g["x"], g["y"], g["vx"], g["vy"], g["v_des"], g["status"],
+                                          g["key_of_agent"], fields, sim.X0, sim.Y0, wms, rects, g["noise"])
+    assert np.allclose(nx, g["syn_x"], atol=1e-10) and np.allclose(ny, g["syn_y"], atol=1e-10)
+    assert np.allclose(nvx, g["syn_vx"], atol=1e-9) and np.allclose(nvy, g["syn_vy"], atol=1e-9)
+    assert np.array_equal(nst.astype(bool), g["syn_status"])
