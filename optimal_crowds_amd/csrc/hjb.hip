@@ -296,12 +296,26 @@ __device__ __forceinline__ HaloRole halo_role(int i0, int j0, int Ny, int Nx) {
     return r;
 }
 
+// XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so workgroup b works on
+// logical tile (b % 8) * per + b / 8: every XCD sweeps a contiguous band of tiles in row-major order and the halo
+// lines of neighbouring tiles are served by that XCD's own L2 instead of the fabric.
+__device__ __forceinline__ bool tile_of_block(int Ny, int Nx, int& i0, int& j0, int& logical) {
+    const int nbx = (Nx + HT_X - 1) / HT_X, nby = (Ny + HT_Y - 1) / HT_Y, nb = nbx * nby;
+    const int per = (nb + 7) / 8;
+    logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    if ((int)(blockIdx.x / 8) >= per || logical >= nb) return false;
+    i0 = (logical / nbx) * HT_Y;
+    j0 = (logical % nbx) * HT_X;
+    return true;
+}
+
 template <typename T, int S, bool FINAL>
 __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
     __shared__ alignas(16) T tile[HT_LH][HT_LS];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
-    const int j0 = blockIdx.x * HT_X, i0 = blockIdx.y * HT_Y;
     const int Ny = A.Ny, Nx = A.Nx;
+    int i0, j0, logical;
+    if (!tile_of_block(Ny, Nx, i0, j0, logical)) return;
     const int gi = i0 + ry, gj = j0 + 4 * cx;
     const bool valid = gi < Ny && gj < Nx;             // Nx % 4 == 0: a vector is inside or outside as a whole
     const int64_t idx = (int64_t)gi * Nx + gj;
@@ -385,9 +399,8 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int b = blockIdx.y * gridDim.x + blockIdx.x;
-            A.partial[2 * b] = ls[0] + ls[1] + ls[2] + ls[3];
-            A.partial[2 * b + 1] = fmax(fmax(lm[0], lm[1]), fmax(lm[2], lm[3]));
+            A.partial[2 * logical] = ls[0] + ls[1] + ls[2] + ls[3];
+            A.partial[2 * logical + 1] = fmax(fmax(lm[0], lm[1]), fmax(lm[2], lm[3]));
         }
     }
 }
@@ -452,8 +465,9 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
     __shared__ alignas(16) T tile[2][HT_LH][HT_LS];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
-    const int j0 = blockIdx.x * HT_X, i0 = blockIdx.y * HT_Y;
     const int Ny = A.Ny, Nx = A.Nx;
+    int i0, j0, logical;
+    if (!tile_of_block(Ny, Nx, i0, j0, logical)) return;
     const int gi = i0 + ry, gj = j0 + 4 * cx;
     const bool valid = gi < Ny && gj < Nx;
     const int64_t idx = (int64_t)gi * Nx + gj;
@@ -561,6 +575,7 @@ struct Solver {
         ++nfev;
     }
     int fused_blocks() const { return ((Nx + HT_X - 1) / HT_X) * ((Ny + HT_Y - 1) / HT_Y); }
+    int fused_grid() const { return 8 * ((fused_blocks() + 7) / 8); }
     int reduce(double* sum, double* mx, int nblocks = 1024) {   // partials written by the preceding kernel
         hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, h->red_partial, nblocks, h->red_out);
         OC_HIP_CHECK(hipMemcpyAsync(h->red_host, h->red_out, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -573,8 +588,7 @@ struct Solver {
 
 template <typename T, int SG>
 void launch_stage(Solver<T>& S, StageArgs<T>& A) {
-    dim3 g((S.Nx + HT_X - 1) / HT_X, (S.Ny + HT_Y - 1) / HT_Y);
-    hipLaunchKernelGGL((k_stage<T, SG, false>), g, dim3(256), 0, S.s, A);
+    hipLaunchKernelGGL((k_stage<T, SG, false>), dim3(S.fused_grid()), dim3(256), 0, S.s, A);
 }
 
 // the six RHS evaluations of one RK attempt as six fused launches (stages 1..5 + y_new/K6/error)
@@ -613,8 +627,7 @@ void launch_stages_fused(Solver<T>& S, double hh, T atol_s, T rtol) {
     A.he6 = (T)(RK_E[6] * hh);
     A.out = S.K[6];
     A.ynew = S.ynew;
-    dim3 g((S.Nx + HT_X - 1) / HT_X, (S.Ny + HT_Y - 1) / HT_Y);
-    hipLaunchKernelGGL((k_stage<T, 5, true>), g, dim3(256), 0, S.s, A);
+    hipLaunchKernelGGL((k_stage<T, 5, true>), dim3(S.fused_grid()), dim3(256), 0, S.s, A);
 }
 
 // dense output of every t_eval point in (t_new, t] + direction field slices, <= OUT_MAXS slices per launch
@@ -663,9 +676,8 @@ int emit_slices_fused(Solver<T>& S, const std::vector<double>& te, int nt, int& 
         }
         if (ns == 0) continue;
         A.ns = ns;
-        dim3 g((S.Nx + HT_X - 1) / HT_X, (S.Ny + HT_Y - 1) / HT_Y);
         oc_timer_begin(S.h, "hjb_out", S.s);
-        hipLaunchKernelGGL(k_out<T>, g, dim3(256), 0, S.s, A);
+        hipLaunchKernelGGL(k_out<T>, dim3(S.fused_grid()), dim3(256), 0, S.s, A);
         // algorithmic bytes: read y_old + 6 stage arrays once, write 2 field components per slice
         oc_timer_end(S.h, "hjb_out", S.s, sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(c.Ny - 2) * (c.Nx - 2)));
         stats.n_slices_written += nv;
