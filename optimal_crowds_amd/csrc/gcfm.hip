@@ -41,7 +41,7 @@ struct GcfmParams {
     double cut_d2max;   // largest double d2 with sqrt(d2) < cutoff: `d2 <= cut_d2max` IS the reference's decision
     double cell;        // coarse cell size for ordering
     double drift;       // D: how far a tile box may grow beyond its sort-time box before the lists are invalid
-    int32_t ncx, ncy;
+    int32_t ncx, ncy, horder;
 };
 
 #define NB_MAX 63
@@ -51,7 +51,6 @@ struct GcfmParams {
 #define C_ACTIVE 2
 #define C_WCOUNT 4      // [4], [5]: wall work-list lengths (ping-pong)
 #define C_INVALID 6     // neighbour lists no longer cover the tile boxes -> full tile scan
-#define C_QUEUE 7       // next i-tile of k_pair's work queue (reset by k_finish / repack)
 
 struct Scratch {
     uint32_t *keys_a, *keys_b;
@@ -81,6 +80,26 @@ __device__ __forceinline__ double wmax(double v) {
 }
 
 // ---------------------------------------------------------------------------------- ordering
+// Hilbert-curve index of coarse cell (x, y) on a 2^order x 2^order grid: consecutive indices are adjacent cells, so
+// any 64 consecutive agents form a compact blob (a row-major order makes tiles that wrap a cell row span the room).
+__device__ __forceinline__ uint32_t hilbert_index(uint32_t x, uint32_t y, int order) {
+    uint32_t d = 0;
+    for (uint32_t s = 1u << (order - 1); s > 0; s >>= 1) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0) {                       // rotate the quadrant
+            if (rx == 1) {
+                x = s - 1 - x;
+                y = s - 1 - y;
+            }
+            const uint32_t t = x;
+            x = y;
+            y = t;
+        }
+    }
+    return d;
+}
+
 __global__ void k_cell_keys(const double* __restrict__ x, const double* __restrict__ y,
                             const uint8_t* __restrict__ status, int N, GcfmParams P, uint32_t* __restrict__ keys,
                             int32_t* __restrict__ vals) {
@@ -91,7 +110,7 @@ __global__ void k_cell_keys(const double* __restrict__ x, const double* __restri
         double fx = x[i] / P.cell, fy = y[i] / P.cell;
         int cx = (fx > 0) ? (fx < P.ncx - 1 ? (int)fx : P.ncx - 1) : 0;
         int cy = (fy > 0) ? (fy < P.ncy - 1 ? (int)fy : P.ncy - 1) : 0;
-        key = (uint32_t)(cy * P.ncx + cx);
+        key = hilbert_index((uint32_t)cx, (uint32_t)cy, P.horder);
     }
     keys[i] = key;
     vals[i] = i;
@@ -317,9 +336,9 @@ __global__ void __launch_bounds__(64) k_tile_lists(GcfmParams P, Scratch S) {
 
 // force of j on i (pedestrians.py:242-280) in trig-free form: cos(alpha-beta) = e.h, sin = h x e.
 // float32 with hardware rcp/rsq/exp2 (1 ulp); R is the float64-differenced relative vector rounded to float32.
-__device__ __forceinline__ void pair_term(float Rx, float Ry, float vxi, float vyi, float si, float hxi, float hyi,
-                                          float ia2_i, float ib2_i, float inv_vdes_i, float4 vj, float2 hj,
-                                          float b_max, float db, float neg_inv_eta_log2e, double& fx, double& fy) {
+__device__ __forceinline__ float2 pair_term(float Rx, float Ry, float vxi, float vyi, float si, float hxi, float hyi,
+                                            float ia2_i, float ib2_i, float inv_vdes_i, float4 vj, float2 hj,
+                                            float b_max, float db, float neg_inv_eta_log2e) {
     float r2 = __builtin_fmaf(Rx, Rx, Ry * Ry);
     float inv_r = __builtin_amdgcn_rsqf(r2);
     float r = r2 * inv_r;
@@ -337,132 +356,219 @@ __device__ __forceinline__ void pair_term(float Rx, float Ry, float vxi, float v
     float q_j = __builtin_amdgcn_rsqf(__builtin_fmaf(cj * cj, vj.w, sn_j * sn_j * ib2_j));
     float dist = r - q_i - q_j;
     float rep = fminf(k * __builtin_amdgcn_exp2f(dist * neg_inv_eta_log2e * __builtin_amdgcn_rcpf(1.f + vrel)), 1.f);
-    fx += (double)(-rep * Rx);
-    fy += (double)(-rep * Ry);
+    return make_float2(-rep * Rx, -rep * Ry);
 }
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+#define PAIR_LIST_CAP 4096      // 64 x 64: every (i, j) of a tile pair can be a candidate
+
+struct JRec {                   // one lane's share of a staged j-tile (prefetched into registers)
+    double2 pos;
+    float4 vel;
+    float2 head;
+};
+
+// One WAVEFRONT per i-tile (4 independent wavefronts per block, no block-level synchronisation).  Per j-tile:
+//   stage    the tile's 64 packed records go to wave-private LDS; the next tile's records are already being loaded
+//            (register prefetch, double-buffered LDS) while this one is processed;
+//   phase 1  per lane (= agent i) a 64-bit candidate mask from a conservative float32 distance test on box-relative
+//            coordinates: packed float2 math, sign bits collected with v_alignbit (3 VALU per j);
+//   compact  candidates are appended to a wave-private LDS list in rank-major order (all lanes' 1st candidate, then
+//            all 2nd ones, ...) with ballot/mbcnt -- no shuffles, and 64 consecutive entries name distinct agents;
+//   phase 2  the list is processed 64 pairs at a time with every lane busy: exact float64 cutoff decision, float32
+//            force, float64 LDS atomic accumulation per agent (at most 2 lanes per address).
 __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const double* __restrict__ v_des, int nxt,
                                               int32_t* __restrict__ cnt_out) {
-    __shared__ double2 l_pos[4][64];
-    __shared__ float4 l_vel[4][64];
-    __shared__ float2 l_head[4][64];
-    __shared__ alignas(16) float l_rx[4][64];
-    __shared__ alignas(16) float l_ry[4][64];
-    __shared__ double2 l_red[4][64];
+    __shared__ double2 li_pos[4][64];
+    __shared__ float4 li_vel[4][64];
+    __shared__ float4 li_aux[4][64];              // (hx, hy, 1/b_i^2, 1/v_des_i)
+    __shared__ double2 l_pos[4][2][64];
+    __shared__ float4 l_vel[4][2][64];
+    __shared__ float2 l_head[4][2][64];
+    __shared__ alignas(16) float l_rx[4][2][64];
+    __shared__ alignas(16) float l_ry[4][2][64];
+    __shared__ unsigned short l_list[4][PAIR_LIST_CAP];
+    __shared__ double l_accx[4][64], l_accy[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __shared__ int l_it;
     if (blockIdx.x == 0 && threadIdx.x == 0) {      // this step's counters (k_finish adds to them later in the stream)
         cnt_out[0] = cnt_out[1] = cnt_out[2] = cnt_out[3] = 0;
         S.ctrl[C_WCOUNT + nxt] = 0;
     }
-    // i-tiles are pulled from a queue: a tile costs 20-50 us and there are only a few per resident block, so a
-    // static assignment would quantise badly.  Every block leaves as soon as the queue is empty.
-  for (;;) {
-    __syncthreads();
-    if (threadIdx.x == 0) l_it = atomicAdd(&S.ctrl[C_QUEUE], 1);
-    __syncthreads();
-    const int it = l_it;
-    if (it >= S.ntiles) break;
+    const int it = blockIdx.x * 4 + w;
+    if (it >= S.ntiles) return;                     // wavefronts are independent: no barrier below
+    const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
+    const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
+    const double c = P.cutoff, c2 = c * c;
     const int k = it * 64 + lane;
     const int i = S.pidx[k];
     const double2 pi = S.ppos[k];
-    const float4 vi = S.pvel[k];
-    const float2 hi = S.phead[k];
-    float inv_vdes = 0.f, ib2_i = 0.f;
-    const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
-    const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
-    if (i >= 0) {
-        double vd = v_des[i];
-        inv_vdes = (float)(1.0 / vd);
-        double b = P.b_max - (P.b_max - P.b_min) * fmin((double)vi.z / vd, 1.0);
-        ib2_i = (float)(1.0 / (b * b));
+    {                                               // the i-tile in LDS: in phase 2 any lane works on any agent
+        const float4 vi = S.pvel[k];
+        const float2 hi = S.phead[k];
+        float inv_vdes = 0.f, ib2_i = 0.f;
+        if (i >= 0) {
+            double vd = v_des[i];
+            inv_vdes = (float)(1.0 / vd);
+            double b = P.b_max - (P.b_max - P.b_min) * fmin((double)vi.z / vd, 1.0);
+            ib2_i = (float)(1.0 / (b * b));
+        }
+        li_pos[w][lane] = pi;
+        li_vel[w][lane] = vi;
+        li_aux[w][lane] = make_float4(hi.x, hi.y, ib2_i, inv_vdes);
+        l_accx[w][lane] = 0.0;
+        l_accy[w][lane] = 0.0;
     }
     const double4 bi = S.tile_box[it];
-    const double c = P.cutoff;
-    const double c2 = c * c;
-    const double ox = bi.x, oy = bi.y;                 // origin of the box-relative float32 coordinates
+    const double ox = bi.x, oy = bi.y;             // origin of the box-relative float32 coordinates
     const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
-    double fx = 0.0, fy = 0.0;
+    const f2v xi2 = {xi_f, xi_f}, yi2 = {yi_f, yi_f};
+    unsigned short* lst = l_list[w];
 
     // candidate tiles: the neighbour list (if valid) or every tile, filtered by the live boxes
     const int32_t* nb = S.nb_list + (size_t)it * (NB_MAX + 1);
     const int nb_cnt = nb[0];
     const bool use_list = (nb_cnt >= 0) && (S.ctrl[C_INVALID] == 0);
     const int nchunk = use_list ? 1 : (S.ntiles + 63) / 64;
-    int ord = 0;
-
-    auto process = [&](int jt) {
-        // ---- stage tile jt in this wavefront's LDS area (LDS ops of one wavefront complete in order)
-        __builtin_amdgcn_wave_barrier();
-        const double2 pj_own = S.ppos[jt * 64 + lane];
-        l_pos[w][lane] = pj_own;
-        l_rx[w][lane] = (float)(pj_own.x - ox);
-        l_ry[w][lane] = (float)(pj_own.y - oy);
-        l_vel[w][lane] = S.pvel[jt * 64 + lane];
-        l_head[w][lane] = S.phead[jt * 64 + lane];
-        // conservative float32 bound: rounding of the relative coordinates scales with the boxes' extent
-        const double4 bj = S.tile_box[jt];
-        const float ext = (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
-                                  fmax(fmax(bi.w, bj.w) - oy, oy - fmin(bi.y, bj.y)));
-        const float c2f = (float)c2 * 1.00001f + 1e-6f * ext * (ext + (float)c);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- phase 1: 64 candidate bits of this lane's agent (broadcast float4 LDS reads)
-        uint32_t mw[2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            uint32_t acc = 0u;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const float4 xs = *reinterpret_cast<const float4*>(&l_rx[w][32 * half + 4 * g]);
-                const float4 ys = *reinterpret_cast<const float4*>(&l_ry[w][32 * half + 4 * g]);
-                const float dx0 = xs.x - xi_f, dx1 = xs.y - xi_f, dx2 = xs.z - xi_f, dx3 = xs.w - xi_f;
-                const float dy0 = ys.x - yi_f, dy1 = ys.y - yi_f, dy2 = ys.z - yi_f, dy3 = ys.w - yi_f;
-                const float e0 = __builtin_fmaf(dx0, dx0, dy0 * dy0), e1 = __builtin_fmaf(dx1, dx1, dy1 * dy1);
-                const float e2 = __builtin_fmaf(dx2, dx2, dy2 * dy2), e3 = __builtin_fmaf(dx3, dx3, dy3 * dy3);
-                acc |= ((e0 < c2f ? 1u : 0u) | (e1 < c2f ? 2u : 0u) | (e2 < c2f ? 4u : 0u) | (e3 < c2f ? 8u : 0u))
-                       << (4 * g);
-            }
-            mw[half] = acc;
-        }
-        unsigned long long m = (unsigned long long)mw[0] | ((unsigned long long)mw[1] << 32);
-        if (jt == it) m &= ~(1ull << lane);        // j != i
-        if (i < 0) m = 0ull;
-        // ---- phase 2: this lane's candidates
-        while (m) {
-            const int jj = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const double2 pj = l_pos[w][jj];
-            const double ddx = pj.x - pi.x, ddy = pj.y - pi.y;
-            const double d2 = ddx * ddx + ddy * ddy;
-            // the reference's decision sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291), as d2 <= d2max
-            if (d2 <= P.cut_d2max)
-                pair_term((float)ddx, (float)ddy, vi.x, vi.y, vi.z, hi.x, hi.y, vi.w, ib2_i, inv_vdes, l_vel[w][jj],
-                          l_head[w][jj], b_max, db, neg_inv_eta_log2e, fx, fy);
-        }
-    };
-
+    int buf = 0;
     for (int ch = 0; ch < nchunk; ++ch) {
         int t;
         if (use_list) t = (lane < nb_cnt) ? nb[1 + lane] : -1;
         else t = (ch * 64 + lane < S.ntiles) ? ch * 64 + lane : -1;
-        bool hit = (t >= 0) && box_hit(bi, S.tile_box[t], c);
+        const bool hit = (t >= 0) && box_hit(bi, S.tile_box[t], c);
         unsigned long long tmask = __ballot(hit);
-        while (tmask) {
-            int b = __ffsll((long long)tmask) - 1;
-            tmask &= tmask - 1;
-            if (((ord++) & 3) != w) continue;           // this hit belongs to another wavefront of the block
-            process(__builtin_amdgcn_readlane(t, b));
+        if (!tmask) continue;
+        // prefetch the first hit of this chunk
+        int jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
+        tmask &= tmask - 1;
+        JRec cur;
+        cur.pos = S.ppos[jt * 64 + lane];
+        cur.vel = S.pvel[jt * 64 + lane];
+        cur.head = S.phead[jt * 64 + lane];
+        double4 bj = S.tile_box[jt];
+        for (;;) {
+            // ---- stage tile jt (registers -> wave-private LDS; LDS ops of one wavefront complete in order)
+            l_pos[w][buf][lane] = cur.pos;
+            l_rx[w][buf][lane] = (float)(cur.pos.x - ox);
+            l_ry[w][buf][lane] = (float)(cur.pos.y - oy);
+            l_vel[w][buf][lane] = cur.vel;
+            l_head[w][buf][lane] = cur.head;
+            // conservative float32 bound: rounding of the relative coordinates scales with the boxes' extent
+            const float ext = (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
+                                      fmax(fmax(bi.w, bj.w) - oy, oy - fmin(bi.y, bj.y)));
+            const float c2f = (float)c2 * 1.00001f + 1e-6f * ext * (ext + (float)c);
+            const f2v nc2 = {-c2f, -c2f};
+            const int jt_now = jt;
+            // ---- start loading the next hit while this tile is processed
+            const bool more = tmask != 0ull;
+            if (more) {
+                jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
+                tmask &= tmask - 1;
+                cur.pos = S.ppos[jt * 64 + lane];
+                cur.vel = S.pvel[jt * 64 + lane];
+                cur.head = S.phead[jt * 64 + lane];
+                bj = S.tile_box[jt];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- phase 1: sign(d^2 - c2f) of j = 0..63; j = 32*half + q sits at bit 31 - q of word `half`
+            uint32_t mw[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint32_t acc = 0u;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float4 xs = *reinterpret_cast<const float4*>(&l_rx[w][buf][32 * half + 4 * g]);
+                    const float4 ys = *reinterpret_cast<const float4*>(&l_ry[w][buf][32 * half + 4 * g]);
+                    const f2v xa = {xs.x, xs.y}, xb = {xs.z, xs.w}, ya = {ys.x, ys.y}, yb = {ys.z, ys.w};
+                    const f2v dxa = xa - xi2, dxb = xb - xi2, dya = ya - yi2, dyb = yb - yi2;
+                    const f2v ta = __builtin_elementwise_fma(dxa, dxa, __builtin_elementwise_fma(dya, dya, nc2));
+                    const f2v tb = __builtin_elementwise_fma(dxb, dxb, __builtin_elementwise_fma(dyb, dyb, nc2));
+                    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(ta.x), 31);
+                    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(ta.y), 31);
+                    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(tb.x), 31);
+                    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(tb.y), 31);
+                }
+                mw[half] = acc;
+            }
+            if (jt_now == it) mw[lane >> 5] &= ~(0x80000000u >> (lane & 31));        // j != i
+            if (i < 0) mw[0] = mw[1] = 0u;
+            // ---- compact, lane-major: exclusive prefix sum of the lanes' candidate counts, every lane appends its own
+            const int cntl = __popc(mw[0]) + __popc(mw[1]);
+            int incl = cntl;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            {
+                int off = incl - cntl;
+                uint32_t m0 = mw[0], m1 = mw[1];
+                while (m0) {
+                    const int q = __clz((int)m0);
+                    m0 &= ~(0x80000000u >> q);
+                    lst[off++] = (unsigned short)((lane << 8) | q);
+                }
+                while (m1) {
+                    const int q = __clz((int)m1);
+                    m1 &= ~(0x80000000u >> q);
+                    lst[off++] = (unsigned short)((lane << 8) | (32 + q));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- phase 2: every lane takes a contiguous chunk of R = ceil(total/64) list entries.  The list is sorted
+            // by agent, so a chunk touches 1-3 agents: their data stays in registers and the forces are summed in
+            // registers; LDS is updated (float64 atomic) only when the agent changes.
+            const int R = (total + 63) >> 6;
+            int e_beg = lane * R, e_end = min(e_beg + R, total);
+            int il_cur = -1;
+            double2 pa = make_double2(0.0, 0.0);
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), aux = va;
+            float sfx = 0.f, sfy = 0.f;
+            for (int r = 0; r < R; ++r) {
+                const int tt = e_beg + r;
+                if (tt < e_end) {
+                    const unsigned e = lst[tt];
+                    const int il = e >> 8, jj = e & 63;
+                    if (il != il_cur) {
+                        if (il_cur >= 0) {
+                            atomicAdd(&l_accx[w][il_cur], (double)sfx);
+                            atomicAdd(&l_accy[w][il_cur], (double)sfy);
+                        }
+                        il_cur = il;
+                        sfx = sfy = 0.f;
+                        pa = li_pos[w][il];
+                        va = li_vel[w][il];
+                        aux = li_aux[w][il];
+                    }
+                    const double2 pb = l_pos[w][buf][jj];
+                    const double ddx = pb.x - pa.x, ddy = pb.y - pa.y;
+                    const double d2 = ddx * ddx + ddy * ddy;
+                    // the reference's decision sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291)
+                    if (d2 <= P.cut_d2max) {
+                        const float2 f = pair_term((float)ddx, (float)ddy, va.x, va.y, va.z, aux.x, aux.y, va.w, aux.z,
+                                                   aux.w, l_vel[w][buf][jj], l_head[w][buf][jj], b_max, db,
+                                                   neg_inv_eta_log2e);
+                        sfx += f.x;
+                        sfy += f.y;
+                    }
+                }
+            }
+            if (il_cur >= 0) {
+                atomicAdd(&l_accx[w][il_cur], (double)sfx);
+                atomicAdd(&l_accy[w][il_cur], (double)sfy);
+            }
+            buf ^= 1;
+            if (!more) break;
         }
     }
-    l_red[w][lane] = make_double2(fx, fy);
-    __syncthreads();
-    if (w == 0) {
-        double2 a0 = l_red[0][lane], a1 = l_red[1][lane], a2 = l_red[2][lane], a3 = l_red[3][lane];
-        S.f_pair[k] = make_double2((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
-    }
-  }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    S.f_pair[k] = make_double2(l_accx[w][lane], l_accy[w][lane]);
 }
 
 // ---------------------------------------------------------------------------------- wall search over the work-list
@@ -729,7 +835,6 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const Ke
         S.widx[k] = -1;
     }
     const bool stay = act && !out;
-    if (blockIdx.x == 0 && threadIdx.x == 0) S.ctrl[C_QUEUE] = 0;      // k_pair's queue for the next step
     // counters: one atomic per wavefront (100k same-address atomics cost > 1 ms)
     unsigned long long m_out = __ballot(out), m_in = __ballot(stay);
     const int lane = threadIdx.x;
@@ -811,9 +916,16 @@ GcfmParams make_params(const oc_handle* h) {
     P.a_min = c.a_min; P.tau_a = c.tau_a; P.b_min = c.b_min; P.b_max = c.b_max; P.eta = c.eta;
     P.eta_walls = c.eta_walls; P.cutoff = c.repulsion_cutoff; P.v_max = c.v_max; P.relaxation = c.relaxation;
     P.noise_amp = c.noise_amp; P.wall_radius = c.wall_search_radius;
-    P.cell = c.repulsion_cutoff > 0 ? c.repulsion_cutoff : 4.0;
+    P.cell = c.repulsion_cutoff > 0 ? 0.5 * c.repulsion_cutoff : 2.0;
     P.ncx = (int)(c.room_length / P.cell) + 1;
     P.ncy = (int)(c.room_height / P.cell) + 1;
+    while (P.ncx > 16384 || P.ncy > 16384) {        // keep the curve index inside the 30 sorted key bits
+        P.cell *= 2.0;
+        P.ncx = (int)(c.room_length / P.cell) + 1;
+        P.ncy = (int)(c.room_height / P.cell) + 1;
+    }
+    P.horder = 1;
+    while ((1 << P.horder) < std::max(P.ncx, P.ncy)) ++P.horder;
     P.drift = 1.5 * c.v_max * c.dt * h->resort_every + 0.1;
     {   // sqrt is correctly rounded and monotone: walk down from c^2 to the first d2 whose root is below the cutoff
         double t = P.cutoff * P.cutoff;
@@ -1037,8 +1149,7 @@ extern "C" int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out
     if ((rc = prepare(h, a, &S, &P, s))) return rc;
     h->packed_valid = false;
     oc_timer_begin(h, "gcfm_pair", s);
-    hipLaunchKernelGGL(k_pair, dim3(std::min(S.ntiles, h->pair_grid)), dim3(256), 0, s, P, S, a->v_des, 1 - h->wl_parity, S.ctrl);
-    OC_HIP_CHECK(hipMemsetAsync(S.ctrl + C_QUEUE, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, a->v_des, 1 - h->wl_parity, S.ctrl);
     oc_timer_end(h, "gcfm_pair", s);
     OC_HIP_CHECK(hipMemsetAsync(force_out, 0, sizeof(double) * 2 * (size_t)a->N, s));
     hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_pair, S.pidx, S.Np,
@@ -1065,12 +1176,20 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     const KeyDev* kd = (const KeyDev*)h->key_tables_dev;
     const int cur = h->wl_parity, nxt = 1 - cur;
     int32_t* cnt = counters ? counters : S.ctrl;
+    // k_wall only needs the previous step's results, so it runs beside k_pair on the handle's auxiliary stream
+    hipStream_t sw = h->aux_stream ? h->aux_stream : s;
+    if (sw != s) {
+        OC_HIP_CHECK(hipEventRecord(h->ev_fork, s));
+        OC_HIP_CHECK(hipStreamWaitEvent(sw, h->ev_fork, 0));
+    }
+    oc_timer_begin(h, "gcfm_wall", sw);
+    hipLaunchKernelGGL(k_wall, dim3(S.ntiles * WG), dim3(64), 0, sw, P, S, kd, a->key, h->X0, h->Y0, cur);
+    oc_timer_end(h, "gcfm_wall", sw);
+    if (sw != s) OC_HIP_CHECK(hipEventRecord(h->ev_join, sw));
     oc_timer_begin(h, "gcfm_pair", s);
-    hipLaunchKernelGGL(k_pair, dim3(std::min(S.ntiles, h->pair_grid)), dim3(256), 0, s, P, S, a->v_des, nxt, cnt);
+    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, a->v_des, nxt, cnt);
     oc_timer_end(h, "gcfm_pair", s);
-    oc_timer_begin(h, "gcfm_wall", s);
-    hipLaunchKernelGGL(k_wall, dim3(S.ntiles * WG), dim3(64), 0, s, P, S, kd, a->key, h->X0, h->Y0, cur);
-    oc_timer_end(h, "gcfm_wall", s);
+    if (sw != s) OC_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
     oc_timer_begin(h, "gcfm_finish", s);
     hipLaunchKernelGGL(k_finish, dim3(S.ntiles), dim3(64), 0, s, P, S, kd, a->key, a->x, a->y, a->vx, a->vy, a->v_des,
                        a->status, a->agent_time, noise, seed, simu_step, h->X0, h->Y0, nxt, cnt);

@@ -45,6 +45,9 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
     OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * 2 * h->red_blocks));
     OC_HIP_CHECK(hipMalloc(&h->red_out, sizeof(double) * 16));
     OC_HIP_CHECK(hipHostMalloc(&h->red_host, sizeof(double) * 16));
+    OC_HIP_CHECK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    OC_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    OC_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     *out = h;
     return OC_OK;
 }
@@ -66,6 +69,9 @@ extern "C" int oc_destroy(oc_handle* h) {
     (void)hipFree(h->key_tables_dev);
     (void)hipFree(h->gcfm_buf);
     (void)hipFree(h->sort_tmp);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (auto& kv : h->timers)
         for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
     delete h;

@@ -84,7 +84,9 @@ struct oc_handle {
     bool packed_valid = false;  // the packed snapshot matches the caller's state arrays
     const void* packed_x = nullptr;
     int32_t packed_N = -1;
-    int pair_grid = 2048;       // k_pair blocks (8 per CU x 256 CUs at most resident); tiles are pulled from a queue
+    int pair_grid = 1024;       // k_pair blocks (8 per CU x 256 CUs at most resident); tiles are pulled from a queue
+    hipStream_t aux_stream = nullptr;   // k_wall runs here, beside k_pair
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int wl_parity = 0;          // which wall work-list the next step consumes
     void* gcfm_buf = nullptr;   // carved in gcfm.hip
     size_t gcfm_bytes = 0;
