@@ -258,6 +258,13 @@ template <typename T>
 __device__ __forceinline__ void st4(T* p, const V4<T>& x) { *reinterpret_cast<V4<T>*>(p) = x; }
 
 template <typename T>
+__device__ __forceinline__ void st4_nt(T* p, const V4<T>& x) {      // streaming store: the field is written once
+    typedef T vt __attribute__((ext_vector_type(4)));
+    vt v = {x.v[0], x.v[1], x.v[2], x.v[3]};
+    __builtin_nontemporal_store(v, reinterpret_cast<vt*>(p));
+}
+
+template <typename T>
 struct StageArgs {
     const T* y;
     const T* k[6];
@@ -532,8 +539,8 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
                 ox.v[q] = border ? (T)0 : vxo;
                 oy.v[q] = border ? (T)0 : vyo;
             }
-            st4(A.vx[s] + idx, ox);
-            st4(A.vy[s] + idx, oy);
+            st4_nt(A.vx[s] + idx, ox);
+            st4_nt(A.vy[s] + idx, oy);
         }
     }
 }
