@@ -147,7 +147,8 @@ int oc_density(oc_handle* h, int dtype, const oc_agents* a, double sigma, const 
  * oc_kernel_stats returns, since the last reset: number of launches, summed event time (ms) and summed
  * ALGORITHMIC bytes (DESIGN.md section "Rooflines").  Classes: "hjb_stage" (one RK attempt = 6 fused stage
  * launches), "hjb_out" (dense output + direction-field writer), "gcfm_pair", "gcfm_wall".  Synchronises. */
-int oc_set_profiling(oc_handle* h, int enabled);
+/* mode bits: 1 = HJB kernels, 2 = GCFM kernels every step, 4 = GCFM kernels every 16th step; 0 = off */
+int oc_set_profiling(oc_handle* h, int mode);
 int oc_kernel_stats(oc_handle* h, const char* name, int64_t* launches, double* total_ms, double* total_bytes);
 int oc_reset_kernel_stats(oc_handle* h);
 /* 0 = fused HJB kernels (default), 1 = simple one-array-pass kernels (cross-check). */

@@ -377,8 +377,8 @@ struct JRec {                   // one lane's share of a staged j-tile (prefetch
 //            all 2nd ones, ...) with ballot/mbcnt -- no shuffles, and 64 consecutive entries name distinct agents;
 //   phase 2  the list is processed 64 pairs at a time with every lane busy: exact float64 cutoff decision, float32
 //            force, float64 LDS atomic accumulation per agent (at most 2 lanes per address).
-__global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const double* __restrict__ v_des, int nxt,
-                                              int32_t* __restrict__ cnt_out) {
+__device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S, const double* __restrict__ v_des,
+                                          int it, int w, int lane) {
     __shared__ double2 li_pos[4][64];
     __shared__ float4 li_vel[4][64];
     __shared__ float4 li_aux[4][64];              // (hx, hy, 1/b_i^2, 1/v_des_i)
@@ -389,13 +389,7 @@ __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const dou
     __shared__ alignas(16) float l_ry[4][2][64];
     __shared__ unsigned short l_list[4][PAIR_LIST_CAP];
     __shared__ double l_accx[4][64], l_accy[4][64];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {      // this step's counters (k_finish adds to them later in the stream)
-        cnt_out[0] = cnt_out[1] = cnt_out[2] = cnt_out[3] = 0;
-        S.ctrl[C_WCOUNT + nxt] = 0;
-    }
-    const int it = blockIdx.x * 4 + w;
-    if (it >= S.ntiles) return;                     // wavefronts are independent: no barrier below
+    if (it >= S.ntiles) return;                     // wavefronts are independent: no barrier anywhere
     const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
     const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
     const double c = P.cutoff, c2 = c * c;
@@ -576,11 +570,9 @@ __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const dou
 // downwards, then the group min-reduces (objective, flat index) so every lane prunes with the group's best.  The
 // serial row chain of the one-lane version (latency-bound, up to ~60 dependent rounds) becomes ~8x shorter.
 #define WG 8
-__global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
-                                             const int32_t* __restrict__ key_of, const double* __restrict__ X0,
-                                             const double* __restrict__ Y0, int cur) {
-    const int t = (blockIdx.x * 64 + threadIdx.x) / WG, sub = threadIdx.x & (WG - 1);
-    const int count = S.ctrl[C_WCOUNT + cur];
+__device__ __forceinline__ void wall_group(const GcfmParams& P, const Scratch& S, const KeyDev* __restrict__ keys,
+                                           const int32_t* __restrict__ key_of, const double* __restrict__ X0,
+                                           const double* __restrict__ Y0, int cur, int t, int sub, int count) {
     const bool live = t < count;
     const int k = live ? S.wall_list[cur][t] : 0;
     const int i = live ? S.pidx[k] : -1;
@@ -658,6 +650,43 @@ __global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyD
         }
     }
     if (i >= 0 && sub == 0) S.widx[k] = best_flat;
+}
+
+// standalone wall search (diagnostic exports)
+__global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
+                                             const int32_t* __restrict__ key_of, const double* __restrict__ X0,
+                                             const double* __restrict__ Y0, int cur) {
+    wall_group(P, S, keys, key_of, X0, Y0, cur, (blockIdx.x * 64 + threadIdx.x) / WG, threadIdx.x & (WG - 1),
+               S.ctrl[C_WCOUNT + cur]);
+}
+
+// standalone pair forces (diagnostic exports): 4 independent wavefronts per block
+__global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const double* __restrict__ v_des) {
+    pair_wave(P, S, v_des, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x >> 6, threadIdx.x & 63);
+}
+
+// The step's force kernel: horizontal fusion of the pair forces and the wall search.  A 512-thread block carries
+// 4 pair wavefronts (one i-tile each, LDS) and 4 wall-search wavefronts (no LDS) that sweep the wall work-list; the
+// two kinds never synchronise, so the short wall search hides entirely beside the pair work without a second
+// stream (cross-stream event waits cost ~15 us per dependency on this platform).
+__global__ void __launch_bounds__(512, 4) k_forces(GcfmParams P, Scratch S, const double* __restrict__ v_des,
+                                                const KeyDev* __restrict__ keys, const int32_t* __restrict__ key_of,
+                                                const double* __restrict__ X0, const double* __restrict__ Y0, int cur,
+                                                int nxt, int32_t* __restrict__ cnt_out) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // this step's counters (k_finish adds to them later in the stream)
+        cnt_out[0] = cnt_out[1] = cnt_out[2] = cnt_out[3] = 0;
+        S.ctrl[C_WCOUNT + nxt] = 0;
+    }
+    if (w < 4) {
+        pair_wave(P, S, v_des, blockIdx.x * 4 + w, w, lane);
+    } else {
+        const int count = S.ctrl[C_WCOUNT + cur];
+        const int per_wave = 64 / WG;                               // agents per wavefront and round
+        const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + (w - 4);
+        for (int base = gw * per_wave; base < count; base += nwaves * per_wave)
+            wall_group(P, S, keys, key_of, X0, Y0, cur, base + lane / WG, lane & (WG - 1), count);
+    }
 }
 
 // capped exact distance transform of the site set on the grid nodes (init-time, one thread per node)
@@ -1149,7 +1178,7 @@ extern "C" int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out
     if ((rc = prepare(h, a, &S, &P, s))) return rc;
     h->packed_valid = false;
     oc_timer_begin(h, "gcfm_pair", s);
-    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, a->v_des, 1 - h->wl_parity, S.ctrl);
+    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, a->v_des);
     oc_timer_end(h, "gcfm_pair", s);
     OC_HIP_CHECK(hipMemsetAsync(force_out, 0, sizeof(double) * 2 * (size_t)a->N, s));
     hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_pair, S.pidx, S.Np,
@@ -1176,20 +1205,10 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     const KeyDev* kd = (const KeyDev*)h->key_tables_dev;
     const int cur = h->wl_parity, nxt = 1 - cur;
     int32_t* cnt = counters ? counters : S.ctrl;
-    // k_wall only needs the previous step's results, so it runs beside k_pair on the handle's auxiliary stream
-    hipStream_t sw = h->aux_stream ? h->aux_stream : s;
-    if (sw != s) {
-        OC_HIP_CHECK(hipEventRecord(h->ev_fork, s));
-        OC_HIP_CHECK(hipStreamWaitEvent(sw, h->ev_fork, 0));
-    }
-    oc_timer_begin(h, "gcfm_wall", sw);
-    hipLaunchKernelGGL(k_wall, dim3(S.ntiles * WG), dim3(64), 0, sw, P, S, kd, a->key, h->X0, h->Y0, cur);
-    oc_timer_end(h, "gcfm_wall", sw);
-    if (sw != s) OC_HIP_CHECK(hipEventRecord(h->ev_join, sw));
     oc_timer_begin(h, "gcfm_pair", s);
-    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, a->v_des, nxt, cnt);
+    hipLaunchKernelGGL(k_forces, dim3((S.ntiles + 3) / 4), dim3(512), 0, s, P, S, a->v_des, kd, a->key, h->X0, h->Y0, cur,
+                       nxt, cnt);
     oc_timer_end(h, "gcfm_pair", s);
-    if (sw != s) OC_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
     oc_timer_begin(h, "gcfm_finish", s);
     hipLaunchKernelGGL(k_finish, dim3(S.ntiles), dim3(64), 0, s, P, S, kd, a->key, a->x, a->y, a->vx, a->vy, a->v_des,
                        a->status, a->agent_time, noise, seed, simu_step, h->X0, h->Y0, nxt, cnt);
@@ -1198,5 +1217,6 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     h->wl_parity = nxt;
     h->packed_valid = true;
     ++h->steps_since_sort;
+    ++h->prof_tick;
     return OC_OK;
 }

@@ -94,6 +94,8 @@ struct oc_handle {
     size_t sort_tmp_bytes = 0;
     // ---- profiling
     bool profiling = false;
+    int prof_mode = 0;
+    int64_t prof_tick = 0;          // GCFM step counter for sampled timers
     int hjb_variant = 0;
     std::map<std::string, oc_timer> timers;
 };

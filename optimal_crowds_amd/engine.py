@@ -79,8 +79,9 @@ class Engine:
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def set_profiling(self, on=True):
-        check(self.lib.oc_set_profiling(self.h, int(on)))
+    def set_profiling(self, mode=3):
+        """mode bits: 1 HJB kernels, 2 GCFM kernels every step, 4 GCFM kernels every 16th step; 0/False off."""
+        check(self.lib.oc_set_profiling(self.h, int(mode)))
 
     def kernel_stats(self, name):
         """(launches, total_ms, total_algorithmic_bytes) of a kernel class since the last reset."""
