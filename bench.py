@@ -141,16 +141,19 @@ def main():
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
+    from optimal_crowds_amd import parallel
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # OC_BENCH_ONE_DEVICE=1 (rehearsal on a 1-GPU box): every rank uses cuda:0 and the timing reductions use gloo
+    one_dev = os.environ.get("OC_BENCH_ONE_DEVICE") == "1"
+    torch.cuda.set_device(0 if one_dev else local_rank)
+    rank, world = parallel.init_distributed("gloo" if one_dev else "nccl")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if one_dev else "cuda"
 
     import optimal_crowds_amd.engine  # noqa: F401  (fails loudly without the HIP library)
     t_init = time.perf_counter()
@@ -178,10 +181,7 @@ def main():
     run_steps(sim, K, nt, stats)
     barrier()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    elapsed = parallel.max_over_ranks(elapsed, device=red_dev)
 
     # ---- breakdown (untimed extras for the report)
     t_hjb = sum(s["seconds"] for rnd in stats for s in rnd)

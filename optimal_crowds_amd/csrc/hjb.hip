@@ -203,6 +203,35 @@ __global__ void k_dense(const T* __restrict__ yold, Lin8<T> W /* c_j = h * sum_p
     if (keep) keep[i] = (double)v * unscale;
 }
 
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double fast_rsq(double x) { return 1.0 / sqrt(x); }
+
+// Unit-or-zero direction of v = grad/(mu*phi_c) (optimals.py:179-186) without forming v: in float32 the ratio
+// overflows next to walls late in the solve (|grad| ~ 2^64 against phi_c = lim*2^-e), although its direction and
+// the decision |v| > lim are perfectly representable.  |v| > lim  <=>  m*nn > lim*mu*phi_c with m = max(|gx|,|gy|),
+// nn = |(gx,gy)/m| in [1, sqrt 2].  (|v| == lim, 0/0 in the reference, is treated as "not greater": zero.)
+template <typename T>
+__device__ __forceinline__ void direction_of(T gx, T gy, T mupc, T lim, T& ox, T& oy) {
+    const T m = fmax(fabs(gx), fabs(gy));
+    ox = (T)0;
+    oy = (T)0;
+    if (m > (T)0) {
+        const T im = fast_rcp(m);
+        const T ax = gx * im, ay = gy * im;
+        const T n2 = ax * ax + ay * ay;          // in [1, 2]
+        const T inn = fast_rsq(n2);
+        if (m * (n2 * inn) > lim * mupc) {
+            ox = ax * inn;
+            oy = ay * inn;
+        }
+    } else if (m != m) {                 // NaN input stays visible
+        ox = m;
+        oy = m;
+    }
+}
+
 // vels (optimals.py:168-186) on a phi carried as phi*scale: lim -> lim*scale; everything else is a ratio.
 template <typename TI, typename TO>
 __global__ void k_vels(const TI* __restrict__ phi, TO* __restrict__ vx, TO* __restrict__ vy, int Ny, int Nx,
@@ -218,20 +247,8 @@ __global__ void k_vels(const TI* __restrict__ phi, TO* __restrict__ vx, TO* __re
     TI pc = clip(phi[(int64_t)i * Nx + j]);
     TI gx = (pe - pw) * inv2dx;
     TI gy = (pn - ps) * inv2dy;
-    TI ux = gx / (mu * pc);
-    TI uy = gy / (mu * pc);
-    TI norm = sqrt(ux * ux + uy * uy);
     TI ox, oy;
-    if (norm > lim) {
-        ox = ux / norm;
-        oy = uy / norm;
-    } else if (norm < lim) {
-        ox = (TI)0;
-        oy = (TI)0;
-    } else {            // norm == lim (-> 0/0 in the reference) or NaN
-        ox = (TI)NAN;
-        oy = (TI)NAN;
-    }
+    direction_of<TI>(gx, gy, mu * pc, lim, ox, oy);
     int64_t o = (int64_t)i * Nx + j;                 // padded (Ny, Nx) slice
     vx[o] = (TO)ox;
     vy[o] = (TO)oy;
@@ -412,11 +429,6 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
     }
 }
 
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
-__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ double fast_rsq(double x) { return 1.0 / sqrt(x); }
-
 // Dense output + direction field for every t_eval point of one accepted step, in one pass: the quartic
 // interpolant's coefficients Q = K^T P (scipy rk.py:178-180) stay in registers, each slice's phi goes through a
 // double-buffered LDS tile, and vels (optimals.py:168-186) writes the slice of the (padded) direction field.
@@ -484,7 +496,6 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
     const int hn = (hr.kind == 1 || hr.kind == 2) ? 4 : (hr.kind >= 3 ? 1 : 0);
     if (hn) interp_coeffs(A, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
     auto clip = [&](T v) { return (v > A.lim_s) ? v : ((v < A.lim_s) ? A.lim_s : (T)0); };
-    const T lim2 = A.lim * A.lim;
     for (int s = 0; s < A.ns; ++s) {
         const int buf = s & 1;
         const T h1 = A.hx[s][0], h2 = A.hx[s][1], h3 = A.hx[s][2], h4 = A.hx[s][3];
@@ -520,21 +531,8 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
                 const T ps = clip(up.v[q]), pn = clip(dn.v[q]);
                 const T pc = clip(clip(ph.v[q]));
                 const T gx = (pe - pw) * A.inv2dx, gy = (pn - ps) * A.inv2dy;
-                const T rden = fast_rcp(A.mu * pc);
-                const T ux = gx * rden, uy = gy * rden;
-                const T n2 = ux * ux + uy * uy;
                 T vxo, vyo;
-                if (n2 > lim2) {                       // |v| > lim  ->  unit vector
-                    const T rn = fast_rsq(n2);
-                    vxo = ux * rn;
-                    vyo = uy * rn;
-                } else if (n2 < lim2) {
-                    vxo = (T)0;
-                    vyo = (T)0;
-                } else {                               // |v| == lim (0/0 in the reference) or NaN
-                    vxo = (T)NAN;
-                    vyo = (T)NAN;
-                }
+                direction_of<T>(gx, gy, A.mu * pc, A.lim, vxo, vyo);
                 const bool border = gi < 1 || gi >= Ny - 1 || gj + q < 1 || gj + q >= Nx - 1;
                 ox.v[q] = border ? (T)0 : vxo;
                 oy.v[q] = border ? (T)0 : vyo;

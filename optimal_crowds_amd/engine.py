@@ -92,6 +92,13 @@ class Engine:
     def reset_kernel_stats(self):
         check(self.lib.oc_reset_kernel_stats(self.h))
 
+    def set_resort_every(self, steps):
+        check(self.lib.oc_set_resort_every(self.h, int(steps)))
+
+    def agents_changed(self):
+        """Call after modifying the agent tensors in place between steps."""
+        check(self.lib.oc_agents_changed(self.h))
+
     def set_hjb_variant(self, variant):
         check(self.lib.oc_set_hjb_variant(self.h, int(variant)))
 
