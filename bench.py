@@ -131,6 +131,25 @@ def cpu_baseline(sim, cfg, n_attempt, budget_s=20.0):
             "t_hjb_solve_s": t_hjb, "t_step_s": t_step}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per k_out launch from the committed PMC summary (profiles/rNN_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command, gfx950 FETCH_SIZE x2 correction applied by
+    tools/collect_profiles.py).  Counters cannot be collected from inside the timed run, hence the file; None if
+    absent or for another workload."""
+    import glob
+    if workload != "metro_station":
+        return None
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
+    for f in reversed(files):
+        try:
+            v = json.load(open(f)).get("k_out_hbm_bytes_per_launch")
+            if v:
+                return v
+        except Exception:
+            pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,7 +220,8 @@ def main():
     if ko["launches"]:
         ach = ko["achieved_GBps"]
         roof = {"bound": "hbm", "kernel": "k_out (HJB dense output + direction-field writer)",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(args.workload), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes)",
                 "launches": ko["launches"], "avg_launch_ms": ko["avg_ms"],
                 "algorithmic_GB_per_launch": ko["algorithmic_GB_per_launch"]}
     result = {

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 outputs under gpurun_out/ into the tracked summaries under profiles/ (round tag as argv[1]).
+
+Expects (produced by the commands in profiles/README.md):
+  gpurun_out/<tag>_stats/   rocprofv3 --kernel-trace --stats of `python bench.py`
+  gpurun_out/<tag>_pmc_fetch/, <tag>_pmc_write/   separate --pmc FETCH_SIZE / WRITE_SIZE passes
+  gpurun_out/<tag>_bench.log  stdout of the profiled bench run;  gpurun_out/<tag>_bench_plain.log  un-profiled run
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(REPO, "gpurun_out")
+P = os.path.join(REPO, "profiles")
+os.makedirs(P, exist_ok=True)
+
+
+def short(name):
+    for k in ("k_out", "k_forces", "k_finish", "k_pack", "k_tile_lists", "k_cell_keys", "k_edt", "k_wallmap", "k_reduce_final",
+              "k_rhs", "k_lincomb", "k_scale", "k_fill", "k_make_coef", "k_norm_scaled", "k_density"):
+        if k + "<" in name or k + "(" in name:
+            return k
+    if "k_stage" in name:
+        a = name.index("k_stage<")
+        return name[a:name.index(">", a) + 1].replace("float, ", "").replace(" ", "")
+    return name[:48]
+
+
+st = sorted(glob.glob(os.path.join(G, tag + "_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
+if st:
+    shutil.copy(st[0], os.path.join(P, tag + "_bench_kernel_stats.csv"))
+for name in (tag + "_bench.log", tag + "_bench_plain.log"):
+    src = os.path.join(G, name)
+    if os.path.exists(src):
+        lines = [l for l in open(src) if l.startswith("{")]
+        if lines:
+            open(os.path.join(P, name.replace(".log", ".json")), "w").write(lines[-1])
+
+traffic = {}
+for d, cname in ((tag + "_pmc_fetch", "FETCH_SIZE"), (tag + "_pmc_write", "WRITE_SIZE")):
+    f = sorted(glob.glob(os.path.join(G, d, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == cname:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    traffic[cname] = {k: {"launches": len(v), "avg_KB_per_launch": sum(v) / len(v)} for k, v in sorted(agg.items())
+                      if k.startswith("k_")}
+if traffic:
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a
+    # wide (16 B/lane) coalesced read -> doubled; WRITE_SIZE is exact for 16 B/lane streaming stores.
+    ko_f = traffic.get("FETCH_SIZE", {}).get("k_out")
+    ko_w = traffic.get("WRITE_SIZE", {}).get("k_out")
+    if ko_f and ko_w:
+        traffic["k_out_hbm_bytes_per_launch"] = 2 * ko_f["avg_KB_per_launch"] * 1024 + ko_w["avg_KB_per_launch"] * 1024
+        traffic["note"] = ("k_out: 2 x FETCH_SIZE (gfx950 correction for 16 B/lane reads) + WRITE_SIZE, KB -> bytes, "
+                           "average over the launches of a --steps 20 run (separate --pmc passes)")
+    json.dump(traffic, open(os.path.join(P, tag + "_pmc_traffic.json"), "w"), indent=1)
+print("profiles:", sorted(os.listdir(P)))
