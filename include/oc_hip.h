@@ -90,6 +90,42 @@ int oc_hjb_solve(oc_handle* h, int dtype, const void* coef, double T, int32_t nt
                  double* t_steps, int32_t t_steps_cap,
                  oc_hjb_stats* stats, void* stream);
 
+/* ---- row-block (domain-decomposed) HJB solve: one rank of `world` ranks that split the grid rows ------------------
+ * The same solve as oc_hjb_solve (optimals.py:193-204) on rows [row0, row0 + Ny_local) of the grid.  The local arrays
+ * hold the rank's owned rows plus `halo` rows of each neighbour:
+ *     local rows [0, own_lo)  upper halo (has_up)   [own_lo, own_hi)  owned   [own_hi, Ny_local)  lower halo (has_dn)
+ * One RK step applies the 5-point stencil 6 times (5 stages + the FSAL derivative), so with y and K0 valid `halo`
+ * rows deep at the start of a step, K1..K5, y_new, K6 are valid halo-1 .. halo-6 rows deep: halo >= 6 keeps the owned
+ * rows exact, and the direction field is exact on the owned rows +- (halo - 6).  After every ACCEPTED step the rank
+ * sends its `halo` owned rows next to each neighbour of (y_new, K6) and receives the neighbour's: one message of
+ * 2*halo*Nx elements per neighbour and step (instead of one row per RHS evaluation).  The error norm of an attempt
+ * (scipy rk.py:146-147) is summed over owned rows and completed by an all-gather of (sum, max|y|) that every rank adds
+ * in rank order, so all ranks take identical step-size decisions.
+ * The library does the packing/unpacking and the controller; the two collectives are the caller's (host callbacks that
+ * enqueue on `stream`, e.g. torch.distributed over RCCL):
+ *   allgather_red(user): red_all[r][0..1] = rank r's red_local[0..1]
+ *   exchange_halo(user): send_up -> upper neighbour's recv_dn, send_dn -> lower neighbour's recv_up
+ * Buffers (device, caller-owned): send_up/recv_up/send_dn/recv_dn: dtype (2, halo, Nx); red_local: float64 (2);
+ * red_all: float64 (world, 2).  coef_rows / vx_out / vy_out / phi_keep cover the LOCAL rows: coef_rows (Ny_local, Nx),
+ * vx_out (nslice, Ny_local, Nx), phi_keep (n_keep, Ny_local, Nx).  Ny_global*Nx is the RMS norm's cell count. */
+#define OC_MAX_WORLD 64
+typedef struct oc_hjb_shard {
+    int32_t Ny_local, Ny_global;
+    int32_t own_lo, own_hi;
+    int32_t halo;
+    int32_t has_up, has_dn;
+    int32_t world;
+    void *send_up, *recv_up, *send_dn, *recv_dn;
+    double *red_local, *red_all;
+    int (*allgather_red)(void* user);
+    int (*exchange_halo)(void* user);
+    void* user;
+} oc_hjb_shard;
+int oc_hjb_solve_rows(oc_handle* h, int dtype, const void* coef_rows, double T, int32_t nt,
+                      void* vx_out, void* vy_out, const oc_hjb_shard* shard,
+                      const int32_t* keep_idx, int32_t n_keep, double* phi_keep,
+                      oc_hjb_stats* stats, void* stream);
+
 /* Direction field of one phi (float64 input (Ny,Nx), dtype output padded (Ny,Nx)): replaces `vels`, optimals.py:168-186. */
 int oc_hjb_vels(oc_handle* h, int dtype, const void* phi, double scale, void* vx, void* vy, void* stream);
 

@@ -42,6 +42,21 @@ class OcHjbStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+HALO_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)     # int (*)(void* user)
+
+
+class OcHjbShard(C.Structure):
+    _fields_ = [
+        ("Ny_local", C.c_int32), ("Ny_global", C.c_int32),
+        ("own_lo", C.c_int32), ("own_hi", C.c_int32),
+        ("halo", C.c_int32), ("has_up", C.c_int32), ("has_dn", C.c_int32), ("world", C.c_int32),
+        ("send_up", C.c_void_p), ("recv_up", C.c_void_p), ("send_dn", C.c_void_p), ("recv_dn", C.c_void_p),
+        ("red_local", C.c_void_p), ("red_all", C.c_void_p),
+        ("allgather_red", HALO_CB), ("exchange_halo", HALO_CB),
+        ("user", C.c_void_p),
+    ]
+
+
 class OcAgents(C.Structure):
     _fields_ = [
         ("N", C.c_int32),
@@ -61,6 +76,9 @@ SIGNATURES = {
     "oc_hjb_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                C.POINTER(OcHjbStats), C.c_void_p]),
+    "oc_hjb_solve_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.POINTER(OcHjbShard), C.c_void_p, C.c_int32, C.c_void_p,
+                                    C.POINTER(OcHjbStats), C.c_void_p]),
     "oc_hjb_vels": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "oc_set_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "oc_set_key_targets": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]),

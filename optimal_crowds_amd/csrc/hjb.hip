@@ -294,6 +294,7 @@ struct StageArgs {
     T atol, rtol, a_lap;
     double* partial;
     int Ny, Nx;
+    int row_lo, row_hi;   // rows whose error / max|y| this launch accounts for (row-block solves: the owned rows)
 };
 
 // halo role of a thread: wave 0 lanes 0-15 top row, wave 1 lanes 0-15 bottom row (4 cells each),
@@ -400,7 +401,7 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
             f.v[q] = (cf.v[q] != cf.v[q]) ? (T)0 : A.a_lap * sum - cf.v[q] * C;
         }
         st4(A.out + idx, f);
-        if (FINAL) {
+        if (FINAL && gi >= A.row_lo && gi < A.row_hi) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 T e = A.he6 * f.v[q];
@@ -554,14 +555,16 @@ struct Solver {
     const T* coef;
     T a_lap;
     int nfev = 0;
+    const oc_hjb_shard* sh = nullptr;   // row-block solve: reductions and halos go through the caller's callbacks
 
     int alloc() {
         size_t need = sizeof(T) * (size_t)n * 12;
-        if (h->hjb_buf == nullptr || h->hjb_elem < sizeof(T)) {
+        if (h->hjb_buf == nullptr || h->hjb_bytes < need) {
             if (h->hjb_buf) OC_HIP_CHECK(hipFree(h->hjb_buf));
             h->hjb_buf = nullptr;
+            h->hjb_bytes = 0;
             OC_HIP_CHECK(hipMalloc(&h->hjb_buf, need));
-            h->hjb_elem = sizeof(T);
+            h->hjb_bytes = need;
         }
         T* b = (T*)h->hjb_buf;
         y = b;
@@ -582,11 +585,59 @@ struct Solver {
     int fused_blocks() const { return ((Nx + HT_X - 1) / HT_X) * ((Ny + HT_Y - 1) / HT_Y); }
     int fused_grid() const { return 8 * ((fused_blocks() + 7) / 8); }
     int reduce(double* sum, double* mx, int nblocks = 1024) {   // partials written by the preceding kernel
+        if (sh) {
+            // every rank contributes (sum, max) of its owned rows; the caller's collective gathers them (on `s`) and
+            // every rank adds them up in rank order, so all ranks take bit-identical controller decisions
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, h->red_partial, nblocks, sh->red_local);
+            if (sh->allgather_red(sh->user) != 0) {
+                oc_set_error("hjb_solve_rows: the allgather_red callback failed");
+                return OC_ERR_STATE;
+            }
+            OC_HIP_CHECK(hipMemcpyAsync(h->red_host, sh->red_all, 2 * sizeof(double) * sh->world,
+                                        hipMemcpyDeviceToHost, s));
+            OC_HIP_CHECK(hipStreamSynchronize(s));
+            double a = 0.0, m = 0.0;
+            for (int r = 0; r < sh->world; ++r) {
+                a += h->red_host[2 * r];
+                m = std::max(m, h->red_host[2 * r + 1]);
+            }
+            *sum = a;
+            if (mx) *mx = m;
+            return OC_OK;
+        }
         hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, h->red_partial, nblocks, h->red_out);
         OC_HIP_CHECK(hipMemcpyAsync(h->red_host, h->red_out, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
         OC_HIP_CHECK(hipStreamSynchronize(s));
         *sum = h->red_host[0];
         if (mx) *mx = h->red_host[1];
+        return OC_OK;
+    }
+    // after an accepted step: the `halo` owned rows next to each neighbour of y_new and K6 travel to that
+    // neighbour's halo rows (staged through the caller's contiguous buffers; rows are contiguous in memory)
+    int exchange_halo() {
+        if (!sh || !(sh->has_up || sh->has_dn)) return OC_OK;
+        const size_t hb = sizeof(T) * (size_t)sh->halo * Nx;
+        const size_t lo = (size_t)sh->own_lo * Nx, hi = (size_t)sh->own_hi * Nx, hn = (size_t)sh->halo * Nx;
+        if (sh->has_up) {
+            OC_HIP_CHECK(hipMemcpyAsync(sh->send_up, ynew + lo, hb, hipMemcpyDeviceToDevice, s));
+            OC_HIP_CHECK(hipMemcpyAsync((char*)sh->send_up + hb, K[6] + lo, hb, hipMemcpyDeviceToDevice, s));
+        }
+        if (sh->has_dn) {
+            OC_HIP_CHECK(hipMemcpyAsync(sh->send_dn, ynew + hi - hn, hb, hipMemcpyDeviceToDevice, s));
+            OC_HIP_CHECK(hipMemcpyAsync((char*)sh->send_dn + hb, K[6] + hi - hn, hb, hipMemcpyDeviceToDevice, s));
+        }
+        if (sh->exchange_halo(sh->user) != 0) {
+            oc_set_error("hjb_solve_rows: the exchange_halo callback failed");
+            return OC_ERR_STATE;
+        }
+        if (sh->has_up) {
+            OC_HIP_CHECK(hipMemcpyAsync(ynew + lo - hn, sh->recv_up, hb, hipMemcpyDeviceToDevice, s));
+            OC_HIP_CHECK(hipMemcpyAsync(K[6] + lo - hn, (char*)sh->recv_up + hb, hb, hipMemcpyDeviceToDevice, s));
+        }
+        if (sh->has_dn) {
+            OC_HIP_CHECK(hipMemcpyAsync(ynew + hi, sh->recv_dn, hb, hipMemcpyDeviceToDevice, s));
+            OC_HIP_CHECK(hipMemcpyAsync(K[6] + hi, (char*)sh->recv_dn + hb, hb, hipMemcpyDeviceToDevice, s));
+        }
         return OC_OK;
     }
 };
@@ -609,6 +660,8 @@ void launch_stages_fused(Solver<T>& S, double hh, T atol_s, T rtol) {
     A.atol = atol_s;
     A.rtol = rtol;
     A.partial = S.h->red_partial;
+    A.row_lo = S.sh ? S.sh->own_lo : 0;
+    A.row_hi = S.sh ? S.sh->own_hi : S.Ny;
     for (int sg = 1; sg < 6; ++sg) {
         for (int j = 0; j < 6; ++j) {
             A.k[j] = S.K[j < sg ? j : 0];
@@ -657,8 +710,8 @@ int emit_slices_fused(Solver<T>& S, const std::vector<double>& te, int nt, int& 
         A.mu = (T)c.mu;
         A.inv2dx = (T)(1.0 / (2 * c.dx));
         A.inv2dy = (T)(1.0 / (2 * c.dy));
-        A.Ny = c.Ny;
-        A.Nx = c.Nx;
+        A.Ny = S.Ny;
+        A.Nx = S.Nx;
         int ns = 0, nv = 0;
         while (ns < OUT_MAXS && k_next < nt && te[k_next] >= t_new) {
             int k = k_next++;
@@ -684,7 +737,7 @@ int emit_slices_fused(Solver<T>& S, const std::vector<double>& te, int nt, int& 
         oc_timer_begin(S.h, "hjb_out", S.s);
         hipLaunchKernelGGL(k_out<T>, dim3(S.fused_grid()), dim3(256), 0, S.s, A);
         // algorithmic bytes: read y_old + 6 stage arrays once, write 2 field components per slice
-        oc_timer_end(S.h, "hjb_out", S.s, sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(c.Ny - 2) * (c.Nx - 2)));
+        oc_timer_end(S.h, "hjb_out", S.s, sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2)));
         stats.n_slices_written += nv;
     }
     return OC_OK;
@@ -693,14 +746,21 @@ int emit_slices_fused(Solver<T>& S, const std::vector<double>& te, int nt, int& 
 template <typename T>
 int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, void* vx_out, void* vy_out,
                 const int32_t* keep_idx, int32_t n_keep, double* phi_keep, double* t_steps, int32_t t_steps_cap,
-                oc_hjb_stats* st, hipStream_t s) {
+                oc_hjb_stats* st, hipStream_t s, const oc_hjb_shard* sh = nullptr) {
     const oc_config& c = h->cfg;
     Solver<T> S;
     S.h = h;
     S.s = s;
-    S.Ny = c.Ny;
+    S.sh = sh;
+    // row-block solve: all arrays hold Ny_local rows (owned rows + halo rows); the kernels treat them as a grid of
+    // that height -- the mirror condition they apply at a halo edge only spoils rows that are never used (see
+    // oc_hip.h, oc_hjb_solve_rows); error norms run over the owned rows and are completed by the collective
+    S.Ny = sh ? sh->Ny_local : c.Ny;
     S.Nx = c.Nx;
-    S.n = h->ncell;
+    S.n = (int64_t)S.Ny * S.Nx;
+    const int own_lo = sh ? sh->own_lo : 0, own_hi = sh ? sh->own_hi : S.Ny;
+    const int64_t own_off = (int64_t)own_lo * S.Nx, n_own = (int64_t)(own_hi - own_lo) * S.Nx;
+    const double n_rms = sh ? (double)sh->Ny_global * S.Nx : (double)S.n;     // cells of the whole grid
     S.coef = (const T*)coef_v;
     S.a_lap = (T)(-0.5 * c.sigma * c.sigma / (c.dx * c.dy));
     int rc = S.alloc();
@@ -709,6 +769,10 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
     const double rtol = c.rtol, atol0 = c.atol;
     const int RB = 1024;
     const bool use_fused = (h->hjb_variant == 0) && (c.Nx % 4 == 0);   // vector kernels need 16-byte rows
+    if (sh && !use_fused) {
+        oc_set_error("hjb_solve_rows needs the fused kernels (Nx %% 4 == 0, hjb variant 0)");
+        return OC_ERR_ARG;
+    }
 
     oc_hjb_stats stats;
     memset(&stats, 0, sizeof(stats));
@@ -742,13 +806,13 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
     {
         double interval = std::fabs(tf - t0);
         double s0, s1, s2;
-        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, S.y, (const T*)nullptr, S.y, (T)atol0,
-                           (T)rtol, n, h->red_partial);
+        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, S.y + own_off, (const T*)nullptr,
+                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
         if ((rc = S.reduce(&s0, nullptr))) return rc;
-        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, S.K[6], (const T*)nullptr, S.y,
-                           (T)atol0, (T)rtol, n, h->red_partial);
+        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, S.K[6] + own_off, (const T*)nullptr,
+                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
         if ((rc = S.reduce(&s1, nullptr))) return rc;
-        double d0 = std::sqrt(s0) / std::sqrt((double)n), d1 = std::sqrt(s1) / std::sqrt((double)n);
+        double d0 = std::sqrt(s0) / std::sqrt(n_rms), d1 = std::sqrt(s1) / std::sqrt(n_rms);
         double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
         h0 = std::min(h0, interval);
         Lin8<T> L;
@@ -757,10 +821,10 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
         L.c[0] = (T)(h0 * direction);
         hipLaunchKernelGGL(k_lincomb<T>, S.g1(), dim3(256), 0, s, S.y, L, S.ytmp, n);
         S.rhs(S.ytmp, S.K[0]);
-        hipLaunchKernelGGL((k_norm_scaled<T, 1>), dim3(RB), dim3(256), 0, s, S.K[0], S.K[6], S.y, (T)atol0, (T)rtol,
-                           n, h->red_partial);
+        hipLaunchKernelGGL((k_norm_scaled<T, 1>), dim3(RB), dim3(256), 0, s, S.K[0] + own_off, S.K[6] + own_off,
+                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
         if ((rc = S.reduce(&s2, nullptr))) return rc;
-        double d2 = std::sqrt(s2) / std::sqrt((double)n) / h0;
+        double d2 = std::sqrt(s2) / std::sqrt(n_rms) / h0;
         double h1;
         if (d1 <= 1e-15 && d2 <= 1e-15)
             h1 = std::max(1e-6, h0 * 1e-3);
@@ -773,7 +837,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
     if (t_steps && t_steps_cap > 0) t_steps[n_steps_rec++] = t;
 
     int k_next = 0;                     // next t_eval index to emit
-    const size_t slice_elems = (size_t)c.Ny * c.Nx;     // padded slices: the reference's array is [1:-1, 1:-1]
+    const size_t slice_elems = (size_t)S.Ny * S.Nx;     // padded slices: the reference's array is [1:-1, 1:-1]
     const double err_exp = -1.0 / 5.0;
 
     while (t != tf) {
@@ -836,7 +900,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
             oc_timer_end(h, "hjb_stage", s, 39.0 * sizeof(T) * (double)n);
             double esum, ymax;
             if ((rc = S.reduce(&esum, &ymax, nred))) return rc;
-            double err = std::sqrt(esum) / std::sqrt((double)n);
+            double err = std::sqrt(esum) / std::sqrt(n_rms);
             if (!(err == err)) {
                 oc_set_error("RK45: NaN error norm at t=%g (state overflow?)", t);
                 return OC_ERR_SOLVER;
@@ -848,6 +912,8 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                 accepted = true;
                 stats.h_min = std::min(stats.h_min, std::fabs(hh));
                 stats.h_max = std::max(stats.h_max, std::fabs(hh));
+                // ---- row-block solve: refresh the halo rows of y_new and K6 (valid again `halo` rows deep)
+                if ((rc = S.exchange_halo())) return rc;
                 // ---- dense output for t_eval points in (t_new, t]  (scipy ivp.py:706-723)
                 if (use_fused) {
                     if ((rc = emit_slices_fused(S, te, nt, k_next, t, t_new, hh, keep_slot, phi_keep, vx_out, vy_out,
@@ -993,6 +1059,47 @@ extern "C" int oc_hjb_solve(oc_handle* h, int dtype, const void* coef, double T,
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             oc_set_error("hjb_solve: %s", hipGetErrorString(e));
+            return OC_ERR_HIP;
+        }
+        if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return rc;
+}
+
+// Row-block variant of oc_hjb_solve (one rank of a domain-decomposed solve), see oc_hip.h.
+extern "C" int oc_hjb_solve_rows(oc_handle* h, int dtype, const void* coef_rows, double T, int32_t nt, void* vx_out,
+                                 void* vy_out, const oc_hjb_shard* sh, const int32_t* keep_idx, int32_t n_keep,
+                                 double* phi_keep, oc_hjb_stats* stats, void* stream) {
+    OC_REQUIRE(h && coef_rows && sh, "null argument");
+    OC_REQUIRE(nt <= 1 || (vx_out && vy_out), "null output field");
+    OC_REQUIRE(n_keep == 0 || (keep_idx && phi_keep), "keep list without buffer");
+    OC_REQUIRE(sh->world >= 1 && sh->world <= OC_MAX_WORLD, "bad world size");
+    OC_REQUIRE(sh->halo >= 6, "halo must cover the 6 stencil applications of one RK step");
+    OC_REQUIRE(sh->own_lo == (sh->has_up ? sh->halo : 0), "own_lo must equal the upper halo depth");
+    OC_REQUIRE(sh->own_hi > sh->own_lo && sh->Ny_local == sh->own_hi + (sh->has_dn ? sh->halo : 0), "bad row window");
+    OC_REQUIRE(!(sh->has_up || sh->has_dn) || sh->own_hi - sh->own_lo >= sh->halo, "owned block thinner than the halo");
+    OC_REQUIRE(sh->Ny_local >= 3 && sh->Ny_local <= sh->Ny_global && sh->Ny_global <= h->cfg.Ny, "bad row counts");
+    OC_REQUIRE(sh->red_local && sh->red_all && sh->allgather_red, "missing reduction buffers / callback");
+    OC_REQUIRE(!(sh->has_up || sh->has_dn) || sh->exchange_halo, "missing halo callback");
+    OC_REQUIRE(!sh->has_up || (sh->send_up && sh->recv_up), "missing upper staging buffers");
+    OC_REQUIRE(!sh->has_dn || (sh->send_dn && sh->recv_dn), "missing lower staging buffers");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    if (dtype == OC_F32)
+        rc = hjb_solve_t<float>(h, coef_rows, T, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, nullptr, 0, stats, s, sh);
+    else if (dtype == OC_F64)
+        rc = hjb_solve_t<double>(h, coef_rows, T, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, nullptr, 0, stats, s,
+                                 sh);
+    else {
+        oc_set_error("bad dtype %d", dtype);
+        return OC_ERR_ARG;
+    }
+    if (rc == OC_OK) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            oc_set_error("hjb_solve_rows: %s", hipGetErrorString(e));
             return OC_ERR_HIP;
         }
         if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -65,7 +65,7 @@ struct oc_handle {
     double* X0 = nullptr;       // device (Nx)
     double* Y0 = nullptr;       // device (Ny)
     // ---- HJB scratch (allocated lazily per dtype size)
-    size_t hjb_elem = 0;        // element size the scratch was allocated for
+    size_t hjb_bytes = 0;       // size of the scratch below
     void* hjb_buf = nullptr;    // y, ynew, ytmp, K0..K6, phi_tmp  (11 arrays)
     double* red_partial = nullptr;   // per-block partial sums
     double* red_out = nullptr;       // device: few doubles

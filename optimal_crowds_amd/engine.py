@@ -171,6 +171,35 @@ class Engine:
             st["t_steps"] = tsteps[:st["n_accept"] + 1].copy()
         return st, phi_keep
 
+    def solve_rows(self, key, T, nt, comm, m=None, keep=None, field=None):
+        """This rank's part of a row-block HJB solve (oc_hjb_solve_rows; `comm`: parallel.DistHaloComm or
+        ThreadHaloComm built on a parallel.RowShard).  Returns (stats, (vx, vy), phi_keep): the direction field
+        (nt-1, Ny_local, Nx) and kept phi (len(keep), Ny_local, Nx) cover the LOCAL rows comm.shard.rows()."""
+        sh = comm.shard
+        self.make_coef(key, m)
+        coef_rows = self.coef[sh.rows()]
+        if field is None:
+            shape = (max(nt - 1, 0), sh.Ny_local, self.Nx)
+            field = (torch.zeros(shape, dtype=self.tdtype, device=self.device),
+                     torch.zeros(shape, dtype=self.tdtype, device=self.device))
+        vx, vy = field
+        stats = OcHjbStats()
+        keep_arr = phi_keep = None
+        n_keep = 0
+        if keep is not None and len(keep):
+            keep_arr = np.ascontiguousarray(keep, dtype=np.int32)
+            n_keep = len(keep_arr)
+            phi_keep = torch.empty((n_keep, sh.Ny_local, self.Nx), dtype=torch.float64, device=self.device)
+        st = comm.struct()
+        rc = self.lib.oc_hjb_solve_rows(self.h, self.dtype, _ptr(coef_rows), float(T), int(nt), _ptr(vx), _ptr(vy),
+                                        C.byref(st), keep_arr.ctypes.data_as(C.c_void_p) if n_keep else None, n_keep,
+                                        _ptr(phi_keep), C.byref(stats), self.stream())
+        if comm.error is not None:
+            err, comm.error = comm.error, None
+            raise err
+        check(rc)
+        return stats.as_dict(), (vx, vy), phi_keep
+
     def set_field_horizon(self, key, nt):
         vx, vy, nslice, _ = self.fields[key]
         self.fields[key][3] = nt

@@ -1,14 +1,19 @@
 """Multi-GPU plumbing for the path (one process per GPU, torch.distributed; backend "nccl" = RCCL on ROCm).
 
-This round the bench runs independent replicas: no data-path collective.  The helpers below
-are the host side of the partition that does shard -- the HJB grid by row blocks, or whole keys over ranks -- and
-are covered by world-size-2 gloo tests on CPU (tests/test_parallel_gloo.py).  They move tensors only; the numerics
-stay in the HIP library (on CPU tests the oracle's RHS stands in for it).
+The bench's default for N > 1 is independent replicas.  What shards is the HJB grid, by row
+blocks: `RowShard` is the geometry of one rank's block, `DistHaloComm` carries the two collectives of
+`oc_hjb_solve_rows` (include/oc_hip.h) over torch.distributed -- RCCL point-to-point on device tensors, or gloo with
+host staging for tests -- and `ThreadHaloComm` runs several virtual ranks inside one process on one GPU (tests).
+The numerics stay in the HIP library; this module only moves tensors.
 """
+import ctypes as C
 import os
+import threading
 
 import torch
 import torch.distributed as dist
+
+from ._lib import HALO_CB, OcHjbShard
 
 
 def init_distributed(backend=None):
@@ -89,3 +94,149 @@ def error_norm_allreduce(local_sumsq, local_max, device="cpu"):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
     return float(t.item()), float(m.item())
+
+
+# ---------------------------------------------------------------------------------------------- row-block HJB solve
+class RowShard:
+    """One rank's row block of the (Ny, Nx) grid plus `halo` rows of each neighbour (oc_hip.h: oc_hjb_shard).
+    halo >= 6 (one RK step applies the stencil 6 times); the direction field is exact on owned rows +- (halo - 6)."""
+
+    def __init__(self, Ny, rank, world, halo=8):
+        r0, r1 = row_blocks(Ny, world)[rank]
+        if world > 1 and (halo < 6 or Ny // world < halo):
+            raise ValueError("row blocks of %d rows cannot carry a halo of %d rows" % (Ny // world, halo))
+        self.Ny, self.rank, self.world, self.halo = Ny, rank, world, halo
+        self.has_up, self.has_dn = rank > 0, rank < world - 1
+        self.g0, self.g1 = r0, r1                                   # owned global rows [g0, g1)
+        self.row0 = r0 - (halo if self.has_up else 0)               # global row of local row 0
+        self.own_lo = halo if self.has_up else 0
+        self.own_hi = self.own_lo + (r1 - r0)
+        self.Ny_local = self.own_hi + (halo if self.has_dn else 0)
+        self.field_margin = halo - 6                                # rows beyond the block where the field is exact
+
+    def rows(self):
+        """slice of the global grid rows held locally (owned + halo)"""
+        return slice(self.row0, self.row0 + self.Ny_local)
+
+
+class _HaloComm:
+    """Staging buffers + the two host callbacks of oc_hjb_solve_rows.  Subclasses implement the collectives."""
+
+    def __init__(self, shard, Nx, tdtype, device):
+        self.shard, self.device = shard, torch.device(device)
+        mk = lambda: torch.zeros((2, shard.halo, Nx), dtype=tdtype, device=self.device)
+        self.send_up, self.recv_up, self.send_dn, self.recv_dn = mk(), mk(), mk(), mk()
+        self.red_local = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.red_all = torch.zeros((shard.world, 2), dtype=torch.float64, device=self.device)
+        self.error = None
+        self.n_allgather = self.n_exchange = 0
+        self._cb_red = HALO_CB(self._red)
+        self._cb_halo = HALO_CB(self._halo)
+
+    def _red(self, user):
+        try:
+            self.allgather_red()
+            self.n_allgather += 1
+            return 0
+        except BaseException as e:        # an exception must not unwind through the C frames
+            self.error = e
+            return -1
+
+    def _halo(self, user):
+        try:
+            self.exchange_halo()
+            self.n_exchange += 1
+            return 0
+        except BaseException as e:
+            self.error = e
+            return -1
+
+    def struct(self):
+        sh, st = self.shard, OcHjbShard()
+        st.Ny_local, st.Ny_global = sh.Ny_local, sh.Ny
+        st.own_lo, st.own_hi, st.halo = sh.own_lo, sh.own_hi, sh.halo
+        st.has_up, st.has_dn, st.world = int(sh.has_up), int(sh.has_dn), sh.world
+        st.send_up, st.recv_up = self.send_up.data_ptr(), self.recv_up.data_ptr()
+        st.send_dn, st.recv_dn = self.send_dn.data_ptr(), self.recv_dn.data_ptr()
+        st.red_local, st.red_all = self.red_local.data_ptr(), self.red_all.data_ptr()
+        st.allgather_red, st.exchange_halo = self._cb_red, self._cb_halo
+        st.user = None
+        return st
+
+
+class DistHaloComm(_HaloComm):
+    """The collectives over torch.distributed.  `ranks`: global ranks of the group's members in block order (default:
+    the whole world).  Backend nccl (= RCCL): device tensors, enqueued on the current stream, neighbour messages as one
+    batched send/recv pair per side over xGMI; backend gloo: staged through host memory (tests)."""
+
+    def __init__(self, shard, Nx, tdtype, device, group=None, ranks=None):
+        super().__init__(shard, Nx, tdtype, device)
+        self.group = group
+        self.ranks = list(range(dist.get_world_size())) if ranks is None else list(ranks)
+        assert len(self.ranks) == shard.world
+        self.host_staged = dist.get_backend(group) != "nccl"
+
+    def allgather_red(self):
+        if self.host_staged:
+            loc = self.red_local.cpu()
+            parts = [torch.empty_like(loc) for _ in range(self.shard.world)]
+            dist.all_gather(parts, loc, group=self.group)
+            self.red_all.copy_(torch.stack(parts))
+        else:
+            dist.all_gather_into_tensor(self.red_all, self.red_local, group=self.group)
+
+    def exchange_halo(self):
+        sh = self.shard
+        stage = (lambda t: t.cpu()) if self.host_staged else (lambda t: t)
+        ops, post = [], []
+        if sh.has_up:
+            peer = self.ranks[sh.rank - 1]
+            rbuf = torch.empty_like(stage(self.recv_up))
+            ops += [dist.P2POp(dist.isend, stage(self.send_up), peer, group=self.group),
+                    dist.P2POp(dist.irecv, rbuf, peer, group=self.group)]
+            post.append((self.recv_up, rbuf))
+        if sh.has_dn:
+            peer = self.ranks[sh.rank + 1]
+            rbuf = torch.empty_like(stage(self.recv_dn))
+            ops += [dist.P2POp(dist.isend, stage(self.send_dn), peer, group=self.group),
+                    dist.P2POp(dist.irecv, rbuf, peer, group=self.group)]
+            post.append((self.recv_dn, rbuf))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for dst, src in post:
+            dst.copy_(src)
+
+
+class ThreadWorld:
+    """Shared state of `world` virtual ranks living in threads of one process (one GPU): a barrier and the comms."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.comms = [None] * world
+
+    def sync(self):
+        torch.cuda.synchronize()
+        self.barrier.wait()
+
+
+class ThreadHaloComm(_HaloComm):
+    def __init__(self, shard, Nx, tdtype, device, tworld):
+        super().__init__(shard, Nx, tdtype, device)
+        self.tw = tworld
+        tworld.comms[shard.rank] = self
+
+    def allgather_red(self):
+        self.tw.sync()                                  # every rank's red_local is final
+        for r, c in enumerate(self.tw.comms):
+            self.red_all[r].copy_(c.red_local)
+        self.tw.sync()                                  # nobody overwrites red_local before it was read
+
+    def exchange_halo(self):
+        sh = self.shard
+        self.tw.sync()
+        if sh.has_up:
+            self.recv_up.copy_(self.tw.comms[sh.rank - 1].send_dn)
+        if sh.has_dn:
+            self.recv_dn.copy_(self.tw.comms[sh.rank + 1].send_up)
+        self.tw.sync()

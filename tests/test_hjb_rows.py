@@ -1,0 +1,221 @@
+"""Row-block (domain-decomposed) HJB solve, SURVEY 8e: oc_hjb_solve_rows against the single-GPU oc_hjb_solve.
+
+* virtual ranks: `world` threads of one process, one engine (library handle) each, all on cuda:0; the collectives are
+  device copies between the ranks' staging buffers (parallel.ThreadHaloComm);
+* two processes sharing cuda:0 with torch.distributed/gloo carrying the collectives (parallel.DistHaloComm, the class
+  that runs over RCCL on a multi-GPU node; gloo stages through host memory).
+
+The decomposed solve applies the same arithmetic to every owned cell; only the summation order of the error norm
+differs (per-rank partial sums), which perturbs the step sizes at the 1e-16 level.  Tolerances are written below."""
+import copy
+import os
+import socket
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from optimal_crowds_amd import host, room_library      # noqa: E402
+
+
+def _setup(room_name, grid_step):
+    cfg = copy.deepcopy(host.load_config())
+    cfg["grid_step"] = grid_step
+    room = room_library.ROOMS[room_name]()
+    Nx, Ny = host.grid_dims(room["room_length"], room["room_height"], grid_step)
+    X0, Y0 = host.axes(room["room_length"], room["room_height"], Nx, Ny)
+    box = list(room["initial_boxes"].values())[0]
+    V = host.create_potential(room, box[5:], X0, Y0)
+    host.finalize_potential(V, cfg)
+    return cfg, room, Nx, Ny, X0, Y0, V
+
+
+def _new_engine(cfg, room, Nx, Ny, X0, Y0, V, dtype):
+    from optimal_crowds_amd.engine import Engine
+    eng = Engine(cfg, room["room_length"], room["room_height"], Nx, Ny, X0, Y0, 1, 64, dtype=dtype)
+    eng.set_potential(0, V, np.zeros((0, 4)))
+    return eng
+
+
+def _density_like(Ny, Nx, seed=3):
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:Ny, 0:Nx]
+    m = np.zeros((Ny, Nx))
+    for _ in range(6):
+        cy, cx = rng.uniform(0, Ny), rng.uniform(0, Nx)
+        m += 3.0 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 6.0 ** 2))
+    return m
+
+
+def _solve_virtual_ranks(setup, dtype, world, halo, T, nt, keep, m):
+    """world threads, one engine each; returns per-rank (shard, stats, vx, vy, phi_keep) with tensors on the host."""
+    import torch
+    from optimal_crowds_amd import parallel
+    cfg, room, Nx, Ny, X0, Y0, V = setup
+    tw = parallel.ThreadWorld(world)
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            eng = _new_engine(cfg, room, Nx, Ny, X0, Y0, V, dtype)
+            sh = parallel.RowShard(Ny, rank, world, halo)
+            comm = parallel.ThreadHaloComm(sh, Nx, eng.tdtype, eng.device, tw)
+            tw.barrier.wait(timeout=120)                          # every comm registered
+            mt = None if m is None else torch.as_tensor(m)
+            st, (vx, vy), phi = eng.solve_rows(0, T, nt, comm, m=mt, keep=keep)
+            st["n_exchange"], st["n_allgather"] = comm.n_exchange, comm.n_allgather
+            out[rank] = (sh, st, vx.cpu().numpy(), vy.cpu().numpy(), None if phi is None else phi.cpu().numpy())
+            eng.close()
+        except BaseException as e:      # noqa: BLE001
+            errs.append((rank, e))
+            tw.barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    if errs:
+        raise errs[0][1]
+    return out
+
+
+def _assemble(parts, Ny, what):
+    """global array from the ranks' OWNED rows"""
+    first = parts[0][what]
+    full = np.zeros(first.shape[:1] + (Ny,) + first.shape[2:], dtype=first.dtype)
+    for sh, st, vx, vy, phi in parts:
+        src = (None, None, vx, vy, phi)[what]
+        full[:, sh.g0:sh.g1] = src[:, sh.own_lo:sh.own_hi]
+    return full
+
+
+@pytest.mark.parametrize("room_name,world,halo,dtype", [
+    ("gold_a", 2, 6, "float64"), ("gold_a", 3, 8, "float64"), ("gold_b", 4, 9, "float64"),
+    ("gold_a", 2, 8, "float32"), ("gold_b", 3, 6, "float32"),
+])
+def test_row_block_solve_matches_single_solve(room_name, world, halo, dtype):
+    """float64: same number of attempts/accepted steps, phi rel <= 1e-9, direction field |diff| <= 1e-7 on every
+    owned cell and on the `halo - 6` margin rows beyond each block.
+    float32: phi rel <= 2e-5; direction field may differ by more than 1e-4 on at most 0.1% of cells (unit-or-zero
+    decisions at |v| ~ lim flip with the last bits)."""
+    import torch
+    setup = _setup(room_name, 0.05)
+    cfg, room, Nx, Ny, X0, Y0, V = setup
+    T, nt = 3.0, 150
+    keep = [1, 40, 100, nt - 1]
+    m = _density_like(Ny, Nx)
+    ref = _new_engine(*setup, dtype)
+    ref.alloc_field(0, nt - 1)
+    st0, phi0 = ref.solve(0, T, nt, m=torch.as_tensor(m), keep=keep)
+    phi0 = phi0.cpu().numpy()
+    vx0, vy0 = ref.fields[0][0].cpu().numpy(), ref.fields[0][1].cpu().numpy()
+    ref.close()
+
+    parts = _solve_virtual_ranks(setup, dtype, world, halo, T, nt, keep, m)
+    for sh, st, *_ in parts:
+        assert st["n_attempt"] == st0["n_attempt"] and st["n_accept"] == st0["n_accept"]
+        assert st["nfev"] == st0["nfev"]
+        assert st["n_exchange"] == (st0["n_accept"] if world > 1 else 0)
+        assert st["n_allgather"] == st0["n_attempt"] + 3          # + select_initial_step's three norms
+        assert st["h_abs0"] == pytest.approx(st0["h_abs0"], rel=1e-12)
+    phi = _assemble(parts, Ny, 4)
+    vx, vy = _assemble(parts, Ny, 2), _assemble(parts, Ny, 3)
+    if dtype == "float64":
+        assert np.allclose(phi, phi0, rtol=1e-9, atol=0)
+        assert np.abs(vx - vx0).max() <= 1e-7 and np.abs(vy - vy0).max() <= 1e-7
+    else:
+        assert np.allclose(phi, phi0, rtol=2e-5, atol=0)
+        bad = (np.abs(vx - vx0) > 1e-4) | (np.abs(vy - vy0) > 1e-4)
+        assert bad.mean() <= 1e-3
+    # the field is also exact `halo - 6` rows beyond the block (what lets agents near a block edge be served locally)
+    for sh, st, lvx, lvy, lphi in parts:
+        mg = sh.field_margin
+        lo, hi = sh.own_lo - (mg if sh.has_up else 0), sh.own_hi + (mg if sh.has_dn else 0)
+        g_lo = sh.row0 + lo
+        a, b = lvx[:, lo:hi], vx0[:, g_lo:g_lo + (hi - lo)]
+        if dtype == "float64":
+            assert np.abs(a - b).max() <= 1e-7
+        else:
+            assert (np.abs(a - b) > 1e-4).mean() <= 1e-3
+
+
+def test_row_block_t20_range_management():
+    """T = 20 in float32: the power-of-two rescaling (max|y| is a global maximum over ranks) must happen at the same
+    steps on every rank and give the single-GPU field."""
+    import torch
+    setup = _setup("room_test", 0.1)       # 100 x 100 grid: nt = 1000 slices stay small
+    cfg, room, Nx, Ny, X0, Y0, V = setup
+    if Nx % 4:
+        pytest.skip("fused kernels need Nx % 4 == 0")
+    T, nt = 20.0, 1000
+    ref = _new_engine(*setup, "float32")
+    ref.alloc_field(0, nt - 1)
+    st0, _ = ref.solve(0, T, nt)
+    vx0 = ref.fields[0][0].cpu().numpy()
+    ref.close()
+    parts = _solve_virtual_ranks(setup, "float32", 2, 6, T, nt, None, None)
+    for sh, st, *_ in parts:
+        assert st["n_rescale"] == st0["n_rescale"] and st["n_rescale"] > 0
+        assert st["final_exponent"] == st0["final_exponent"]
+        assert st["n_accept"] == st0["n_accept"]
+    vx = _assemble(parts, Ny, 2)
+    assert (np.abs(vx - vx0) > 1e-4).mean() <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ two processes, gloo
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dist_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from optimal_crowds_amd import parallel
+    try:
+        parallel.init_distributed("gloo")
+        setup = _setup("gold_b", 0.05)
+        cfg, room, Nx, Ny, X0, Y0, V = setup
+        T, nt, keep = 2.0, 100, [1, 50, 99]
+        eng = _new_engine(*setup, "float64")
+        sh = parallel.RowShard(Ny, rank, world, halo=7)
+        comm = parallel.DistHaloComm(sh, Nx, eng.tdtype, eng.device)
+        st, (vx, vy), phi = eng.solve_rows(0, T, nt, comm, keep=keep)
+        res = dict(rank=rank, g0=sh.g0, g1=sh.g1, st=st, vx=vx[:, sh.own_lo:sh.own_hi].cpu().numpy(),
+                   phi=phi[:, sh.own_lo:sh.own_hi].cpu().numpy())
+        if rank == 0:
+            eng.alloc_field(0, nt - 1)
+            st0, phi0 = eng.solve(0, T, nt, keep=keep)
+            res.update(st0=st0, phi0=phi0.cpu().numpy(), vx0=eng.fields[0][0].cpu().numpy())
+        q.put(res)
+        dist.barrier()
+        eng.close()
+        dist.destroy_process_group()
+    except BaseException as e:      # noqa: BLE001
+        q.put(dict(rank=rank, error=repr(e)))
+        raise
+
+
+def test_row_block_solve_two_processes_gloo():
+    """World-size-2 torch.distributed run (gloo, both ranks on cuda:0): float64, phi rel <= 1e-9, field <= 1e-7."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=300) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    for r in res:
+        assert "error" not in r, r
+    res.sort(key=lambda r: r["rank"])
+    r0 = res[0]
+    for r in res:
+        assert r["st"]["n_attempt"] == r0["st0"]["n_attempt"] and r["st"]["n_accept"] == r0["st0"]["n_accept"]
+        assert np.allclose(r["phi"], r0["phi0"][:, r["g0"]:r["g1"]], rtol=1e-9, atol=0)
+        assert np.abs(r["vx"] - r0["vx0"][:, r["g0"]:r["g1"]]).max() <= 1e-7
