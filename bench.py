@@ -35,7 +35,7 @@ WORKLOADS = {   # name -> (room, grid_step, T)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def build_sim(workload, seed=20240807):
+def build_sim(workload, seed=20240807, wall_search_radius=-1.0):
     import io
     import contextlib
     from optimal_crowds_amd import host, simulations
@@ -45,7 +45,7 @@ def build_sim(workload, seed=20240807):
     np.random.seed(seed)
     with contextlib.redirect_stdout(io.StringIO()):
         sim = simulations.simulation(room, T, config=cfg, noise="device", seed=seed, record=False, history=False,
-                                     wall_search_radius=-1.0)
+                                     wall_search_radius=wall_search_radius)
     return sim, cfg
 
 
@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="metro_station", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wall-radius", type=float, default=-1.0,
+                    help="diagnostic: wall search radius in m (default -1: per-agent radius from the 1e-12 m/s force bound)")
+    ap.add_argument("--tune", default="", help="launch-shape knobs, e.g. pair_split=4,wall_blocks=64 (oc_set_tuning)")
     args = ap.parse_args()
 
     import torch
@@ -176,9 +179,12 @@ def main():
 
     import optimal_crowds_amd.engine  # noqa: F401  (fails loudly without the HIP library)
     t_init = time.perf_counter()
-    sim, cfg = build_sim(args.workload)
+    sim, cfg = build_sim(args.workload, wall_search_radius=args.wall_radius)
     t_init = time.perf_counter() - t_init
     eng = sim._engine
+    for kv in filter(None, args.tune.split(",")):
+        name, val = kv.split("=")
+        eng.set_tuning(name, int(val))
     nt = sim._nt0
     K, W = args.steps, args.warmup
 

@@ -97,6 +97,7 @@ SIGNATURES = {
                                   C.POINTER(C.c_double)]),
     "oc_reset_kernel_stats": (C.c_int, [C.c_void_p]),
     "oc_set_hjb_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "oc_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
 }
 
 _lib = None

@@ -27,6 +27,7 @@ struct KeyDev {
     const void* vy;
     const int2* lr;        // [Nx][Ny]: (nearest site column <= j or -1, nearest site column >= j+1 or Nx) of row r
     const float* edt;      // (Ny,Nx) distance from each grid node to the nearest site, capped at edt_cap (lower bound)
+    const int32_t* gap8;   // [Nx][ceil(Ny/8)]: min over 8 grid rows of the column gap to the row's nearest site
     double off;
     double edt_cap;
     int32_t dtype, nslice_alloc, nt_opt, nrect;
@@ -52,6 +53,18 @@ struct GcfmParams {
 #define C_WCOUNT 4      // [4], [5]: wall work-list lengths (ping-pong)
 #define C_INVALID 6     // neighbour lists no longer cover the tile boxes -> full tile scan
 
+// One entry of the wall work-list: everything the search needs, so that its first dependent load is already the
+// table (the search is a chain of dependent loads; every level removed is ~1 us off each group's latency).
+struct alignas(64) WEntry {
+    double px, py;          // the agent's position
+    double lim2;            // min(search radius^2, upper bound^2 on the distance to the nearest site)
+    double off;             // the key's objective offset V_min * 10e3
+    const int2* col;        // lr + jx * Ny: the agent's column of the transposed nearest-site table
+    const int32_t* g8;      // gap8 + jx * nb8
+    int32_t k, b0;          // packed slot; 8-row block of the nearest grid row
+    int32_t prune_ok, pad;  // column-gap bounds valid (agent within one cell of column jx)
+};
+
 struct Scratch {
     uint32_t *keys_a, *keys_b;
     int32_t *vals_a, *vals_b;
@@ -63,9 +76,21 @@ struct Scratch {
     int32_t* nb_list;       // [ntiles][NB_MAX + 1]: count (or -1 = overflow) then tile ids
     double2 *f_pair, *f_wall, *des;
     long long* widx;
-    int32_t* wall_list[2];
+    WEntry* wall_list[2];   // work-list of the nearest-wall search (ping-pong): self-contained 64-byte records
     int32_t* ctrl;
     int32_t Np, ntiles;
+};
+
+// A grid axis.  The reference builds both with np.linspace(0, len, n) (simulations.py:69-70), whose elements are
+// fl(j * step), step = len / (n - 1), the last one set to len; when the caller's arrays are exactly that (checked in
+// oc_create) coordinates are computed instead of loaded -- the nearest-wall search is a chain of dependent loads.
+struct Axis {
+    const double* a;
+    double h, len;
+    int32_t n, lin;
+    __device__ __forceinline__ double operator[](int j) const {
+        return lin ? (j == n - 1 ? len : (double)j * h) : a[j];
+    }
 };
 
 __device__ __forceinline__ double wmin(double v) {
@@ -118,7 +143,7 @@ __global__ void k_cell_keys(const double* __restrict__ x, const double* __restri
 
 // Exact nearest-site query (same cell as numpy's argmin over the full grid, see oracle WallMap for the proof
 // sketch): per grid row only the nearest site left and right of the agent's column can be the row minimum.
-__device__ __forceinline__ void wall_try(double px, double py, int r, int cnd, int Nx, const double* __restrict__ X0,
+__device__ __forceinline__ void wall_try(double px, double py, int r, int cnd, int Nx, const Axis X0,
                                          double yr, double off, double& best_d2, double& thr, double& best_f,
                                          long long& best_flat) {
     if (cnd < 0 || cnd >= Nx) return;
@@ -142,7 +167,7 @@ __device__ __forceinline__ void wall_try(double px, double py, int r, int cnd, i
 // 1e-12 m/s for this agent's own speed (q <= a^2, v_rel <= |v|; 33 = ln(3 * 60 m / 1e-12 m/s) rounded up)
 __device__ __forceinline__ double wall_radius_of(const GcfmParams& P, double s) {
     if (P.wall_radius >= 0) return P.wall_radius;
-    double a = P.a_min + P.tau_a * s;
+    double a = fmax(P.a_min + P.tau_a * s, P.b_max);        // q <= max(a, b)^2
     return a * a + P.eta_walls * (1.0 + s) * 33.0;
 }
 
@@ -151,7 +176,7 @@ __device__ __forceinline__ double wall_radius_of(const GcfmParams& P, double s) 
 // transposed table lr[jx][row] (rows contiguous: 4 rows = 32 bytes per lane and direction).  Rows stop when
 // their |dy| alone exceeds the best distance (+ tie slack), the search radius, or a known upper bound ub2.
 __device__ __forceinline__ void wall_scan(double px, double py, const int2* __restrict__ lr, int Nx, int Ny, double hx,
-                                          double hy, const double* __restrict__ X0, const double* __restrict__ Y0,
+                                          double hy, const Axis X0, const Axis Y0,
                                           double off, double rad2, double ub2, long long& best_flat, double& best_d2) {
     int jx = (int)floor(px / hx);
     jx = jx < 0 ? 0 : (jx > Nx - 1 ? Nx - 1 : jx);
@@ -204,8 +229,8 @@ __device__ __forceinline__ void wall_scan(double px, double py, const int2* __re
 // Can this agent feel a wall?  Uses the capped distance transform at the nearest grid node:
 // d(node) - |p - node| <= d*(p) <= d(node) + |p - node|.  Returns false when d*(p) provably exceeds the agent's
 // search radius (force < 1e-12 m/s); ub2 = squared upper bound on d*(p) (or inf).
-__device__ __forceinline__ bool wall_needed(const GcfmParams& P, const KeyDev& kd, const double* __restrict__ X0,
-                                            const double* __restrict__ Y0, double px, double py, double speed,
+__device__ __forceinline__ bool wall_needed(const GcfmParams& P, const KeyDev& kd, const Axis X0,
+                                            const Axis Y0, double px, double py, double speed,
                                             double& rad2, double& ub2) {
     const int Nx = P.Nx, Ny = P.Ny;
     const double hx = P.L / (Nx - 1), hy = P.H / (Ny - 1);
@@ -226,11 +251,37 @@ __device__ __forceinline__ bool wall_needed(const GcfmParams& P, const KeyDev& k
     return true;
 }
 
+// wall_needed + the start of the search (column, nearest row), packed for the work-list
+__device__ __forceinline__ bool wall_prepare(const GcfmParams& P, const KeyDev& kd, const Axis X0, const Axis Y0, double px,
+                                             double py, double speed, int k, WEntry& e) {
+    double rad2, ub2;
+    if (!wall_needed(P, kd, X0, Y0, px, py, speed, rad2, ub2)) return false;
+    const int Nx = P.Nx, Ny = P.Ny;
+    const double hx = P.L / (Nx - 1), hy = P.H / (Ny - 1);
+    int jx = (int)floor(px / hx);
+    jx = jx < 0 ? 0 : (jx > Nx - 1 ? Nx - 1 : jx);
+    while (jx > 0 && X0[jx] > px) --jx;
+    while (jx < Nx - 1 && X0[jx + 1] <= px) ++jx;
+    int r0 = (int)floor(py / hy + 0.5);
+    r0 = r0 < 0 ? 0 : (r0 > Ny - 1 ? Ny - 1 : r0);
+    e.px = px;
+    e.py = py;
+    e.lim2 = fmin(rad2, ub2);
+    e.off = kd.off;
+    e.col = kd.lr + (size_t)jx * Ny;
+    e.g8 = kd.gap8 + (size_t)jx * ((Ny + 7) >> 3);
+    e.k = k;
+    e.b0 = r0 >> 3;
+    e.prune_ok = fabs(px - X0[jx]) <= hx;                          // false only for agents outside the room
+    e.pad = 0;
+    return true;
+}
+
 // wall force from the selected cell, float64 (pedestrians.py:317-334); zero if no cell was selected.
 // R = 0 (agent exactly on a wall node) gives NaN in the reference; here the force is 0 (deviation D1).
 __device__ __forceinline__ double2 wall_force_of(const GcfmParams& P, long long flat, double px, double py, double vxd,
-                                                 double vyd, double vdes, const double* __restrict__ X0,
-                                                 const double* __restrict__ Y0) {
+                                                 double vyd, double vdes, const Axis X0,
+                                                 const Axis Y0) {
     if (flat < 0) return make_double2(0.0, 0.0);
     int r = (int)(flat / P.Nx), cc = (int)(flat % P.Nx);
     double Rx = X0[cc] - px, Ry = Y0[r] - py;
@@ -262,14 +313,14 @@ __device__ __forceinline__ void make_record(const GcfmParams& P, double vxd, dou
 }
 
 // append the lanes with `need` to the wall work-list (one atomic per wavefront)
-__device__ __forceinline__ void wall_list_push(bool need, int k, int32_t* __restrict__ list, int32_t* count) {
+__device__ __forceinline__ void wall_list_push(bool need, const WEntry& e, WEntry* __restrict__ list, int32_t* count) {
     unsigned long long m = __ballot(need);
     if (!m) return;
     int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
     int base = 0;
     if (lane == leader) base = atomicAdd(count, __popcll(m));
     base = __shfl(base, leader, 64);
-    if (need) list[base + __popcll(m & ((1ull << lane) - 1))] = k;
+    if (need) list[base + __popcll(m & ((1ull << lane) - 1))] = e;
 }
 
 // full pack from the state arrays (after a re-sort): one wavefront per tile
@@ -277,8 +328,8 @@ __global__ void __launch_bounds__(64) k_pack(const double* __restrict__ x, const
                                              const double* __restrict__ vx, const double* __restrict__ vy,
                                              const uint8_t* __restrict__ status, const int32_t* __restrict__ key_of,
                                              const int32_t* __restrict__ order, int N, GcfmParams P, Scratch S,
-                                             const KeyDev* __restrict__ keys, const double* __restrict__ X0,
-                                             const double* __restrict__ Y0, int cur) {
+                                             const KeyDev* __restrict__ keys, const Axis X0,
+                                             const Axis Y0, int cur) {
     int k = blockIdx.x * 64 + threadIdx.x;
     int i = (k < N) ? order[k] : -1;
     bool act = (i >= 0) && status[i];
@@ -286,21 +337,19 @@ __global__ void __launch_bounds__(64) k_pack(const double* __restrict__ x, const
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 ph = make_float2(1.f, 0.f);
     bool need = false;
+    WEntry we;
     if (act) {
         px = x[i];
         py = y[i];
         make_record(P, vx[i], vy[i], pv, ph);
-        if (keys) {
-            double r2, u2;
-            need = wall_needed(P, keys[key_of[i]], X0, Y0, px, py, (double)pv.z, r2, u2);
-        }
+        if (keys) need = wall_prepare(P, keys[key_of[i]], X0, Y0, px, py, (double)pv.z, k, we);
     }
     S.ppos[k] = make_double2(px, py);
     S.pvel[k] = pv;
     S.phead[k] = ph;
     S.pidx[k] = act ? i : -1;
     S.widx[k] = -1;
-    wall_list_push(need, k, S.wall_list[cur], &S.ctrl[C_WCOUNT + cur]);
+    wall_list_push(need, we, S.wall_list[cur], &S.ctrl[C_WCOUNT + cur]);
     double mnx = wmin(act ? px : INFINITY), mny = wmin(act ? py : INFINITY);
     double mxx = wmax(act ? px : -INFINITY), mxy = wmax(act ? py : -INFINITY);
     if (threadIdx.x == 0) {
@@ -360,7 +409,8 @@ __device__ __forceinline__ float2 pair_term(float Rx, float Ry, float vxi, float
 }
 
 typedef float f2v __attribute__((ext_vector_type(2)));
-#define PAIR_LIST_CAP 4096      // 64 x 64: every (i, j) of a tile pair can be a candidate
+#define PAIR_LIST_CAP 1024      // 64 x 16: a quarter of a tile pair always fits
+#define PAIR_SPLIT_MAX 4
 
 struct JRec {                   // one lane's share of a staged j-tile (prefetched into registers)
     double2 pos;
@@ -368,25 +418,35 @@ struct JRec {                   // one lane's share of a staged j-tile (prefetch
     float2 head;
 };
 
-// One WAVEFRONT per i-tile (4 independent wavefronts per block, no block-level synchronisation).  Per j-tile:
-//   stage    the tile's 64 packed records go to wave-private LDS; the next tile's records are already being loaded
-//            (register prefetch, double-buffered LDS) while this one is processed;
-//   phase 1  per lane (= agent i) a 64-bit candidate mask from a conservative float32 distance test on box-relative
+// One WAVEFRONT per (i-tile, share): wavefronts are fully independent (no block-level synchronisation).  NS of them
+// share an i-tile: share `sub` takes the j = sub*64/NS .. (sub+1)*64/NS - 1 of EVERY candidate j-tile (so the shares of
+// a tile carry equal work, whatever the geometry) and writes its partial sums to its own slab of f_pair (k_finish adds
+// the slabs).  Splitting exists for occupancy and balance: a tile's work is one long dependent chain, the chip holds
+// only ~1.5 tiles per SIMD, and the kernel ends with its slowest wavefront.  Per j-tile:
+//   stage    this share's NJ = 64/NS packed records go to wave-private LDS; the next tile's records are already being
+//            loaded (register prefetch) while this one is processed;
+//   phase 1  per lane (= agent i) an NJ-bit candidate mask from a conservative float32 distance test on box-relative
 //            coordinates: packed float2 math, sign bits collected with v_alignbit (3 VALU per j);
-//   compact  candidates are appended to a wave-private LDS list in rank-major order (all lanes' 1st candidate, then
-//            all 2nd ones, ...) with ballot/mbcnt -- no shuffles, and 64 consecutive entries name distinct agents;
-//   phase 2  the list is processed 64 pairs at a time with every lane busy: exact float64 cutoff decision, float32
-//            force, float64 LDS atomic accumulation per agent (at most 2 lanes per address).
+//   compact  candidates are appended to a wave-private LDS list, lane-major (sorted by agent); dense tile pairs
+//            (more than PAIR_LIST_CAP candidates) are taken in rounds of 16 j each;
+//   phase 2  every lane walks a contiguous chunk of the list: exact float64 cutoff decision, float32 force, float64
+//            LDS atomic accumulation when the agent changes.  The list entry and the j record of the NEXT pair are
+//            fetched from LDS while the current pair is evaluated.
+template <int NS>
 __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S, const double* __restrict__ v_des,
-                                          int it, int w, int lane) {
+                                          int it, int sub, int w, int lane) {
+    constexpr int NJ = 64 / NS;                   // j records of a tile handled by this share
+    constexpr int NW = (NJ + 31) / 32;            // 32-bit mask words per lane
+    constexpr int WB = NJ < 32 ? NJ : 32;         // bits used per word
+    constexpr int NROUND = (64 * NJ + PAIR_LIST_CAP - 1) / PAIR_LIST_CAP;     // rounds of 16 j for a dense tile pair
     __shared__ double2 li_pos[4][64];
     __shared__ float4 li_vel[4][64];
     __shared__ float4 li_aux[4][64];              // (hx, hy, 1/b_i^2, 1/v_des_i)
-    __shared__ double2 l_pos[4][2][64];
-    __shared__ float4 l_vel[4][2][64];
-    __shared__ float2 l_head[4][2][64];
-    __shared__ alignas(16) float l_rx[4][2][64];
-    __shared__ alignas(16) float l_ry[4][2][64];
+    __shared__ double2 l_pos[4][NJ];
+    __shared__ float4 l_vel[4][NJ];
+    __shared__ float2 l_head[4][NJ];
+    __shared__ alignas(16) float l_rx[4][NJ];
+    __shared__ alignas(16) float l_ry[4][NJ];
     __shared__ unsigned short l_list[4][PAIR_LIST_CAP];
     __shared__ double l_accx[4][64], l_accy[4][64];
     if (it >= S.ntiles) return;                     // wavefronts are independent: no barrier anywhere
@@ -417,13 +477,14 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
     const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
     const f2v xi2 = {xi_f, xi_f}, yi2 = {yi_f, yi_f};
     unsigned short* lst = l_list[w];
+    const int j0 = sub * NJ;                        // this share's records of a j-tile: j0 .. j0 + NJ - 1
+    const int jl = lane & (NJ - 1);                 // lanes >= NJ duplicate the loads of lanes < NJ (same cache lines)
 
     // candidate tiles: the neighbour list (if valid) or every tile, filtered by the live boxes
     const int32_t* nb = S.nb_list + (size_t)it * (NB_MAX + 1);
     const int nb_cnt = nb[0];
     const bool use_list = (nb_cnt >= 0) && (S.ctrl[C_INVALID] == 0);
     const int nchunk = use_list ? 1 : (S.ntiles + 63) / 64;
-    int buf = 0;
     for (int ch = 0; ch < nchunk; ++ch) {
         int t;
         if (use_list) t = (lane < nb_cnt) ? nb[1 + lane] : -1;
@@ -435,17 +496,20 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
         int jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
         tmask &= tmask - 1;
         JRec cur;
-        cur.pos = S.ppos[jt * 64 + lane];
-        cur.vel = S.pvel[jt * 64 + lane];
-        cur.head = S.phead[jt * 64 + lane];
+        cur.pos = S.ppos[jt * 64 + j0 + jl];
+        cur.vel = S.pvel[jt * 64 + j0 + jl];
+        cur.head = S.phead[jt * 64 + j0 + jl];
         double4 bj = S.tile_box[jt];
         for (;;) {
-            // ---- stage tile jt (registers -> wave-private LDS; LDS ops of one wavefront complete in order)
-            l_pos[w][buf][lane] = cur.pos;
-            l_rx[w][buf][lane] = (float)(cur.pos.x - ox);
-            l_ry[w][buf][lane] = (float)(cur.pos.y - oy);
-            l_vel[w][buf][lane] = cur.vel;
-            l_head[w][buf][lane] = cur.head;
+            // ---- stage this share of tile jt (registers -> wave-private LDS; LDS ops of one wavefront complete in
+            // order, so the single buffer is safe: the previous tile's reads were issued before these writes)
+            if (lane < NJ) {
+                l_pos[w][lane] = cur.pos;
+                l_rx[w][lane] = (float)(cur.pos.x - ox);
+                l_ry[w][lane] = (float)(cur.pos.y - oy);
+                l_vel[w][lane] = cur.vel;
+                l_head[w][lane] = cur.head;
+            }
             // conservative float32 bound: rounding of the relative coordinates scales with the boxes' extent
             const float ext = (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
                                       fmax(fmax(bi.w, bj.w) - oy, oy - fmin(bi.y, bj.y)));
@@ -457,23 +521,23 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
             if (more) {
                 jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
                 tmask &= tmask - 1;
-                cur.pos = S.ppos[jt * 64 + lane];
-                cur.vel = S.pvel[jt * 64 + lane];
-                cur.head = S.phead[jt * 64 + lane];
+                cur.pos = S.ppos[jt * 64 + j0 + jl];
+                cur.vel = S.pvel[jt * 64 + j0 + jl];
+                cur.head = S.phead[jt * 64 + j0 + jl];
                 bj = S.tile_box[jt];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- phase 1: sign(d^2 - c2f) of j = 0..63; j = 32*half + q sits at bit 31 - q of word `half`
-            uint32_t mw[2];
+            // ---- phase 1: sign(d^2 - c2f) of local j = 0..NJ-1; local j = 32*h + q sits at bit 31 - q of word h
+            uint32_t mw[NW];
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int h = 0; h < NW; ++h) {
                 uint32_t acc = 0u;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const float4 xs = *reinterpret_cast<const float4*>(&l_rx[w][buf][32 * half + 4 * g]);
-                    const float4 ys = *reinterpret_cast<const float4*>(&l_ry[w][buf][32 * half + 4 * g]);
+                for (int g = 0; g < WB / 4; ++g) {
+                    const float4 xs = *reinterpret_cast<const float4*>(&l_rx[w][32 * h + 4 * g]);
+                    const float4 ys = *reinterpret_cast<const float4*>(&l_ry[w][32 * h + 4 * g]);
                     const f2v xa = {xs.x, xs.y}, xb = {xs.z, xs.w}, ya = {ys.x, ys.y}, yb = {ys.z, ys.w};
                     const f2v dxa = xa - xi2, dxb = xb - xi2, dya = ya - yi2, dyb = yb - yi2;
                     const f2v ta = __builtin_elementwise_fma(dxa, dxa, __builtin_elementwise_fma(dya, dya, nc2));
@@ -483,215 +547,340 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
                     acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(tb.x), 31);
                     acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(tb.y), 31);
                 }
-                mw[half] = acc;
+                mw[h] = acc << (32 - WB);
             }
-            if (jt_now == it) mw[lane >> 5] &= ~(0x80000000u >> (lane & 31));        // j != i
-            if (i < 0) mw[0] = mw[1] = 0u;
-            // ---- compact, lane-major: exclusive prefix sum of the lanes' candidate counts, every lane appends its own
-            const int cntl = __popc(mw[0]) + __popc(mw[1]);
-            int incl = cntl;
+            if (jt_now == it && (lane / NJ) == sub) mw[jl >> 5] &= ~(0x80000000u >> (jl & 31));        // j != i
+            if (i < 0) {
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += v;
+                for (int h = 0; h < NW; ++h) mw[h] = 0u;
             }
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            {
-                int off = incl - cntl;
-                uint32_t m0 = mw[0], m1 = mw[1];
-                while (m0) {
-                    const int q = __clz((int)m0);
-                    m0 &= ~(0x80000000u >> q);
-                    lst[off++] = (unsigned short)((lane << 8) | q);
-                }
-                while (m1) {
-                    const int q = __clz((int)m1);
-                    m1 &= ~(0x80000000u >> q);
-                    lst[off++] = (unsigned short)((lane << 8) | (32 + q));
-                }
+            // dense tile pairs do not fit the list: rounds of 16 j each (64 x 16 = PAIR_LIST_CAP always fits)
+            int nround = 1;
+            if (NROUND > 1) {
+                int all = 0;
+#pragma unroll
+                for (int h = 0; h < NW; ++h) all += __popc(mw[h]);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) all += __shfl_xor(all, o, 64);
+                if (all > PAIR_LIST_CAP) nround = NROUND;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- phase 2: every lane takes a contiguous chunk of R = ceil(total/64) list entries.  The list is sorted
-            // by agent, so a chunk touches 1-3 agents: their data stays in registers and the forces are summed in
-            // registers; LDS is updated (float64 atomic) only when the agent changes.
-            const int R = (total + 63) >> 6;
-            int e_beg = lane * R, e_end = min(e_beg + R, total);
-            int il_cur = -1;
-            double2 pa = make_double2(0.0, 0.0);
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), aux = va;
-            float sfx = 0.f, sfy = 0.f;
-            for (int r = 0; r < R; ++r) {
-                const int tt = e_beg + r;
-                if (tt < e_end) {
-                    const unsigned e = lst[tt];
-                    const int il = e >> 8, jj = e & 63;
-                    if (il != il_cur) {
-                        if (il_cur >= 0) {
-                            atomicAdd(&l_accx[w][il_cur], (double)sfx);
-                            atomicAdd(&l_accy[w][il_cur], (double)sfy);
+            for (int rd = 0; rd < nround; ++rd) {
+                uint32_t m[NW];
+#pragma unroll
+                for (int h = 0; h < NW; ++h) m[h] = mw[h];
+                if (NROUND > 1 && nround > 1) {     // round rd: local j in [16 rd, 16 rd + 16)
+                    const uint32_t sel = (rd & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+#pragma unroll
+                    for (int h = 0; h < NW; ++h) m[h] = ((rd >> 1) == h) ? (m[h] & sel) : 0u;
+                }
+                // ---- compact, lane-major: exclusive prefix sum of the lanes' candidate counts, every lane appends
+                int cntl = 0;
+#pragma unroll
+                for (int h = 0; h < NW; ++h) cntl += __popc(m[h]);
+                int incl = cntl;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += v;
+                }
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                if (total == 0) continue;
+                {
+                    int off = incl - cntl;
+#pragma unroll
+                    for (int h = 0; h < NW; ++h) {
+                        uint32_t mm = m[h];
+                        while (mm) {
+                            const int q = __clz((int)mm);
+                            mm &= ~(0x80000000u >> q);
+                            lst[off++] = (unsigned short)((lane << 8) | (32 * h + q));
                         }
-                        il_cur = il;
-                        sfx = sfy = 0.f;
-                        pa = li_pos[w][il];
-                        va = li_vel[w][il];
-                        aux = li_aux[w][il];
-                    }
-                    const double2 pb = l_pos[w][buf][jj];
-                    const double ddx = pb.x - pa.x, ddy = pb.y - pa.y;
-                    const double d2 = ddx * ddx + ddy * ddy;
-                    // the reference's decision sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291)
-                    if (d2 <= P.cut_d2max) {
-                        const float2 f = pair_term((float)ddx, (float)ddy, va.x, va.y, va.z, aux.x, aux.y, va.w, aux.z,
-                                                   aux.w, l_vel[w][buf][jj], l_head[w][buf][jj], b_max, db,
-                                                   neg_inv_eta_log2e);
-                        sfx += f.x;
-                        sfy += f.y;
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // ---- phase 2: every lane takes a contiguous chunk of R = ceil(total/64) list entries.  The list is
+                // sorted by agent, so a chunk touches 1-3 agents: their data stays in registers and the forces are
+                // summed in registers; LDS is updated (float64 atomic) only when the agent changes.  Software pipeline:
+                // entry t+2 and the j record of entry t+1 are read while pair t is evaluated (indices are clamped to
+                // the list, so the reads past a chunk's end are harmless).
+                const int R = (total + 63) >> 6;
+                const int e_beg = lane * R, e_end = min(e_beg + R, total), last = total - 1;
+                int il_cur = -1;
+                double2 pa = make_double2(0.0, 0.0);
+                float4 va = make_float4(0.f, 0.f, 0.f, 0.f), aux = va;
+                float sfx = 0.f, sfy = 0.f;
+                unsigned e0 = lst[min(e_beg, last)], e1 = lst[min(e_beg + 1, last)];
+                double2 pb = l_pos[w][e0 & 63];
+                float4 vb = l_vel[w][e0 & 63];
+                float2 hb = l_head[w][e0 & 63];
+                for (int r = 0; r < R; ++r) {
+                    const int tt = e_beg + r;
+                    const unsigned e2 = lst[min(tt + 2, last)];
+                    const double2 pb_n = l_pos[w][e1 & 63];
+                    const float4 vb_n = l_vel[w][e1 & 63];
+                    const float2 hb_n = l_head[w][e1 & 63];
+                    if (tt < e_end) {
+                        const int il = e0 >> 8;
+                        if (il != il_cur) {
+                            if (il_cur >= 0) {
+                                atomicAdd(&l_accx[w][il_cur], (double)sfx);
+                                atomicAdd(&l_accy[w][il_cur], (double)sfy);
+                            }
+                            il_cur = il;
+                            sfx = sfy = 0.f;
+                            pa = li_pos[w][il];
+                            va = li_vel[w][il];
+                            aux = li_aux[w][il];
+                        }
+                        const double ddx = pb.x - pa.x, ddy = pb.y - pa.y;
+                        const double d2 = ddx * ddx + ddy * ddy;
+                        // the reference's decision sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291)
+                        if (d2 <= P.cut_d2max) {
+                            const float2 f = pair_term((float)ddx, (float)ddy, va.x, va.y, va.z, aux.x, aux.y, va.w,
+                                                       aux.z, aux.w, vb, hb, b_max, db, neg_inv_eta_log2e);
+                            sfx += f.x;
+                            sfy += f.y;
+                        }
+                    }
+                    e0 = e1;
+                    e1 = e2;
+                    pb = pb_n;
+                    vb = vb_n;
+                    hb = hb_n;
+                }
+                if (il_cur >= 0) {
+                    atomicAdd(&l_accx[w][il_cur], (double)sfx);
+                    atomicAdd(&l_accy[w][il_cur], (double)sfy);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            if (il_cur >= 0) {
-                atomicAdd(&l_accx[w][il_cur], (double)sfx);
-                atomicAdd(&l_accy[w][il_cur], (double)sfy);
-            }
-            buf ^= 1;
             if (!more) break;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    S.f_pair[k] = make_double2(l_accx[w][lane], l_accy[w][lane]);
+    S.f_pair[(size_t)sub * S.Np + k] = make_double2(l_accx[w][lane], l_accy[w][lane]);
 }
 
 // ---------------------------------------------------------------------------------- wall search over the work-list
-// WG lanes cooperate on one agent: in round o lane `sub` takes row r0 + WG*o + sub upwards and r0 - 1 - WG*o - sub
-// downwards, then the group min-reduces (objective, flat index) so every lane prunes with the group's best.  The
-// serial row chain of the one-lane version (latency-bound, up to ~60 dependent rounds) becomes ~8x shorter.
-#define WG 8
-__device__ __forceinline__ void wall_group(const GcfmParams& P, const Scratch& S, const KeyDev* __restrict__ keys,
-                                           const int32_t* __restrict__ key_of, const double* __restrict__ X0,
-                                           const double* __restrict__ Y0, int cur, int t, int sub, int count) {
-    const bool live = t < count;
-    const int k = live ? S.wall_list[cur][t] : 0;
-    const int i = live ? S.pidx[k] : -1;
-    // (all lanes of a group share t, so `live`/`i` are uniform inside the group; idle groups still shuffle)
-    const int ii = i >= 0 ? i : 0;
-    const KeyDev& kd = keys[i >= 0 ? key_of[ii] : 0];
-    const double2 p = S.ppos[k];
-    const int Nx = P.Nx, Ny = P.Ny;
-    const double hx = P.L / (Nx - 1), hy = P.H / (Ny - 1);
-    double rad2 = 0, ub2 = 0;
-    bool go = (i >= 0) && wall_needed(P, kd, X0, Y0, p.x, p.y, (double)S.pvel[k].z, rad2, ub2);
+// One LANE per agent (the search is a chain of dependent loads, so a wavefront should carry as many agents as it
+// can).  Rows are taken in aligned blocks of 8, outward from the agent's row, 8 blocks each way per round: the round
+// loads the 16 column-gap bounds (gap8, built with the wall map) in one batch, marks the blocks in which some
+// candidate can still win or tie -- lower bound from the vertical distance to the block's nearest row and the smallest
+// column gap of its rows -- and then visits the marked blocks nearest first: 8 table entries in one batch of loads,
+// pass 1 = smallest squared distance (no square roots), pass 2 = the reference's objective for the candidates inside
+// the tie band.  An agent 12 m from a pillar marks 2-3 blocks in 2 rounds instead of walking ~240 rows.
+#define GAP_NONE (1 << 28)
+// lower bound on the squared distance to any candidate of 8-row block `blk`
+__device__ __forceinline__ double wall_block_bound(double py, int blk, int gap, bool prune_ok, int Ny, double hx,
+                                                   const Axis Y0, double& dyb2) {
+    const int rlo = 8 * blk, rhi = min(rlo + 7, Ny - 1);
+    const double ylo = Y0[rlo], yhi = Y0[rhi];
+    const double dyb = (py < ylo) ? ylo - py : (py > yhi ? py - yhi : 0.0);
+    // every candidate of the block: |dy| >= dyb, |dx| >= (gap - 1) hx (the agent sits within one cell of column jx)
+    const double lbh = prune_ok ? (double)max(gap - 1, 0) * hx * (1.0 - 1e-9) : 0.0;
+    dyb2 = dyb * dyb * (1.0 - 1e-12);
+    return dyb2 + lbh * lbh;
+}
+
+// pass 1: smallest squared distance among the block's candidates (no square roots)
+__device__ __forceinline__ double wall_block_min(double px, double py, int blk, const int2 (&c)[8], int Nx, int Ny,
+                                                 const Axis X0, const Axis Y0, double thr, double lim2) {
+    const int rlo = 8 * blk, rhi = min(rlo + 7, Ny - 1);
+    double m = INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = rlo + q;
+        if (r <= rhi) {
+            const double ddy = Y0[r] - py, ady2 = ddy * ddy;
+            if (!(ady2 > thr || ady2 > lim2)) {
+                if (c[q].x >= 0) {
+                    const double ddx = X0[c[q].x] - px;
+                    m = fmin(m, ddx * ddx + ady2);
+                }
+                if (c[q].y < Nx) {
+                    const double ddx = X0[c[q].y] - px;
+                    m = fmin(m, ddx * ddx + ady2);
+                }
+            }
+        }
+    }
+    return m;
+}
+
+// pass 2: the reference's objective fl(fl(sqrt(d2)) + V*10e3) for the candidates that can still win or tie;
+// ties -> lowest flat index (numpy's first minimum)
+__device__ __forceinline__ void wall_block_eval(double px, double py, int blk, const int2 (&c)[8], int Nx, int Ny,
+                                                const Axis X0, const Axis Y0, double off, double thr, double lim2,
+                                                double& best_f, long long& best_flat) {
+    const int rlo = 8 * blk, rhi = min(rlo + 7, Ny - 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = rlo + q;
+        if (r <= rhi) {
+            const double ddy = Y0[r] - py, ady2 = ddy * ddy;
+            if (!(ady2 > thr || ady2 > lim2)) {
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int cnd = side ? c[q].y : c[q].x;
+                    if (cnd < 0 || cnd >= Nx) continue;
+                    const double ddx = X0[cnd] - px;
+                    const double d2 = ddx * ddx + ady2;
+                    if (d2 > thr) continue;
+                    const double f = sqrt(d2) + off;
+                    const long long flat = (long long)r * Nx + cnd;
+                    if (f < best_f || (f == best_f && flat < best_flat)) {
+                        best_f = f;
+                        best_flat = flat;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void wall_lane(const GcfmParams& P, const Scratch& S, const Axis X0, const Axis Y0, int cur,
+                                          int t, int count) {
+    const bool go = t < count;
+    const WEntry& we = S.wall_list[cur][go ? t : 0];
+    const double px = we.px, py = we.py;
+    const int Nx = P.Nx, Ny = P.Ny, nb8 = (Ny + 7) >> 3;
+    const double hx = P.L / (Nx - 1);
+    const double lim2 = we.lim2, off = we.off;
+    const int2* __restrict__ col = we.col;
+    const int32_t* __restrict__ g8 = we.g8;
+    const int k = we.k, b0 = we.b0;
+    const bool prune_ok = we.prune_ok != 0;
     double best_f = INFINITY, best_d2 = INFINITY, thr = INFINITY;
     long long best_flat = -1;
-    int jx = 0, r0 = 0;
-    if (go) {
-        jx = (int)floor(p.x / hx);
-        jx = jx < 0 ? 0 : (jx > Nx - 1 ? Nx - 1 : jx);
-        while (jx > 0 && X0[jx] > p.x) --jx;
-        while (jx < Nx - 1 && X0[jx + 1] <= p.x) ++jx;
-        r0 = (int)floor(p.y / hy + 0.5);
-        r0 = r0 < 0 ? 0 : (r0 > Ny - 1 ? Ny - 1 : r0);
-    }
-    const int2* __restrict__ col = kd.lr + (size_t)jx * Ny;
-    const double lim2 = fmin(rad2, ub2);
     bool up = go, dn = go;
-    for (int o = 0; __any(up || dn); ++o) {
-        if (up || dn) {
-            const int ru = r0 + WG * o + sub, rd = r0 - 1 - WG * o - sub;
-            const bool vu = up && ru < Ny, vd = dn && rd >= 0;
-            const int ruc = vu ? ru : 0, rdc = vd ? rd : 0;
-            const double yu = Y0[ruc], yd = Y0[rdc];
-            const int2 cu = col[ruc], cd = col[rdc];
-            if (vu) {
-                const double ady = fabs(yu - p.y), ady2 = ady * ady;
-                if (!(ady2 > thr || ady2 > lim2)) {
-                    wall_try(p.x, p.y, ru, cu.x, Nx, X0, yu, kd.off, best_d2, thr, best_f, best_flat);
-                    wall_try(p.x, p.y, ru, cu.y, Nx, X0, yu, kd.off, best_d2, thr, best_f, best_flat);
-                }
-            }
-            if (vd) {
-                const double ady = fabs(yd - p.y), ady2 = ady * ady;
-                if (!(ady2 > thr || ady2 > lim2)) {
-                    wall_try(p.x, p.y, rd, cd.x, Nx, X0, yd, kd.off, best_d2, thr, best_f, best_flat);
-                    wall_try(p.x, p.y, rd, cd.y, Nx, X0, yd, kd.off, best_d2, thr, best_f, best_flat);
-                }
-            }
-        }
-        // group reduction: minimum objective, ties -> lowest flat index (numpy's first minimum)
+    for (int o = 0; __any(up || dn); o += 8) {
+        // ---- this round's 16 blocks: slot 2q = up-block b0 + o + q, slot 2q + 1 = down-block b0 - 1 - o - q
+        int gap[16];
 #pragma unroll
-        for (int m = 1; m < WG; m <<= 1) {
-            const double of = __shfl_xor(best_f, m, 64), od2 = __shfl_xor(best_d2, m, 64);
-            const long long ofl = __shfl_xor(best_flat, m, 64);
-            if (of < best_f || (of == best_f && ofl >= 0 && (best_flat < 0 || ofl < best_flat))) {
-                best_f = of;
-                best_flat = ofl;
-            }
-            best_d2 = fmin(best_d2, od2);
+        for (int q = 0; q < 8; ++q) {
+            const int bu = b0 + o + q, bd = b0 - 1 - o - q;
+            gap[2 * q] = (up && bu < nb8) ? g8[bu] : GAP_NONE;
+            gap[2 * q + 1] = (dn && bd >= 0) ? g8[bd] : GAP_NONE;
         }
-        if (best_d2 < INFINITY) thr = best_d2 + 4.8e-10 * sqrt(best_d2) + 1e-19;
-        // next round's nearest rows (group-uniform): stop a direction once its rows cannot matter any more
-        const int nu = r0 + WG * (o + 1), nd = r0 - 1 - WG * (o + 1);
+        uint32_t pending = 0u;
+        const double cut0 = fmin(thr, lim2);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int bu = b0 + o + q, bd = b0 - 1 - o - q;
+            if (up) {
+                if (bu >= nb8) up = false;
+                else {
+                    double dyb2;
+                    const double lb = wall_block_bound(py, bu, gap[2 * q], prune_ok, Ny, hx, Y0, dyb2);
+                    if (dyb2 > cut0) up = false;                    // every farther block is farther still
+                    else if (!(lb > cut0)) pending |= 1u << (2 * q);
+                }
+            }
+            if (dn) {
+                if (bd < 0) dn = false;
+                else {
+                    double dyb2;
+                    const double lb = wall_block_bound(py, bd, gap[2 * q + 1], prune_ok, Ny, hx, Y0, dyb2);
+                    if (dyb2 > cut0) dn = false;
+                    else if (!(lb > cut0)) pending |= 1u << (2 * q + 1);
+                }
+            }
+        }
+        // ---- visit the marked blocks, nearest first (slots are ordered by distance within a direction)
+        while (__any(pending != 0u)) {
+            if (pending) {
+                const int slot = __ffs((int)pending) - 1;
+                pending &= pending - 1u;
+                const int q = slot >> 1;
+                const int blk = (slot & 1) ? b0 - 1 - o - q : b0 + o + q;
+                int gsel = GAP_NONE;
+#pragma unroll
+                for (int z = 0; z < 16; ++z) gsel = (z == slot) ? gap[z] : gsel;
+                double dyb2;
+                const double lb = wall_block_bound(py, blk, gsel, prune_ok, Ny, hx, Y0, dyb2);
+                const double cut = fmin(thr, lim2);
+                if (dyb2 > cut) {                                   // this direction is finished
+                    if (slot & 1) { dn = false; pending &= 0x55555555u; }
+                    else { up = false; pending &= 0xAAAAAAAAu; }
+                } else if (!(lb > cut)) {
+                    const int rlo = 8 * blk, rhi = min(rlo + 7, Ny - 1);
+                    int2 c[8];                                      // the block's table entries: one batch of loads
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) c[z] = col[min(rlo + z, rhi)];
+                    best_d2 = fmin(best_d2, wall_block_min(px, py, blk, c, Nx, Ny, X0, Y0, thr, lim2));
+                    // anything farther than thr cannot tie after the rounding of sqrt(d2) + off at ulp(1e6)
+                    if (best_d2 < INFINITY) thr = best_d2 + 4.8e-10 * sqrt(best_d2) + 1e-19;
+                    wall_block_eval(px, py, blk, c, Nx, Ny, X0, Y0, off, thr, lim2, best_f, best_flat);
+                }
+            }
+        }
+        // ---- next round's nearest rows: stop a direction once its rows cannot matter any more
+        const double cut = fmin(thr, lim2);
+        const int nu = b0 + o + 8, nd = b0 - 1 - o - 8;
         if (up) {
-            if (nu >= Ny) up = false;
+            if (nu >= nb8) up = false;
             else {
-                const double yy = Y0[nu], a2 = (yy - p.y) * (yy - p.y);
-                if (yy > p.y && (a2 > thr || a2 > lim2)) up = false;
+                const double yy = Y0[8 * nu], a2 = (yy - py) * (yy - py);
+                if (yy > py && a2 > cut) up = false;
             }
         }
         if (dn) {
             if (nd < 0) dn = false;
             else {
-                const double yy = Y0[nd], a2 = (yy - p.y) * (yy - p.y);
-                if (yy < p.y && (a2 > thr || a2 > lim2)) dn = false;
+                const double yy = Y0[min(8 * nd + 7, Ny - 1)], a2 = (yy - py) * (yy - py);
+                if (yy < py && a2 > cut) dn = false;
             }
         }
     }
-    if (i >= 0 && sub == 0) S.widx[k] = best_flat;
+    if (go) S.widx[k] = best_flat;
 }
 
 // standalone wall search (diagnostic exports)
 __global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
-                                             const int32_t* __restrict__ key_of, const double* __restrict__ X0,
-                                             const double* __restrict__ Y0, int cur) {
-    wall_group(P, S, keys, key_of, X0, Y0, cur, (blockIdx.x * 64 + threadIdx.x) / WG, threadIdx.x & (WG - 1),
-               S.ctrl[C_WCOUNT + cur]);
+                                             const int32_t* __restrict__ key_of, const Axis X0,
+                                             const Axis Y0, int cur) {
+    wall_lane(P, S, X0, Y0, cur, blockIdx.x * 64 + threadIdx.x, S.ctrl[C_WCOUNT + cur]);
 }
 
 // standalone pair forces (diagnostic exports): 4 independent wavefronts per block
-__global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, const double* __restrict__ v_des) {
-    pair_wave(P, S, v_des, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x >> 6, threadIdx.x & 63);
+__global__ void __launch_bounds__(256, 4) k_pair(GcfmParams P, Scratch S, const double* __restrict__ v_des) {
+    pair_wave<1>(P, S, v_des, blockIdx.x * 4 + (threadIdx.x >> 6), 0, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
-// The step's force kernel: horizontal fusion of the pair forces and the wall search.  A 512-thread block carries
-// 4 pair wavefronts (one i-tile each, LDS) and 4 wall-search wavefronts (no LDS) that sweep the wall work-list; the
-// two kinds never synchronise, so the short wall search hides entirely beside the pair work without a second
-// stream (cross-stream event waits cost ~15 us per dependency on this platform).
-__global__ void __launch_bounds__(512, 4) k_forces(GcfmParams P, Scratch S, const double* __restrict__ v_des,
+// The step's force kernel: horizontal fusion of the pair forces and the wall search in one launch (a second stream
+// costs ~15 us per cross-stream dependency on this platform).  Blocks of 4 independent wavefronts; the first
+// `nwall` blocks sweep the wall work-list (they are dispatched first and finish early), every other block carries
+// 4 pair wavefronts: wavefront gw handles i-tile gw / nsplit, share gw % nsplit.  128 registers and 9 KB of LDS per
+// pair wavefront keep 4 wavefronts per SIMD resident, i.e. every (tile, share) of C4 at nsplit = 2 is in flight at once.
+template <int NS>
+__global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, const double* __restrict__ v_des,
                                                 const KeyDev* __restrict__ keys, const int32_t* __restrict__ key_of,
-                                                const double* __restrict__ X0, const double* __restrict__ Y0, int cur,
-                                                int nxt, int32_t* __restrict__ cnt_out) {
+                                                const Axis X0, const Axis Y0, int cur,
+                                                int nxt, int32_t* __restrict__ cnt_out, int nwall) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) {      // this step's counters (k_finish adds to them later in the stream)
         cnt_out[0] = cnt_out[1] = cnt_out[2] = cnt_out[3] = 0;
         S.ctrl[C_WCOUNT + nxt] = 0;
     }
-    if (w < 4) {
-        pair_wave(P, S, v_des, blockIdx.x * 4 + w, w, lane);
+    if ((int)blockIdx.x >= nwall) {
+        const int gw = ((int)blockIdx.x - nwall) * 4 + w;
+        pair_wave<NS>(P, S, v_des, gw / NS, gw % NS, w, lane);
     } else {
         const int count = S.ctrl[C_WCOUNT + cur];
-        const int per_wave = 64 / WG;                               // agents per wavefront and round
-        const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + (w - 4);
-        for (int base = gw * per_wave; base < count; base += nwaves * per_wave)
-            wall_group(P, S, keys, key_of, X0, Y0, cur, base + lane / WG, lane & (WG - 1), count);
+        const int nwaves = nwall * 4, gw = blockIdx.x * 4 + w;
+        for (int base = gw * 64; base < count; base += nwaves * 64) wall_lane(P, S, X0, Y0, cur, base + lane, count);
     }
 }
 
 // capped exact distance transform of the site set on the grid nodes (init-time, one thread per node)
 __global__ void __launch_bounds__(256) k_edt(const int2* __restrict__ lr, int Nx, int Ny, double hx, double hy,
-                                             const double* __restrict__ X0, const double* __restrict__ Y0, double cap,
+                                             const Axis X0, const Axis Y0, double cap,
                                              float* __restrict__ edt) {
     int j = blockIdx.x * 64 + (threadIdx.x & 63);
     int i = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -794,11 +983,12 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const Ke
                                                double* __restrict__ vy, const double* __restrict__ v_des,
                                                uint8_t* __restrict__ status, double* __restrict__ agent_time,
                                                const double* __restrict__ noise, uint64_t seed, int step,
-                                               const double* __restrict__ X0, const double* __restrict__ Y0, int nxt,
-                                               int32_t* __restrict__ cnt_out) {
+                                               const Axis X0, const Axis Y0, int nxt,
+                                               int32_t* __restrict__ cnt_out, int nsplit) {
     const int k = blockIdx.x * 64 + threadIdx.x;
     const int i = S.pidx[k];
     bool act = i >= 0, out = false, need = false;
+    WEntry we;
     double nx = 1e300, ny = 1e300;
     if (act) {
         const KeyDev& kd = keys[key_of[i]];
@@ -806,7 +996,12 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const Ke
         const double vxd = vx[i], vyd = vy[i], vd = v_des[i];
         // desired velocity, repulsions
         const double2 ds = lookup(P, kd, p.x, p.y, vd, step, i, &cnt_out[C_ERR]);
-        const double2 fp = S.f_pair[k];
+        double2 fp = S.f_pair[k];
+        for (int q = 1; q < nsplit; ++q) {                  // partial sums of the tile's pair wavefronts
+            const double2 fq = S.f_pair[(size_t)q * S.Np + k];
+            fp.x += fq.x;
+            fp.y += fq.y;
+        }
         const double2 fw = wall_force_of(P, S.widx[k], p.x, p.y, vxd, vyd, vd, X0, Y0);
         // noise: caller's standard normals, or Philox4x32-10 + Box-Muller (float32)
         double n0, n1;
@@ -858,8 +1053,7 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const Ke
             S.ppos[k] = make_double2(nx, ny);
             S.pvel[k] = pv;
             S.phead[k] = ph;
-            double r2, u2;
-            need = wall_needed(P, kd, X0, Y0, nx, ny, (double)pv.z, r2, u2);
+            need = wall_prepare(P, kd, X0, Y0, nx, ny, (double)pv.z, k, we);
         }
         S.widx[k] = -1;
     }
@@ -869,7 +1063,7 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const Ke
     const int lane = threadIdx.x;
     if (m_out && lane == __ffsll((long long)m_out) - 1) atomicAdd(&cnt_out[C_EXIT], __popcll(m_out));
     if (m_in && lane == __ffsll((long long)m_in) - 1) atomicAdd(&cnt_out[C_ACTIVE], __popcll(m_in));
-    wall_list_push(need, k, S.wall_list[nxt], &S.ctrl[C_WCOUNT + nxt]);
+    wall_list_push(need, we, S.wall_list[nxt], &S.ctrl[C_WCOUNT + nxt]);
     // tile box of the new positions + validity of the neighbour lists
     double mnx = wmin(stay ? nx : INFINITY), mny = wmin(stay ? ny : INFINITY);
     double mxx = wmax(stay ? nx : -INFINITY), mxy = wmax(stay ? ny : -INFINITY);
@@ -897,8 +1091,8 @@ __global__ void k_lookup_diag(GcfmParams P, Scratch S, const KeyDev* __restrict_
 }
 
 __global__ void k_wall_force_diag(GcfmParams P, Scratch S, const double* __restrict__ vx, const double* __restrict__ vy,
-                                  const double* __restrict__ v_des, const double* __restrict__ X0,
-                                  const double* __restrict__ Y0) {
+                                  const double* __restrict__ v_des, const Axis X0,
+                                  const Axis Y0) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= S.Np) return;
     int i = S.pidx[k];
@@ -936,7 +1130,29 @@ __global__ void k_wallmap(const float* __restrict__ V, float vmin, int Ny, int N
     }
 }
 
+// gap8[j][b] = min over rows 8b..8b+7 of min(j - left site column, right site column - j) (GAP_NONE: no site at all)
+__global__ void __launch_bounds__(256) k_gap8(const int2* __restrict__ lr, int Nx, int Ny, int32_t* __restrict__ gap8) {
+    const int nb8 = (Ny + 7) >> 3;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)Nx * nb8) return;
+    const int j = (int)(t / nb8), b = (int)(t % nb8);
+    int g = GAP_NONE;
+    for (int r = 8 * b; r < min(8 * b + 8, Ny); ++r) {
+        const int2 c = lr[(size_t)j * Ny + r];
+        if (c.x >= 0) g = min(g, j - c.x);
+        if (c.y < Nx) g = min(g, c.y - j);
+    }
+    gap8[t] = g;
+}
+
 // ---------------------------------------------------------------------------------- host helpers
+Axis axis_x(const oc_handle* h) {
+    return Axis{h->X0, h->cfg.room_length / (h->cfg.Nx - 1), h->cfg.room_length, h->cfg.Nx, h->axes_linspace ? 1 : 0};
+}
+Axis axis_y(const oc_handle* h) {
+    return Axis{h->Y0, h->cfg.room_height / (h->cfg.Ny - 1), h->cfg.room_height, h->cfg.Ny, h->axes_linspace ? 1 : 0};
+}
+
 GcfmParams make_params(const oc_handle* h) {
     const oc_config& c = h->cfg;
     GcfmParams P;
@@ -970,7 +1186,7 @@ int carve(oc_handle* h, int N, Scratch* S) {
     if (Np == 0) Np = 64;
     const int nt = Np / 64;
     size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + sizeof(double2) + sizeof(float4) + sizeof(float2) +
-                 sizeof(int32_t) + 3 * sizeof(double2) + sizeof(long long) + 2 * sizeof(int32_t);
+                 sizeof(int32_t) + (2 + PAIR_SPLIT_MAX) * sizeof(double2) + sizeof(long long) + 2 * sizeof(WEntry);
     size_t need = per * (size_t)Np + (2 * sizeof(double4) + (NB_MAX + 1) * sizeof(int32_t)) * (size_t)nt + 64 + 8192;
     if (need > h->gcfm_bytes) {
         if (h->gcfm_buf) OC_HIP_CHECK(hipFree(h->gcfm_buf));
@@ -987,7 +1203,7 @@ int carve(oc_handle* h, int N, Scratch* S) {
     };
     S->ppos = (double2*)take(sizeof(double2) * Np);
     S->pvel = (float4*)take(sizeof(float4) * Np);
-    S->f_pair = (double2*)take(sizeof(double2) * Np);
+    S->f_pair = (double2*)take(sizeof(double2) * Np * PAIR_SPLIT_MAX);     // one slab per share of a tile
     S->f_wall = (double2*)take(sizeof(double2) * Np);
     S->des = (double2*)take(sizeof(double2) * Np);
     S->tile_box = (double4*)take(sizeof(double4) * nt);
@@ -999,8 +1215,8 @@ int carve(oc_handle* h, int N, Scratch* S) {
     S->vals_a = (int32_t*)take(sizeof(int32_t) * Np);
     S->vals_b = (int32_t*)take(sizeof(int32_t) * Np);
     S->pidx = (int32_t*)take(sizeof(int32_t) * Np);
-    S->wall_list[0] = (int32_t*)take(sizeof(int32_t) * Np);
-    S->wall_list[1] = (int32_t*)take(sizeof(int32_t) * Np);
+    S->wall_list[0] = (WEntry*)take(sizeof(WEntry) * Np);
+    S->wall_list[1] = (WEntry*)take(sizeof(WEntry) * Np);
     S->nb_list = (int32_t*)take(sizeof(int32_t) * (NB_MAX + 1) * (size_t)nt);
     S->ctrl = (int32_t*)take(64);
     S->Np = Np;
@@ -1022,6 +1238,7 @@ int upload_keys(oc_handle* h, hipStream_t s) {
         d.nt_opt = h->fields[k].vx ? h->fields[k].nt_opt : 0;
         d.lr = (const int2*)h->wallmaps[k].left;
         d.edt = (const float*)h->wallmaps[k].right;
+        d.gap8 = (const int32_t*)h->wallmaps[k].gap8;
         d.off = h->wallmaps[k].off;
         d.edt_cap = h->wallmaps[k].edt_cap;
         d.nrect = h->rects[k].n;
@@ -1060,7 +1277,7 @@ int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hi
     }
     const KeyDev* kd = wallmaps_ready(h) ? (const KeyDev*)h->key_tables_dev : nullptr;
     hipLaunchKernelGGL(k_pack, dim3(S->ntiles), dim3(64), 0, s, a->x, a->y, a->vx, a->vy, a->status, a->key, S->vals_b, N,
-                       P, *S, kd, h->X0, h->Y0, h->wl_parity);
+                       P, *S, kd, axis_x(h), axis_y(h), h->wl_parity);
     hipLaunchKernelGGL(k_tile_lists, dim3(S->ntiles), dim3(64), 0, s, P, *S);
     h->steps_since_sort = 0;
     h->packed_x = a->x;
@@ -1088,12 +1305,16 @@ extern "C" int oc_wallmap_build(oc_handle* h, int key, const float* V, float vmi
     if (!w.right) OC_HIP_CHECK(hipMalloc((void**)&w.right, sizeof(float) * (size_t)h->ncell));
     const oc_config& c = h->cfg;
     hipLaunchKernelGGL(k_wallmap, dim3((c.Ny + 63) / 64), dim3(64), 0, s, V, vmin, c.Ny, c.Nx, (int2*)w.left);
+    const size_t n8 = (size_t)c.Nx * ((c.Ny + 7) / 8);
+    if (!w.gap8) OC_HIP_CHECK(hipMalloc((void**)&w.gap8, sizeof(int32_t) * n8));
+    hipLaunchKernelGGL(k_gap8, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, (const int2*)w.left, c.Nx, c.Ny,
+                       (int32_t*)w.gap8);
     // cap: no per-agent search radius exceeds a(v_max)^2 + eta_w (1 + v_max) * 33 (wall_radius_of)
     double amax = c.a_min + c.tau_a * c.v_max;
     w.edt_cap = amax * amax + c.eta_walls * (1.0 + c.v_max) * 33.0 + 1.0;
     if (c.wall_search_radius > 0) w.edt_cap = std::max(w.edt_cap, c.wall_search_radius + 1.0);
     hipLaunchKernelGGL(k_edt, dim3((c.Nx + 63) / 64, (c.Ny + 3) / 4), dim3(256), 0, s, (const int2*)w.left, c.Nx, c.Ny,
-                       c.room_length / (c.Nx - 1), c.room_height / (c.Ny - 1), h->X0, h->Y0, w.edt_cap,
+                       c.room_length / (c.Nx - 1), c.room_height / (c.Ny - 1), axis_x(h), axis_y(h), w.edt_cap,
                        (float*)w.right);
     OC_HIP_CHECK(hipGetLastError());
     w.off = (double)vmin * 10e3;
@@ -1149,10 +1370,10 @@ extern "C" int oc_wall_force(oc_handle* h, const oc_agents* a, int64_t* index_ou
     GcfmParams P;
     if ((rc = prepare(h, a, &S, &P, s))) return rc;
     h->packed_valid = false;
-    hipLaunchKernelGGL(k_wall, dim3(S.ntiles * WG), dim3(64), 0, s, P, S, (const KeyDev*)h->key_tables_dev, a->key,
-                       h->X0, h->Y0, h->wl_parity);
+    hipLaunchKernelGGL(k_wall, dim3(S.ntiles), dim3(64), 0, s, P, S, (const KeyDev*)h->key_tables_dev, a->key,
+                       axis_x(h), axis_y(h), h->wl_parity);
     hipLaunchKernelGGL(k_wall_force_diag, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, a->vx, a->vy, a->v_des,
-                       h->X0, h->Y0);
+                       axis_x(h), axis_y(h));
     if (index_out) {
         OC_HIP_CHECK(hipMemsetAsync(index_out, 0xFF, sizeof(int64_t) * (size_t)a->N, s));
         hipLaunchKernelGGL(k_scatter<long long>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.widx, S.pidx, S.Np,
@@ -1206,12 +1427,15 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     const int cur = h->wl_parity, nxt = 1 - cur;
     int32_t* cnt = counters ? counters : S.ctrl;
     oc_timer_begin(h, "gcfm_pair", s);
-    hipLaunchKernelGGL(k_forces, dim3((S.ntiles + 3) / 4), dim3(512), 0, s, P, S, a->v_des, kd, a->key, h->X0, h->Y0, cur,
-                       nxt, cnt);
+    const int nsplit = h->pair_split;
+    const int npair = (S.ntiles * nsplit + 3) / 4, nwall = std::min(std::max(S.ntiles / 8, 1), h->wall_blocks);
+    auto kf = nsplit == 4 ? k_forces<4> : (nsplit == 2 ? k_forces<2> : k_forces<1>);
+    hipLaunchKernelGGL(kf, dim3(nwall + npair), dim3(256), 0, s, P, S, a->v_des, kd, a->key, axis_x(h), axis_y(h), cur,
+                       nxt, cnt, nwall);
     oc_timer_end(h, "gcfm_pair", s);
     oc_timer_begin(h, "gcfm_finish", s);
     hipLaunchKernelGGL(k_finish, dim3(S.ntiles), dim3(64), 0, s, P, S, kd, a->key, a->x, a->y, a->vx, a->vy, a->v_des,
-                       a->status, a->agent_time, noise, seed, simu_step, h->X0, h->Y0, nxt, cnt);
+                       a->status, a->agent_time, noise, seed, simu_step, axis_x(h), axis_y(h), nxt, cnt, nsplit);
     oc_timer_end(h, "gcfm_finish", s);
     OC_HIP_CHECK(hipGetLastError());
     h->wl_parity = nxt;

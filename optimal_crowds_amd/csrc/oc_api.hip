@@ -41,6 +41,16 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
     OC_HIP_CHECK(hipMalloc(&h->Y0, sizeof(double) * cfg->Ny));
     OC_HIP_CHECK(hipMemcpy(h->X0, X0_host, sizeof(double) * cfg->Nx, hipMemcpyHostToDevice));
     OC_HIP_CHECK(hipMemcpy(h->Y0, Y0_host, sizeof(double) * cfg->Ny, hipMemcpyHostToDevice));
+    {   // np.linspace(0, len, n): fl(j * step), last element = len (gcfm.hip: struct Axis)
+        auto is_linspace = [](const double* a, int n, double len) {
+            if (n < 2) return false;
+            const double step = len / (n - 1);
+            for (int j = 0; j < n - 1; ++j)
+                if (a[j] != (double)j * step) return false;
+            return a[n - 1] == len;
+        };
+        h->axes_linspace = is_linspace(X0_host, cfg->Nx, cfg->room_length) && is_linspace(Y0_host, cfg->Ny, cfg->room_height);
+    }
     h->red_blocks = std::max(1024, ((cfg->Nx + 63) / 64) * ((cfg->Ny + 15) / 16));
     OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * 2 * h->red_blocks));
     OC_HIP_CHECK(hipMalloc(&h->red_out, sizeof(double) * 16));
@@ -65,6 +75,7 @@ extern "C" int oc_destroy(oc_handle* h) {
     for (auto& w : h->wallmaps) {
         (void)hipFree(w.left);
         (void)hipFree(w.right);
+        (void)hipFree(w.gap8);
     }
     (void)hipFree(h->key_tables_dev);
     (void)hipFree(h->gcfm_buf);
@@ -176,6 +187,21 @@ extern "C" int oc_set_key_targets(oc_handle* h, int key, const double* rects, in
     for (int i = 0; i < n; ++i)
         for (int c = 0; c < 4; ++c) h->rects[key].r[i][c] = rects[4 * i + c];
     h->key_tables_dirty = true;
+    return OC_OK;
+}
+
+extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
+    OC_REQUIRE(h && name, "null argument");
+    if (!strcmp(name, "pair_split")) {
+        OC_REQUIRE(value == 1 || value == 2 || value == 4, "pair_split must be 1, 2 or 4");
+        h->pair_split = value;
+    } else if (!strcmp(name, "wall_blocks")) {
+        OC_REQUIRE(value >= 1 && value <= 4096, "wall_blocks out of range");
+        h->wall_blocks = value;
+    } else {
+        oc_set_error("oc_set_tuning: unknown knob '%s'", name);
+        return OC_ERR_ARG;
+    }
     return OC_OK;
 }
 

@@ -40,6 +40,7 @@ struct oc_field_desc {
 struct oc_wallmap {
     void* left = nullptr;       // int2 [Nx][Ny]: (nearest site column <= j or -1, nearest site column >= j+1 or Nx)
     void* right = nullptr;      // float (Ny,Nx): capped distance from each grid node to the nearest site
+    void* gap8 = nullptr;       // int32 [Nx][ceil(Ny/8)]: smallest column gap to a site within 8 grid rows
     double edt_cap = 0.0;
     double off = 0.0;           // vmin * 10e3 (the reference adds V*10e3 before the argmin)
     bool built = false;
@@ -64,6 +65,7 @@ struct oc_handle {
     int64_t ncell = 0;
     double* X0 = nullptr;       // device (Nx)
     double* Y0 = nullptr;       // device (Ny)
+    bool axes_linspace = false; // X0, Y0 are exactly np.linspace(0, L, Nx), np.linspace(0, H, Ny)
     // ---- HJB scratch (allocated lazily per dtype size)
     size_t hjb_bytes = 0;       // size of the scratch below
     void* hjb_buf = nullptr;    // y, ynew, ytmp, K0..K6, phi_tmp  (11 arrays)
@@ -84,7 +86,8 @@ struct oc_handle {
     bool packed_valid = false;  // the packed snapshot matches the caller's state arrays
     const void* packed_x = nullptr;
     int32_t packed_N = -1;
-    int pair_grid = 1024;       // k_pair blocks (8 per CU x 256 CUs at most resident); tiles are pulled from a queue
+    int pair_split = 4;         // pair wavefronts per i-tile (1, 2 or 4): occupancy of k_forces (gcfm.hip)
+    int wall_blocks = 128;      // blocks of k_forces that sweep the wall work-list
     hipStream_t aux_stream = nullptr;   // k_wall runs here, beside k_pair
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int wl_parity = 0;          // which wall work-list the next step consumes

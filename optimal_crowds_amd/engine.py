@@ -102,6 +102,10 @@ class Engine:
     def set_hjb_variant(self, variant):
         check(self.lib.oc_set_hjb_variant(self.h, int(variant)))
 
+    def set_tuning(self, name, value):
+        """Launch-shape knobs of the step kernels (oc_hip.h: oc_set_tuning)."""
+        check(self.lib.oc_set_tuning(self.h, name.encode(), int(value)))
+
     # ------------------------------------------------------------------ per-key data
     def set_potential(self, key, V_host, rects):
         """V_host: finalised potential (Ny,Nx) float64 of key; rects: (n,4) exit rectangles of its targets."""
