@@ -383,33 +383,54 @@ __global__ void __launch_bounds__(64) k_tile_lists(GcfmParams P, Scratch S) {
 // ---------------------------------------------------------------------------------- pair forces
 #define COS_VISION (-0.58778525229247312917f)   // cos(0.7 pi), pedestrians.py:262
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+
 // force of j on i (pedestrians.py:242-280) in trig-free form: cos(alpha-beta) = e.h, sin = h x e.
 // float32 with hardware rcp/rsq/exp2 (1 ulp); R is the float64-differenced relative vector rounded to float32.
-__device__ __forceinline__ float2 pair_term(float Rx, float Ry, float vxi, float vyi, float si, float hxi, float hyi,
-                                            float ia2_i, float ib2_i, float inv_vdes_i, float4 vj, float2 hj,
-                                            float b_max, float db, float neg_inv_eta_log2e) {
-    float r2 = __builtin_fmaf(Rx, Rx, Ry * Ry);
-    float inv_r = __builtin_amdgcn_rsqf(r2);
-    float r = r2 * inv_r;
-    float ex = Rx * inv_r, ey = Ry * inv_r;
+// TWO pairs (i, jA), (i, jB) of the same agent i per call, one in each half of packed float2 registers: a plain
+// float32 VALU instruction occupies the SIMD for 4 cycles per wavefront, v_pk_fma/mul/add_f32 do two lanes' worth in
+// the same 4 -- the kernel is VALU-issue-bound (PMC: VALU active 2/3 of the time), so packing is what pays.
+__device__ __forceinline__ void pair_term2(f2v Rx, f2v Ry, float vxi, float vyi, float si, float hxi, float hyi,
+                                           float ia2_i, float ib2_i, float inv_vdes_i, f2v vjx, f2v vjy, f2v sj,
+                                           f2v ia2_j, f2v hjx, f2v hjy, float b_max, float db,
+                                           float neg_inv_eta_log2e, f2v& fx, f2v& fy) {
+    const f2v one = {1.f, 1.f}, zero = {0.f, 0.f};
+    const f2v r2 = __builtin_elementwise_fma(Rx, Rx, Ry * Ry);
+    const f2v inv_r = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+    const f2v r = r2 * inv_r, ex = Rx * inv_r, ey = Ry * inv_r;
     // closing speed (pedestrians.py:254-255)
-    float vrel = fmaxf(__builtin_fmaf(vxi - vj.x, ex, (vyi - vj.y) * ey), 0.f);
+    const f2v vxi2 = {vxi, vxi}, vyi2 = {vyi, vyi};
+    const f2v vrel = __builtin_elementwise_max(__builtin_elementwise_fma(vxi2 - vjx, ex, (vyi2 - vjy) * ey), zero);
     // ellipse radii along the centre line (pedestrians.py:266-271)
-    float ci = __builtin_fmaf(ex, hxi, ey * hyi), sn_i = __builtin_fmaf(hxi, ey, -hyi * ex);
+    const f2v hxi2 = {hxi, hxi}, hyi2 = {hyi, hyi};
+    const f2v ci = __builtin_elementwise_fma(ex, hxi2, ey * hyi2);
+    const f2v sn_i = __builtin_elementwise_fma(hxi2, ey, -(hyi2 * ex));
     // vision factor (pedestrians.py:259-262): v_i.e/|v_i| = h_i.e when |v_i| > 0
-    float k = (si > 0.f) ? fmaxf(ci - COS_VISION, 0.f) * (1.f / (1.f - COS_VISION)) : 0.f;
-    float q_i = __builtin_amdgcn_rsqf(__builtin_fmaf(ci * ci, ia2_i, sn_i * sn_i * ib2_i));
-    float b_j = __builtin_fmaf(-db, fminf(vj.z * inv_vdes_i, 1.f), b_max);          // Q6: i's v_des
-    float ib2_j = __builtin_amdgcn_rcpf(b_j * b_j);
-    float cj = __builtin_fmaf(ex, hj.x, ey * hj.y), sn_j = __builtin_fmaf(hj.x, ey, -hj.y * ex);
-    float q_j = __builtin_amdgcn_rsqf(__builtin_fmaf(cj * cj, vj.w, sn_j * sn_j * ib2_j));
-    float dist = r - q_i - q_j;
-    float rep = fminf(k * __builtin_amdgcn_exp2f(dist * neg_inv_eta_log2e * __builtin_amdgcn_rcpf(1.f + vrel)), 1.f);
-    return make_float2(-rep * Rx, -rep * Ry);
+    const f2v cv = {COS_VISION, COS_VISION};
+    const float kscale = (si > 0.f) ? (1.f / (1.f - COS_VISION)) : 0.f;
+    const f2v kk = __builtin_elementwise_max(ci - cv, zero) * (f2v){kscale, kscale};
+    const f2v ai = __builtin_elementwise_fma(ci * ci, (f2v){ia2_i, ia2_i}, sn_i * sn_i * (f2v){ib2_i, ib2_i});
+    const f2v q_i = {__builtin_amdgcn_rsqf(ai.x), __builtin_amdgcn_rsqf(ai.y)};
+    const f2v b_j = __builtin_elementwise_fma((f2v){-db, -db},
+                                              __builtin_elementwise_min(sj * (f2v){inv_vdes_i, inv_vdes_i}, one),
+                                              (f2v){b_max, b_max});                      // Q6: i's v_des
+    const f2v bj2 = b_j * b_j;
+    const f2v ib2_j = {__builtin_amdgcn_rcpf(bj2.x), __builtin_amdgcn_rcpf(bj2.y)};
+    const f2v cj = __builtin_elementwise_fma(ex, hjx, ey * hjy);
+    const f2v sn_j = __builtin_elementwise_fma(hjx, ey, -(hjy * ex));
+    const f2v aj = __builtin_elementwise_fma(cj * cj, ia2_j, sn_j * sn_j * ib2_j);
+    const f2v q_j = {__builtin_amdgcn_rsqf(aj.x), __builtin_amdgcn_rsqf(aj.y)};
+    const f2v dist = r - q_i - q_j;
+    const f2v den = one + vrel;
+    const f2v arg = dist * (f2v){neg_inv_eta_log2e, neg_inv_eta_log2e} *
+                    (f2v){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const f2v ex2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+    const f2v rep = __builtin_elementwise_min(kk * ex2, one);
+    fx = -(rep * Rx);
+    fy = -(rep * Ry);
 }
 
-typedef float f2v __attribute__((ext_vector_type(2)));
-#define PAIR_LIST_CAP 1024      // 64 x 16: a quarter of a tile pair always fits
+#define PAIR_LIST_CAP 1024      // list entries (two candidates of one agent each): 64 agents x 32 j always fit
 #define PAIR_SPLIT_MAX 4
 
 struct JRec {                   // one lane's share of a staged j-tile (prefetched into registers)
@@ -438,7 +459,7 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
     constexpr int NJ = 64 / NS;                   // j records of a tile handled by this share
     constexpr int NW = (NJ + 31) / 32;            // 32-bit mask words per lane
     constexpr int WB = NJ < 32 ? NJ : 32;         // bits used per word
-    constexpr int NROUND = (64 * NJ + PAIR_LIST_CAP - 1) / PAIR_LIST_CAP;     // rounds of 16 j for a dense tile pair
+    constexpr int NROUND = NW;                    // rounds of 32 j for a dense tile pair
     __shared__ double2 li_pos[4][64];
     __shared__ float4 li_vel[4][64];
     __shared__ float4 li_aux[4][64];              // (hx, hy, 1/b_i^2, 1/v_des_i)
@@ -447,7 +468,7 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
     __shared__ float2 l_head[4][NJ];
     __shared__ alignas(16) float l_rx[4][NJ];
     __shared__ alignas(16) float l_ry[4][NJ];
-    __shared__ unsigned short l_list[4][PAIR_LIST_CAP];
+    __shared__ uint32_t l_list[4][PAIR_LIST_CAP];
     __shared__ double l_accx[4][64], l_accy[4][64];
     if (it >= S.ntiles) return;                     // wavefronts are independent: no barrier anywhere
     const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
@@ -476,7 +497,7 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
     const double ox = bi.x, oy = bi.y;             // origin of the box-relative float32 coordinates
     const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
     const f2v xi2 = {xi_f, xi_f}, yi2 = {yi_f, yi_f};
-    unsigned short* lst = l_list[w];
+    uint32_t* lst = l_list[w];
     const int j0 = sub * NJ;                        // this share's records of a j-tile: j0 .. j0 + NJ - 1
     const int jl = lane & (NJ - 1);                 // lanes >= NJ duplicate the loads of lanes < NJ (same cache lines)
 
@@ -554,12 +575,14 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
 #pragma unroll
                 for (int h = 0; h < NW; ++h) mw[h] = 0u;
             }
-            // dense tile pairs do not fit the list: rounds of 16 j each (64 x 16 = PAIR_LIST_CAP always fits)
+            // list entries hold TWO candidates of one agent (an odd last one is paired with itself, masked).  Dense
+            // tile pairs do not fit the list: rounds of 32 j each (64 agents x 16 entries = PAIR_LIST_CAP always fit)
             int nround = 1;
             if (NROUND > 1) {
                 int all = 0;
 #pragma unroll
                 for (int h = 0; h < NW; ++h) all += __popc(mw[h]);
+                all = (all + 1) >> 1;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) all += __shfl_xor(all, o, 64);
                 if (all > PAIR_LIST_CAP) nround = NROUND;
@@ -567,16 +590,12 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
             for (int rd = 0; rd < nround; ++rd) {
                 uint32_t m[NW];
 #pragma unroll
-                for (int h = 0; h < NW; ++h) m[h] = mw[h];
-                if (NROUND > 1 && nround > 1) {     // round rd: local j in [16 rd, 16 rd + 16)
-                    const uint32_t sel = (rd & 1) ? 0x0000FFFFu : 0xFFFF0000u;
-#pragma unroll
-                    for (int h = 0; h < NW; ++h) m[h] = ((rd >> 1) == h) ? (m[h] & sel) : 0u;
-                }
-                // ---- compact, lane-major: exclusive prefix sum of the lanes' candidate counts, every lane appends
+                for (int h = 0; h < NW; ++h) m[h] = (nround == 1 || rd == h) ? mw[h] : 0u;
+                // ---- compact, lane-major: exclusive prefix sum of the lanes' entry counts, every lane appends
                 int cntl = 0;
 #pragma unroll
                 for (int h = 0; h < NW; ++h) cntl += __popc(m[h]);
+                cntl = (cntl + 1) >> 1;
                 int incl = cntl;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -585,74 +604,73 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
                 }
                 const int total = __builtin_amdgcn_readlane(incl, 63);
                 if (total == 0) continue;
-                {
+                {   // entry: agent lane << 16 | B valid << 14 | jB << 7 | jA
                     int off = incl - cntl;
+                    int prev = -1;
 #pragma unroll
                     for (int h = 0; h < NW; ++h) {
                         uint32_t mm = m[h];
                         while (mm) {
                             const int q = __clz((int)mm);
                             mm &= ~(0x80000000u >> q);
-                            lst[off++] = (unsigned short)((lane << 8) | (32 * h + q));
+                            const int j = 32 * h + q;
+                            if (prev < 0) prev = j;
+                            else {
+                                lst[off++] = ((uint32_t)lane << 16) | (1u << 14) | ((uint32_t)j << 7) | (uint32_t)prev;
+                                prev = -1;
+                            }
                         }
                     }
+                    if (prev >= 0) lst[off] = ((uint32_t)lane << 16) | ((uint32_t)prev << 7) | (uint32_t)prev;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 // ---- phase 2: every lane takes a contiguous chunk of R = ceil(total/64) list entries.  The list is
                 // sorted by agent, so a chunk touches 1-3 agents: their data stays in registers and the forces are
-                // summed in registers; LDS is updated (float64 atomic) only when the agent changes.  Software pipeline:
-                // entry t+2 and the j record of entry t+1 are read while pair t is evaluated (indices are clamped to
-                // the list, so the reads past a chunk's end are harmless).
+                // summed in registers; LDS is updated (float64 atomic) only when the agent changes.
                 const int R = (total + 63) >> 6;
-                const int e_beg = lane * R, e_end = min(e_beg + R, total), last = total - 1;
+                const int e_beg = lane * R, e_end = min(e_beg + R, total);
                 int il_cur = -1;
                 double2 pa = make_double2(0.0, 0.0);
                 float4 va = make_float4(0.f, 0.f, 0.f, 0.f), aux = va;
-                float sfx = 0.f, sfy = 0.f;
-                unsigned e0 = lst[min(e_beg, last)], e1 = lst[min(e_beg + 1, last)];
-                double2 pb = l_pos[w][e0 & 63];
-                float4 vb = l_vel[w][e0 & 63];
-                float2 hb = l_head[w][e0 & 63];
-                for (int r = 0; r < R; ++r) {
-                    const int tt = e_beg + r;
-                    const unsigned e2 = lst[min(tt + 2, last)];
-                    const double2 pb_n = l_pos[w][e1 & 63];
-                    const float4 vb_n = l_vel[w][e1 & 63];
-                    const float2 hb_n = l_head[w][e1 & 63];
-                    if (tt < e_end) {
-                        const int il = e0 >> 8;
-                        if (il != il_cur) {
-                            if (il_cur >= 0) {
-                                atomicAdd(&l_accx[w][il_cur], (double)sfx);
-                                atomicAdd(&l_accy[w][il_cur], (double)sfy);
-                            }
-                            il_cur = il;
-                            sfx = sfy = 0.f;
-                            pa = li_pos[w][il];
-                            va = li_vel[w][il];
-                            aux = li_aux[w][il];
+                f2v sf = {0.f, 0.f};
+                for (int tt = e_beg; tt < e_end; ++tt) {
+                    const uint32_t e = lst[tt];
+                    const int il = e >> 16, jA = e & 127, jB = (e >> 7) & 127;
+                    const double2 pbA = l_pos[w][jA], pbB = l_pos[w][jB];
+                    const float4 vbA = l_vel[w][jA], vbB = l_vel[w][jB];
+                    const float2 hbA = l_head[w][jA], hbB = l_head[w][jB];
+                    if (il != il_cur) {
+                        if (il_cur >= 0) {
+                            atomicAdd(&l_accx[w][il_cur], (double)sf.x);
+                            atomicAdd(&l_accy[w][il_cur], (double)sf.y);
                         }
-                        const double ddx = pb.x - pa.x, ddy = pb.y - pa.y;
-                        const double d2 = ddx * ddx + ddy * ddy;
-                        // the reference's decision sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291)
-                        if (d2 <= P.cut_d2max) {
-                            const float2 f = pair_term((float)ddx, (float)ddy, va.x, va.y, va.z, aux.x, aux.y, va.w,
-                                                       aux.z, aux.w, vb, hb, b_max, db, neg_inv_eta_log2e);
-                            sfx += f.x;
-                            sfy += f.y;
-                        }
+                        il_cur = il;
+                        sf = (f2v){0.f, 0.f};
+                        pa = li_pos[w][il];
+                        va = li_vel[w][il];
+                        aux = li_aux[w][il];
                     }
-                    e0 = e1;
-                    e1 = e2;
-                    pb = pb_n;
-                    vb = vb_n;
-                    hb = hb_n;
+                    const double dxA = pbA.x - pa.x, dyA = pbA.y - pa.y, dxB = pbB.x - pa.x, dyB = pbB.y - pa.y;
+                    const double d2A = dxA * dxA + dyA * dyA, d2B = dxB * dxB + dyB * dyB;
+                    // the reference's decision sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291);
+                    // coincident agents (d2 = 0: NaN in the reference) are skipped (deviation D1)
+                    const bool okA = d2A <= P.cut_d2max && d2A > 0.0;
+                    const bool okB = (e & (1u << 14)) && d2B <= P.cut_d2max && d2B > 0.0;
+                    if (okA || okB) {
+                        f2v fx, fy;
+                        pair_term2((f2v){(float)dxA, (float)dxB}, (f2v){(float)dyA, (float)dyB}, va.x, va.y, va.z, aux.x,
+                                   aux.y, va.w, aux.z, aux.w, (f2v){vbA.x, vbB.x}, (f2v){vbA.y, vbB.y},
+                                   (f2v){vbA.z, vbB.z}, (f2v){vbA.w, vbB.w}, (f2v){hbA.x, hbB.x}, (f2v){hbA.y, hbB.y},
+                                   b_max, db, neg_inv_eta_log2e, fx, fy);
+                        const f2v fA = {okA ? fx.x : 0.f, okA ? fy.x : 0.f}, fB = {okB ? fx.y : 0.f, okB ? fy.y : 0.f};
+                        sf += fA + fB;
+                    }
                 }
                 if (il_cur >= 0) {
-                    atomicAdd(&l_accx[w][il_cur], (double)sfx);
-                    atomicAdd(&l_accy[w][il_cur], (double)sfy);
+                    atomicAdd(&l_accx[w][il_cur], (double)sf.x);
+                    atomicAdd(&l_accy[w][il_cur], (double)sf.y);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();

@@ -86,7 +86,7 @@ struct oc_handle {
     bool packed_valid = false;  // the packed snapshot matches the caller's state arrays
     const void* packed_x = nullptr;
     int32_t packed_N = -1;
-    int pair_split = 4;         // pair wavefronts per i-tile (1, 2 or 4): occupancy of k_forces (gcfm.hip)
+    int pair_split = 2;         // pair wavefronts per i-tile (1, 2 or 4): occupancy of k_forces (gcfm.hip)
     int wall_blocks = 128;      // blocks of k_forces that sweep the wall work-list
     hipStream_t aux_stream = nullptr;   // k_wall runs here, beside k_pair
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
