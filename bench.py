@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wall-radius", type=float, default=-1.0,
                     help="diagnostic: wall search radius in m (default -1: per-agent radius from the 1e-12 m/s force bound)")
-    ap.add_argument("--tune", default="", help="launch-shape knobs, e.g. pair_split=4,wall_blocks=64 (oc_set_tuning)")
+    ap.add_argument("--tune", default="", help="launch-shape knobs, e.g. pair_split=4 (oc_set_tuning)")
     args = ap.parse_args()
 
     import torch
@@ -215,7 +215,7 @@ def main():
     n_acc = stats[0][0]["n_accept"] if stats else 0
     ncell = sim.Nx * sim.Ny
     kstats = {}
-    for name in ("hjb_out", "hjb_stage", "gcfm_pair", "gcfm_finish"):
+    for name in ("hjb_out", "hjb_stage", "gcfm_forces", "gcfm_finish"):
         nl, ms, by = eng.kernel_stats(name)
         kstats[name] = {"launches": nl, "avg_ms": (ms / nl if nl else None), "total_ms": ms,
                         "algorithmic_GB_per_launch": (by / nl / 1e9 if nl else None),

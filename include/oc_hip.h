@@ -182,7 +182,7 @@ int oc_density(oc_handle* h, int dtype, const oc_agents* a, double sigma, const 
 /* With profiling enabled every launch of a named kernel class is bracketed by HIP events on its own stream.
  * oc_kernel_stats returns, since the last reset: number of launches, summed event time (ms) and summed
  * ALGORITHMIC bytes (DESIGN.md section "Rooflines").  Classes: "hjb_stage" (one RK attempt = 6 fused stage
- * launches), "hjb_out" (dense output + direction-field writer), "gcfm_pair", "gcfm_wall".  Synchronises. */
+ * launches), "hjb_out" (dense output + direction-field writer), "gcfm_forces", "gcfm_finish" (the two launches of a step).  Synchronises. */
 /* mode bits: 1 = HJB kernels, 2 = GCFM kernels every step, 4 = GCFM kernels every 16th step; 0 = off */
 int oc_set_profiling(oc_handle* h, int mode);
 int oc_kernel_stats(oc_handle* h, const char* name, int64_t* launches, double* total_ms, double* total_bytes);
@@ -191,7 +191,7 @@ int oc_reset_kernel_stats(oc_handle* h);
 int oc_set_hjb_variant(oc_handle* h, int variant);
 /* Launch-shape knobs of the step kernels (results do not depend on them beyond float64 summation order):
  *   "pair_split"  1, 2 or 4 pair wavefronts per tile of 64 agents (default 2)
- *   "wall_blocks" blocks of the force kernel that sweep the wall work-list (default 128) */
+ *   "prep_blocks" blocks of the force kernel that do the wall search / field lookup of the tiles (default 256) */
 int oc_set_tuning(oc_handle* h, const char* name, int value);
 
 #ifdef __cplusplus

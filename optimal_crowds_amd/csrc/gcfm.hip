@@ -3,19 +3,20 @@
 // pedestrians.py:282-334 (wall_repulsion), optimals.py:212-250 (choose_optimal_velocity).
 //
 // Layout: caller-owned SoA state in agent order (float64 x,y,vx,vy,v_des; uint8 status; int32 key).
-// The library keeps a packed snapshot in SLOT order (agents sorted by 4 m coarse cell; a tile = 64 slots =
-// one wavefront):
+// The library keeps a packed snapshot in SLOT order (agents sorted along a Hilbert curve over 2 m coarse cells; a
+// tile = 64 slots = one wavefront), double-buffered because a step reads the old one while it writes the new one:
 //   ppos  double2 (x,y)      pvel  float4 (vx,vy,|v|,1/a^2)     phead float2 (unit heading, (1,0) if v=0)
 //   tile_box double4 (minx,miny,maxx,maxy) of a tile's active agents;  nb_list: tiles that can come within the
 //   cutoff before the next re-sort (boxes at sort time, cutoff + 2D margin; validity is re-checked every step)
-// One step = 3 launches:
-//   k_pair   one block (4 wavefronts) per i-tile; candidate j-tiles (neighbour list + live box test) are split over
-//            the wavefronts, staged 4 at a time in LDS; phase 1 builds per-lane 64-bit candidate masks with a
-//            conservative float32 test, phase 2 walks each lane's candidates of the whole batch: exact float64
-//            cutoff decision (the reference's sqrt(dx^2+dy^2) < cutoff), float32 force, float64 sum.
-//   k_wall   exact nearest-wall-cell search (float64) for the compacted list of agents that can feel a wall.
-//   k_finish per agent, float64: floor-field lookup, wall force, noisy relaxation step, speed clamp, exit test;
-//            then writes the NEXT step's packed record, tile box and wall work-list.
+//   pvd double2 (float64 velocity), pdk (v_des, key): slot-ordered copies, so a step gathers nothing by agent index
+// One step = ONE launch, k_step: a block carries 4/NS tiles and NS wavefronts per tile.
+//   pair     the NS wavefronts of a tile share its candidate j-tiles by j-range (equal work): phase 1 builds per-lane
+//            candidate masks with a conservative float32 test, the candidates are compacted into an LDS list (two
+//            per entry), phase 2 walks the list: exact float64 cutoff decision (the reference's
+//            sqrt(dx^2+dy^2) < cutoff), packed float32 force, float64 sums in LDS shared by the tile's wavefronts;
+//   finish   after a block barrier the tile's first wavefront does, per agent in float64: exact nearest-wall-cell
+//            search (one lane per agent), floor-field lookup, wall force, noisy relaxation step, speed clamp, exit
+//            test; then it writes the NEXT snapshot (other buffer), the tile box and the step counters.
 #include "oc_internal.h"
 #include <cmath>
 #include <algorithm>
@@ -50,33 +51,43 @@ struct GcfmParams {
 #define C_EXIT 0
 #define C_ERR 1
 #define C_ACTIVE 2
-#define C_WCOUNT 4      // [4], [5]: wall work-list lengths (ping-pong)
-#define C_INVALID 6     // neighbour lists no longer cover the tile boxes -> full tile scan
+#define C_INVALID 6     // neighbour lists no longer cover the tile boxes -> full tile scan (sticky until the re-sort)
+#define C_NACTIVE 7     // active agents (set at the re-sort, decremented by exits): no hot same-address atomics
 
-// One entry of the wall work-list: everything the search needs, so that its first dependent load is already the
-// table (the search is a chain of dependent loads; every level removed is ~1 us off each group's latency).
-struct alignas(64) WEntry {
+// What the nearest-wall search of one agent needs (wall_prepare).
+struct WEntry {
     double px, py;          // the agent's position
     double lim2;            // min(search radius^2, upper bound^2 on the distance to the nearest site)
     double off;             // the key's objective offset V_min * 10e3
     const int2* col;        // lr + jx * Ny: the agent's column of the transposed nearest-site table
     const int32_t* g8;      // gap8 + jx * nb8
-    int32_t k, b0;          // packed slot; 8-row block of the nearest grid row
-    int32_t prune_ok, pad;  // column-gap bounds valid (agent within one cell of column jx)
+    int32_t b0;             // 8-row block of the nearest grid row
+    int32_t prune_ok;       // column-gap bounds valid (agent within one cell of column jx)
+};
+
+struct Snap {               // one buffer of the packed snapshot
+    double2* ppos;
+    float4* pvel;
+    float2* phead;
+    int32_t* pidx;
+    double4* tile_box;
+};
+
+struct PDK {                // per slot, fixed between re-sorts
+    double v_des;
+    int32_t key, pad;
 };
 
 struct Scratch {
     uint32_t *keys_a, *keys_b;
     int32_t *vals_a, *vals_b;
-    double2* ppos;
-    float4* pvel;
-    float2* phead;
-    int32_t* pidx;
-    double4 *tile_box, *tile_box0;
+    Snap snap[2];
+    double2* pvd;           // float64 velocity per slot (only the tile's own finisher touches it: single buffer)
+    PDK* pdk;
+    double4* tile_box0;
     int32_t* nb_list;       // [ntiles][NB_MAX + 1]: count (or -1 = overflow) then tile ids
-    double2 *f_pair, *f_wall, *des;
+    double2 *f_pair, *f_wall, *des;     // single-shot diagnostic exports only
     long long* widx;
-    WEntry* wall_list[2];   // work-list of the nearest-wall search (ping-pong): self-contained 64-byte records
     int32_t* ctrl;
     int32_t Np, ntiles;
 };
@@ -253,7 +264,7 @@ __device__ __forceinline__ bool wall_needed(const GcfmParams& P, const KeyDev& k
 
 // wall_needed + the start of the search (column, nearest row), packed for the work-list
 __device__ __forceinline__ bool wall_prepare(const GcfmParams& P, const KeyDev& kd, const Axis X0, const Axis Y0, double px,
-                                             double py, double speed, int k, WEntry& e) {
+                                             double py, double speed, WEntry& e) {
     double rad2, ub2;
     if (!wall_needed(P, kd, X0, Y0, px, py, speed, rad2, ub2)) return false;
     const int Nx = P.Nx, Ny = P.Ny;
@@ -270,10 +281,8 @@ __device__ __forceinline__ bool wall_prepare(const GcfmParams& P, const KeyDev& 
     e.off = kd.off;
     e.col = kd.lr + (size_t)jx * Ny;
     e.g8 = kd.gap8 + (size_t)jx * ((Ny + 7) >> 3);
-    e.k = k;
     e.b0 = r0 >> 3;
     e.prune_ok = fabs(px - X0[jx]) <= hx;                          // false only for agents outside the room
-    e.pad = 0;
     return true;
 }
 
@@ -312,48 +321,45 @@ __device__ __forceinline__ void make_record(const GcfmParams& P, double vxd, dou
     ph = (s > 0) ? make_float2((float)(vxd / s), (float)(vyd / s)) : make_float2(1.f, 0.f);
 }
 
-// append the lanes with `need` to the wall work-list (one atomic per wavefront)
-__device__ __forceinline__ void wall_list_push(bool need, const WEntry& e, WEntry* __restrict__ list, int32_t* count) {
-    unsigned long long m = __ballot(need);
-    if (!m) return;
-    int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, leader, 64);
-    if (need) list[base + __popcll(m & ((1ull << lane) - 1))] = e;
-}
-
 // full pack from the state arrays (after a re-sort): one wavefront per tile
 __global__ void __launch_bounds__(64) k_pack(const double* __restrict__ x, const double* __restrict__ y,
                                              const double* __restrict__ vx, const double* __restrict__ vy,
-                                             const uint8_t* __restrict__ status, const int32_t* __restrict__ key_of,
-                                             const int32_t* __restrict__ order, int N, GcfmParams P, Scratch S,
-                                             const KeyDev* __restrict__ keys, const Axis X0,
-                                             const Axis Y0, int cur) {
+                                             const double* __restrict__ v_des, const uint8_t* __restrict__ status,
+                                             const int32_t* __restrict__ key_of, const int32_t* __restrict__ order,
+                                             int N, GcfmParams P, Scratch S, int cur) {
+    const Snap& C = S.snap[cur];
     int k = blockIdx.x * 64 + threadIdx.x;
     int i = (k < N) ? order[k] : -1;
     bool act = (i >= 0) && status[i];
-    double px = 1e300, py = 1e300;
+    double px = 1e300, py = 1e300, vxd = 0.0, vyd = 0.0;
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 ph = make_float2(1.f, 0.f);
-    bool need = false;
-    WEntry we;
+    PDK dk = {1.0, 0, 0};
     if (act) {
         px = x[i];
         py = y[i];
-        make_record(P, vx[i], vy[i], pv, ph);
-        if (keys) need = wall_prepare(P, keys[key_of[i]], X0, Y0, px, py, (double)pv.z, k, we);
+        vxd = vx[i];
+        vyd = vy[i];
+        make_record(P, vxd, vyd, pv, ph);
+        dk.v_des = v_des[i];
+        dk.key = key_of[i];
     }
-    S.ppos[k] = make_double2(px, py);
-    S.pvel[k] = pv;
-    S.phead[k] = ph;
-    S.pidx[k] = act ? i : -1;
-    S.widx[k] = -1;
-    wall_list_push(need, we, S.wall_list[cur], &S.ctrl[C_WCOUNT + cur]);
+    C.ppos[k] = make_double2(px, py);
+    C.pvel[k] = pv;
+    C.phead[k] = ph;
+    C.pidx[k] = act ? i : -1;
+    // inactive agents sort to the end, so the active ones occupy slots [0, n): the last of them publishes n
+    {
+        const int inext = (k + 1 < N) ? order[k + 1] : -1;
+        const bool act_next = (inext >= 0) && status[inext];
+        if (act && !act_next) S.ctrl[C_NACTIVE] = k + 1;
+    }
+    S.pvd[k] = make_double2(vxd, vyd);
+    S.pdk[k] = dk;
     double mnx = wmin(act ? px : INFINITY), mny = wmin(act ? py : INFINITY);
     double mxx = wmax(act ? px : -INFINITY), mxy = wmax(act ? py : -INFINITY);
     if (threadIdx.x == 0) {
-        S.tile_box[blockIdx.x] = make_double4(mnx, mny, mxx, mxy);
+        C.tile_box[blockIdx.x] = make_double4(mnx, mny, mxx, mxy);
         S.tile_box0[blockIdx.x] = make_double4(mnx, mny, mxx, mxy);
     }
 }
@@ -439,65 +445,77 @@ struct JRec {                   // one lane's share of a staged j-tile (prefetch
     float2 head;
 };
 
-// One WAVEFRONT per (i-tile, share): wavefronts are fully independent (no block-level synchronisation).  NS of them
-// share an i-tile: share `sub` takes the j = sub*64/NS .. (sub+1)*64/NS - 1 of EVERY candidate j-tile (so the shares of
-// a tile carry equal work, whatever the geometry) and writes its partial sums to its own slab of f_pair (k_finish adds
-// the slabs).  Splitting exists for occupancy and balance: a tile's work is one long dependent chain, the chip holds
-// only ~1.5 tiles per SIMD, and the kernel ends with its slowest wavefront.  Per j-tile:
+// LDS of a block of 4 wavefronts: 4/NS tiles (i records and force sums, shared by the tile's NS wavefronts) and,
+// per wavefront, its share of the staged j-tile and its candidate list.
+template <int NS>
+struct PairLds {
+    static constexpr int NJ = 64 / NS, TPB = 4 / NS;
+    double2 li_pos[TPB][64];
+    float4 li_vel[TPB][64];
+    float4 li_aux[TPB][64];     // (hx, hy, 1/b_i^2, 1/v_des_i)
+    double accx[TPB][64], accy[TPB][64];
+    double2 l_pos[4][NJ];
+    float4 l_vel[4][NJ];
+    float2 l_head[4][NJ];
+    alignas(16) float l_rx[4][NJ];
+    alignas(16) float l_ry[4][NJ];
+    uint32_t list[4][PAIR_LIST_CAP];
+};
+
+// the i-tile in LDS (in phase 2 any lane works on any agent) and zeroed force sums: one wavefront per tile
+template <int NS>
+__device__ __forceinline__ void pair_load_tile(const GcfmParams& P, const Snap& C, const PDK* __restrict__ pdk,
+                                               PairLds<NS>& L, int it, int tl, int lane) {
+    const int k = it * 64 + lane;
+    const int i = C.pidx[k];
+    const float4 vi = C.pvel[k];
+    const float2 hi = C.phead[k];
+    float inv_vdes = 0.f, ib2_i = 0.f;
+    if (i >= 0) {
+        const double vd = pdk[k].v_des;
+        inv_vdes = (float)(1.0 / vd);
+        const double b = P.b_max - (P.b_max - P.b_min) * fmin((double)vi.z / vd, 1.0);
+        ib2_i = (float)(1.0 / (b * b));
+    }
+    L.li_pos[tl][lane] = C.ppos[k];
+    L.li_vel[tl][lane] = vi;
+    L.li_aux[tl][lane] = make_float4(hi.x, hi.y, ib2_i, inv_vdes);
+    L.accx[tl][lane] = 0.0;
+    L.accy[tl][lane] = 0.0;
+}
+
+// One WAVEFRONT per (i-tile, share).  The NS wavefronts of a tile sit in one block and share the tile's i records
+// and force sums in LDS; share `sub` takes the j = sub*64/NS .. (sub+1)*64/NS - 1 of EVERY candidate j-tile, so the
+// shares of a tile carry equal work whatever the geometry.  Splitting exists for occupancy and balance: a tile's
+// work is one long chain, the chip holds only ~1.5 tiles per SIMD, and the launch ends with its slowest wavefront.
+// Per j-tile:
 //   stage    this share's NJ = 64/NS packed records go to wave-private LDS; the next tile's records are already being
 //            loaded (register prefetch) while this one is processed;
 //   phase 1  per lane (= agent i) an NJ-bit candidate mask from a conservative float32 distance test on box-relative
 //            coordinates: packed float2 math, sign bits collected with v_alignbit (3 VALU per j);
-//   compact  candidates are appended to a wave-private LDS list, lane-major (sorted by agent); dense tile pairs
-//            (more than PAIR_LIST_CAP candidates) are taken in rounds of 16 j each;
-//   phase 2  every lane walks a contiguous chunk of the list: exact float64 cutoff decision, float32 force, float64
-//            LDS atomic accumulation when the agent changes.  The list entry and the j record of the NEXT pair are
-//            fetched from LDS while the current pair is evaluated.
+//   compact  candidates are appended, two per entry, to a wave-private LDS list, lane-major (sorted by agent); dense
+//            tile pairs (more than PAIR_LIST_CAP entries) are taken in rounds of 32 j each;
+//   phase 2  every lane walks a contiguous chunk of the list: exact float64 cutoff decision, packed float32 force,
+//            float64 LDS atomic accumulation when the agent changes.
+// The caller brackets this with block barriers (i records loaded before, sums complete after).
 template <int NS>
-__device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S, const double* __restrict__ v_des,
-                                          int it, int sub, int w, int lane) {
+__device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S, const Snap& C, PairLds<NS>& L, int it,
+                                           int tl, int sub, int w, int lane) {
     constexpr int NJ = 64 / NS;                   // j records of a tile handled by this share
     constexpr int NW = (NJ + 31) / 32;            // 32-bit mask words per lane
     constexpr int WB = NJ < 32 ? NJ : 32;         // bits used per word
     constexpr int NROUND = NW;                    // rounds of 32 j for a dense tile pair
-    __shared__ double2 li_pos[4][64];
-    __shared__ float4 li_vel[4][64];
-    __shared__ float4 li_aux[4][64];              // (hx, hy, 1/b_i^2, 1/v_des_i)
-    __shared__ double2 l_pos[4][NJ];
-    __shared__ float4 l_vel[4][NJ];
-    __shared__ float2 l_head[4][NJ];
-    __shared__ alignas(16) float l_rx[4][NJ];
-    __shared__ alignas(16) float l_ry[4][NJ];
-    __shared__ uint32_t l_list[4][PAIR_LIST_CAP];
-    __shared__ double l_accx[4][64], l_accy[4][64];
-    if (it >= S.ntiles) return;                     // wavefronts are independent: no barrier anywhere
     const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
     const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
     const double c = P.cutoff, c2 = c * c;
     const int k = it * 64 + lane;
-    const int i = S.pidx[k];
-    const double2 pi = S.ppos[k];
-    {                                               // the i-tile in LDS: in phase 2 any lane works on any agent
-        const float4 vi = S.pvel[k];
-        const float2 hi = S.phead[k];
-        float inv_vdes = 0.f, ib2_i = 0.f;
-        if (i >= 0) {
-            double vd = v_des[i];
-            inv_vdes = (float)(1.0 / vd);
-            double b = P.b_max - (P.b_max - P.b_min) * fmin((double)vi.z / vd, 1.0);
-            ib2_i = (float)(1.0 / (b * b));
-        }
-        li_pos[w][lane] = pi;
-        li_vel[w][lane] = vi;
-        li_aux[w][lane] = make_float4(hi.x, hi.y, ib2_i, inv_vdes);
-        l_accx[w][lane] = 0.0;
-        l_accy[w][lane] = 0.0;
-    }
-    const double4 bi = S.tile_box[it];
+    const int i = C.pidx[k];
+    const double2 pi = L.li_pos[tl][lane];
+    const double4 bi = C.tile_box[it];
     const double ox = bi.x, oy = bi.y;             // origin of the box-relative float32 coordinates
     const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
     const f2v xi2 = {xi_f, xi_f}, yi2 = {yi_f, yi_f};
-    uint32_t* lst = l_list[w];
+    uint32_t* lst = L.list[w];
     const int j0 = sub * NJ;                        // this share's records of a j-tile: j0 .. j0 + NJ - 1
     const int jl = lane & (NJ - 1);                 // lanes >= NJ duplicate the loads of lanes < NJ (same cache lines)
 
@@ -510,26 +528,26 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
         int t;
         if (use_list) t = (lane < nb_cnt) ? nb[1 + lane] : -1;
         else t = (ch * 64 + lane < S.ntiles) ? ch * 64 + lane : -1;
-        const bool hit = (t >= 0) && box_hit(bi, S.tile_box[t], c);
+        const bool hit = (t >= 0) && box_hit(bi, C.tile_box[t], c);
         unsigned long long tmask = __ballot(hit);
         if (!tmask) continue;
         // prefetch the first hit of this chunk
         int jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
         tmask &= tmask - 1;
         JRec cur;
-        cur.pos = S.ppos[jt * 64 + j0 + jl];
-        cur.vel = S.pvel[jt * 64 + j0 + jl];
-        cur.head = S.phead[jt * 64 + j0 + jl];
-        double4 bj = S.tile_box[jt];
+        cur.pos = C.ppos[jt * 64 + j0 + jl];
+        cur.vel = C.pvel[jt * 64 + j0 + jl];
+        cur.head = C.phead[jt * 64 + j0 + jl];
+        double4 bj = C.tile_box[jt];
         for (;;) {
             // ---- stage this share of tile jt (registers -> wave-private LDS; LDS ops of one wavefront complete in
             // order, so the single buffer is safe: the previous tile's reads were issued before these writes)
             if (lane < NJ) {
-                l_pos[w][lane] = cur.pos;
-                l_rx[w][lane] = (float)(cur.pos.x - ox);
-                l_ry[w][lane] = (float)(cur.pos.y - oy);
-                l_vel[w][lane] = cur.vel;
-                l_head[w][lane] = cur.head;
+                L.l_pos[w][lane] = cur.pos;
+                L.l_rx[w][lane] = (float)(cur.pos.x - ox);
+                L.l_ry[w][lane] = (float)(cur.pos.y - oy);
+                L.l_vel[w][lane] = cur.vel;
+                L.l_head[w][lane] = cur.head;
             }
             // conservative float32 bound: rounding of the relative coordinates scales with the boxes' extent
             const float ext = (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
@@ -542,10 +560,10 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
             if (more) {
                 jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
                 tmask &= tmask - 1;
-                cur.pos = S.ppos[jt * 64 + j0 + jl];
-                cur.vel = S.pvel[jt * 64 + j0 + jl];
-                cur.head = S.phead[jt * 64 + j0 + jl];
-                bj = S.tile_box[jt];
+                cur.pos = C.ppos[jt * 64 + j0 + jl];
+                cur.vel = C.pvel[jt * 64 + j0 + jl];
+                cur.head = C.phead[jt * 64 + j0 + jl];
+                bj = C.tile_box[jt];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -557,8 +575,8 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
                 uint32_t acc = 0u;
 #pragma unroll
                 for (int g = 0; g < WB / 4; ++g) {
-                    const float4 xs = *reinterpret_cast<const float4*>(&l_rx[w][32 * h + 4 * g]);
-                    const float4 ys = *reinterpret_cast<const float4*>(&l_ry[w][32 * h + 4 * g]);
+                    const float4 xs = *reinterpret_cast<const float4*>(&L.l_rx[w][32 * h + 4 * g]);
+                    const float4 ys = *reinterpret_cast<const float4*>(&L.l_ry[w][32 * h + 4 * g]);
                     const f2v xa = {xs.x, xs.y}, xb = {xs.z, xs.w}, ya = {ys.x, ys.y}, yb = {ys.z, ys.w};
                     const f2v dxa = xa - xi2, dxb = xb - xi2, dya = ya - yi2, dyb = yb - yi2;
                     const f2v ta = __builtin_elementwise_fma(dxa, dxa, __builtin_elementwise_fma(dya, dya, nc2));
@@ -638,19 +656,19 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
                 for (int tt = e_beg; tt < e_end; ++tt) {
                     const uint32_t e = lst[tt];
                     const int il = e >> 16, jA = e & 127, jB = (e >> 7) & 127;
-                    const double2 pbA = l_pos[w][jA], pbB = l_pos[w][jB];
-                    const float4 vbA = l_vel[w][jA], vbB = l_vel[w][jB];
-                    const float2 hbA = l_head[w][jA], hbB = l_head[w][jB];
+                    const double2 pbA = L.l_pos[w][jA], pbB = L.l_pos[w][jB];
+                    const float4 vbA = L.l_vel[w][jA], vbB = L.l_vel[w][jB];
+                    const float2 hbA = L.l_head[w][jA], hbB = L.l_head[w][jB];
                     if (il != il_cur) {
                         if (il_cur >= 0) {
-                            atomicAdd(&l_accx[w][il_cur], (double)sf.x);
-                            atomicAdd(&l_accy[w][il_cur], (double)sf.y);
+                            atomicAdd(&L.accx[tl][il_cur], (double)sf.x);
+                            atomicAdd(&L.accy[tl][il_cur], (double)sf.y);
                         }
                         il_cur = il;
                         sf = (f2v){0.f, 0.f};
-                        pa = li_pos[w][il];
-                        va = li_vel[w][il];
-                        aux = li_aux[w][il];
+                        pa = L.li_pos[tl][il];
+                        va = L.li_vel[tl][il];
+                        aux = L.li_aux[tl][il];
                     }
                     const double dxA = pbA.x - pa.x, dyA = pbA.y - pa.y, dxB = pbB.x - pa.x, dyB = pbB.y - pa.y;
                     const double d2A = dxA * dxA + dyA * dyA, d2B = dxB * dxB + dyB * dyB;
@@ -669,8 +687,8 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
                     }
                 }
                 if (il_cur >= 0) {
-                    atomicAdd(&l_accx[w][il_cur], (double)sf.x);
-                    atomicAdd(&l_accy[w][il_cur], (double)sf.y);
+                    atomicAdd(&L.accx[tl][il_cur], (double)sf.x);
+                    atomicAdd(&L.accy[tl][il_cur], (double)sf.y);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -679,13 +697,9 @@ __device__ __forceinline__ void pair_wave(const GcfmParams& P, const Scratch& S,
             if (!more) break;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    S.f_pair[(size_t)sub * S.Np + k] = make_double2(l_accx[w][lane], l_accy[w][lane]);
 }
 
-// ---------------------------------------------------------------------------------- wall search over the work-list
+// ---------------------------------------------------------------------------------- nearest-wall-cell search
 // One LANE per agent (the search is a chain of dependent loads, so a wavefront should carry as many agents as it
 // can).  Rows are taken in aligned blocks of 8, outward from the agent's row, 8 blocks each way per round: the round
 // loads the 16 column-gap bounds (gap8, built with the wall map) in one batch, marks the blocks in which some
@@ -762,17 +776,17 @@ __device__ __forceinline__ void wall_block_eval(double px, double py, int blk, c
     }
 }
 
-__device__ __forceinline__ void wall_lane(const GcfmParams& P, const Scratch& S, const Axis X0, const Axis Y0, int cur,
-                                          int t, int count) {
-    const bool go = t < count;
-    const WEntry& we = S.wall_list[cur][go ? t : 0];
+// Called by all 64 lanes (`go` false for lanes without a search).  Returns the flat index of the cell the reference's
+// np.argmin(distances + V*10e3) selects (pedestrians.py:311-315), or -1 when nothing lies within we.lim2.
+__device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEntry& we, bool go, const Axis X0,
+                                                 const Axis Y0) {
     const double px = we.px, py = we.py;
     const int Nx = P.Nx, Ny = P.Ny, nb8 = (Ny + 7) >> 3;
     const double hx = P.L / (Nx - 1);
     const double lim2 = we.lim2, off = we.off;
     const int2* __restrict__ col = we.col;
     const int32_t* __restrict__ g8 = we.g8;
-    const int k = we.k, b0 = we.b0;
+    const int b0 = we.b0;
     const bool prune_ok = we.prune_ok != 0;
     double best_f = INFINITY, best_d2 = INFINITY, thr = INFINITY;
     long long best_flat = -1;
@@ -856,44 +870,34 @@ __device__ __forceinline__ void wall_lane(const GcfmParams& P, const Scratch& S,
             }
         }
     }
-    if (go) S.widx[k] = best_flat;
+    return best_flat;
 }
 
-// standalone wall search (diagnostic exports)
-__global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
-                                             const int32_t* __restrict__ key_of, const Axis X0,
+// standalone wall search (diagnostic exports): one lane per slot
+__global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, const Axis X0,
                                              const Axis Y0, int cur) {
-    wall_lane(P, S, X0, Y0, cur, blockIdx.x * 64 + threadIdx.x, S.ctrl[C_WCOUNT + cur]);
+    const Snap& C = S.snap[cur];
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    WEntry we = {};
+    bool go = false;
+    if (C.pidx[k] >= 0) {
+        const double2 p = C.ppos[k];
+        go = wall_prepare(P, keys[S.pdk[k].key], X0, Y0, p.x, p.y, (double)C.pvel[k].z, we);
+    }
+    S.widx[k] = wall_search(P, we, go, X0, Y0);
 }
 
-// standalone pair forces (diagnostic exports): 4 independent wavefronts per block
-__global__ void __launch_bounds__(256, 4) k_pair(GcfmParams P, Scratch S, const double* __restrict__ v_des) {
-    pair_wave<1>(P, S, v_des, blockIdx.x * 4 + (threadIdx.x >> 6), 0, threadIdx.x >> 6, threadIdx.x & 63);
-}
-
-// The step's force kernel: horizontal fusion of the pair forces and the wall search in one launch (a second stream
-// costs ~15 us per cross-stream dependency on this platform).  Blocks of 4 independent wavefronts; the first
-// `nwall` blocks sweep the wall work-list (they are dispatched first and finish early), every other block carries
-// 4 pair wavefronts: wavefront gw handles i-tile gw / nsplit, share gw % nsplit.  128 registers and 9 KB of LDS per
-// pair wavefront keep 4 wavefronts per SIMD resident, i.e. every (tile, share) of C4 at nsplit = 2 is in flight at once.
-template <int NS>
-__global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, const double* __restrict__ v_des,
-                                                const KeyDev* __restrict__ keys, const int32_t* __restrict__ key_of,
-                                                const Axis X0, const Axis Y0, int cur,
-                                                int nxt, int32_t* __restrict__ cnt_out, int nwall) {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {      // this step's counters (k_finish adds to them later in the stream)
-        cnt_out[0] = cnt_out[1] = cnt_out[2] = cnt_out[3] = 0;
-        S.ctrl[C_WCOUNT + nxt] = 0;
-    }
-    if ((int)blockIdx.x >= nwall) {
-        const int gw = ((int)blockIdx.x - nwall) * 4 + w;
-        pair_wave<NS>(P, S, v_des, gw / NS, gw % NS, w, lane);
-    } else {
-        const int count = S.ctrl[C_WCOUNT + cur];
-        const int nwaves = nwall * 4, gw = blockIdx.x * 4 + w;
-        for (int base = gw * 64; base < count; base += nwaves * 64) wall_lane(P, S, X0, Y0, cur, base + lane, count);
-    }
+// standalone pair forces (diagnostic exports): 4 tiles per block, one wavefront each
+__global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, int cur) {
+    __shared__ PairLds<1> L;
+    const Snap& C = S.snap[cur];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, it = blockIdx.x * 4 + w;
+    const bool live = it < S.ntiles;
+    if (live) pair_load_tile<1>(P, C, S.pdk, L, it, w, lane);
+    __syncthreads();
+    if (live) pair_share<1>(P, S, C, L, it, w, 0, w, lane);
+    __syncthreads();
+    if (live) S.f_pair[it * 64 + lane] = make_double2(L.accx[w][lane], L.accy[w][lane]);
 }
 
 // capped exact distance transform of the site set on the grid nodes (init-time, one thread per node)
@@ -993,50 +997,111 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// ---------------------------------------------------------------------------------- finish
-// simulations.py:277-332 for every active agent (one wavefront per tile), then the next step's packed snapshot.
-__global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
-                                               const int32_t* __restrict__ key_of, double* __restrict__ x,
-                                               double* __restrict__ y, double* __restrict__ vx,
-                                               double* __restrict__ vy, const double* __restrict__ v_des,
-                                               uint8_t* __restrict__ status, double* __restrict__ agent_time,
-                                               const double* __restrict__ noise, uint64_t seed, int step,
-                                               const Axis X0, const Axis Y0, int nxt,
-                                               int32_t* __restrict__ cnt_out, int nsplit) {
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    const int i = S.pidx[k];
-    bool act = i >= 0, out = false, need = false;
-    WEntry we;
-    double nx = 1e300, ny = 1e300;
-    if (act) {
-        const KeyDev& kd = keys[key_of[i]];
-        const double2 p = S.ppos[k];
-        const double vxd = vx[i], vyd = vy[i], vd = v_des[i];
-        // desired velocity, repulsions
-        const double2 ds = lookup(P, kd, p.x, p.y, vd, step, i, &cnt_out[C_ERR]);
-        double2 fp = S.f_pair[k];
-        for (int q = 1; q < nsplit; ++q) {                  // partial sums of the tile's pair wavefronts
-            const double2 fq = S.f_pair[(size_t)q * S.Np + k];
-            fp.x += fq.x;
-            fp.y += fq.y;
+// ---------------------------------------------------------------------------------- the step: k_forces, k_finish
+struct StepArgs {               // caller-owned state (agent order) and the step's inputs
+    double *x, *y, *vx, *vy;
+    uint8_t* status;
+    double* agent_time;
+    const double* noise;
+    uint64_t seed;
+    int32_t step;
+    int32_t* cnt_out;           // device int32[4]
+};
+
+// Everything of simulations.py:277-299 that does not need the pair forces, for the 64 agents of tile `it` (one
+// wavefront, one lane per agent): the exact nearest wall cell (pedestrians.py:311-315) and its force, and the desired
+// velocity from the floor field.  A chain of dependent loads (key table -> distance bound -> gap table -> site table
+// -> field) with little arithmetic: it runs in spare wavefronts beside the pair forces and leaves k_finish one level
+// of loads.
+__device__ __forceinline__ void prep_tile(const GcfmParams& P, const Scratch& S, const Snap& C,
+                                          const KeyDev* __restrict__ keys, int step, const Axis X0, const Axis Y0,
+                                          int it, int lane, int32_t* err) {
+    const int k = it * 64 + lane;
+    const int i = C.pidx[k];
+    const bool act = i >= 0;
+    const double2 p = C.ppos[k];
+    const double2 v = S.pvd[k];
+    const PDK dk = S.pdk[k];
+    const KeyDev& kd = keys[act ? dk.key : 0];
+    double2 ds = make_double2(0.0, 0.0);
+    if (act) ds = lookup(P, kd, p.x, p.y, dk.v_des, step, i, err);          // its loads fly during the search
+    WEntry we = {};
+    const bool need = act && wall_prepare(P, kd, X0, Y0, p.x, p.y, (double)C.pvel[k].z, we);
+    const long long widx = wall_search(P, we, need, X0, Y0);
+    double2 fw = make_double2(0.0, 0.0);
+    if (act) fw = wall_force_of(P, widx, p.x, p.y, v.x, v.y, dk.v_des, X0, Y0);
+    S.des[k] = ds;
+    S.f_wall[k] = fw;
+}
+
+// The step's force kernel.  Blocks of 4 wavefronts.  The first `nprep` blocks sweep the tiles with prep_tile (they
+// are dispatched first; their wavefronts mostly wait on memory).  Every other block carries 4/NS tiles: barrier 1,
+// the tiles' i records are in LDS; every wavefront does its share of its tile's pair forces (pair_share); barrier 2,
+// the tiles' force sums are complete and go to f_pair.  128 registers and < 40 KB of LDS per block keep 4 blocks per
+// CU resident.
+template <int NS>
+__global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, int step,
+                                                const Axis X0, const Axis Y0, int cur, int nprep,
+                                                int32_t* __restrict__ cnt_out) {
+    __shared__ PairLds<NS> L;
+    const Snap& C = S.snap[cur];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x < nprep) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {     // this step's counters (k_finish updates them later in the stream)
+            cnt_out[C_EXIT] = cnt_out[3] = 0;
+            cnt_out[C_ACTIVE] = S.ctrl[C_NACTIVE];
         }
-        const double2 fw = wall_force_of(P, S.widx[k], p.x, p.y, vxd, vyd, vd, X0, Y0);
-        // noise: caller's standard normals, or Philox4x32-10 + Box-Muller (float32)
-        double n0, n1;
-        if (noise) {
-            n0 = noise[2 * (size_t)i];
-            n1 = noise[2 * (size_t)i + 1];
+        for (int t = blockIdx.x * 4 + w; t < S.ntiles; t += nprep * 4)
+            prep_tile(P, S, C, keys, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8]);
+        return;
+    }
+    const int tl = w / NS, sub = w % NS, it = ((int)blockIdx.x - nprep) * (4 / NS) + tl;
+    const bool live = it < S.ntiles;
+    if (live && sub == 0) pair_load_tile<NS>(P, C, S.pdk, L, it, tl, lane);
+    __syncthreads();
+    if (live) pair_share<NS>(P, S, C, L, it, tl, sub, w, lane);
+    __syncthreads();
+    if (live && sub == 0) S.f_pair[it * 64 + lane] = make_double2(L.accx[tl][lane], L.accy[tl][lane]);
+}
+
+#define RECT_TAB (1 + 4 * OC_MAX_TARGET_RECTS)      // doubles per key in the exit-rectangle table: count, then (cx,cy,w,h)
+#define RECT_KEYS_LDS 8
+
+// simulations.py:303-332 for the 64 agents of a tile, float64, then the next step's packed snapshot in place.
+// Everything is read by slot and was prepared by k_forces: one level of loads.
+__global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const double* __restrict__ rect_tab, int nkeys,
+                                               StepArgs A, int cur) {
+    __shared__ double l_rect[RECT_KEYS_LDS * RECT_TAB];
+    const Snap& C = S.snap[cur];
+    const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
+    const bool tab_lds = nkeys <= RECT_KEYS_LDS;
+    if (tab_lds)
+        for (int q = lane; q < nkeys * RECT_TAB; q += 64) l_rect[q] = rect_tab[q];
+    const int i = C.pidx[k];
+    const bool act = i >= 0;
+    bool out = false;
+    double nx = 1e300, ny = 1e300;
+    const double2 p = C.ppos[k], v = S.pvd[k], ds = S.des[k], fw = S.f_wall[k], fp = S.f_pair[k];
+    const PDK dk = S.pdk[k];
+    double n0 = 0.0, n1 = 0.0;
+    if (act) {      // noise: caller's standard normals, or Philox4x32-10 + Box-Muller (float32)
+        if (A.noise) {
+            n0 = A.noise[2 * (size_t)i];
+            n1 = A.noise[2 * (size_t)i + 1];
         } else {
             uint32_t r[4];
-            philox4x32_10((uint32_t)i, (uint32_t)step, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            philox4x32_10((uint32_t)i, (uint32_t)A.step, 0u, 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), r);
             float u1 = ((float)(r[0] >> 8) + 0.5f) * 0x1p-24f, u2 = ((float)(r[1] >> 8) + 0.5f) * 0x1p-24f;
             float rad = sqrtf(-2.0f * __logf(u1));
             n0 = (double)(rad * __cosf(6.2831853f * u2));
             n1 = (double)(rad * __sinf(6.2831853f * u2));
         }
+    }
+    __syncthreads();
+    if (act) {
         // simulations.py:303-326
-        const double cvx = vxd + P.noise_amp * n0 + fp.x + fw.x;
-        const double cvy = vyd + P.noise_amp * n1 + fp.y + fw.y;
+        const double cvx = v.x + P.noise_amp * n0 + fp.x + fw.x;
+        const double cvy = v.y + P.noise_amp * n1 + fp.y + fw.y;
         const double ax = (ds.x - cvx) / P.relaxation, ay = (ds.y - cvy) / P.relaxation;
         const double dt = P.dt, dt2 = dt * dt;
         nx = p.x + cvx * dt + 0.5 * ax * dt2;
@@ -1048,76 +1113,83 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const Ke
             nvx *= sc;
             nvy *= sc;
         }
-        x[i] = nx;
-        y[i] = ny;
-        vx[i] = nvx;
-        vy[i] = nvy;
-        if (agent_time) agent_time[i] += dt;
+        A.x[i] = nx;
+        A.y[i] = ny;
+        A.vx[i] = nvx;
+        A.vy[i] = nvy;
+        if (A.agent_time) A.agent_time[i] += dt;
         // exit test against the agent's own targets, strict (pedestrians.py:132-136)
-        for (int q = 0; q < kd.nrect; ++q)
-            if (fabs(nx - kd.rect[q][0]) < kd.rect[q][2] * 0.5 && fabs(ny - kd.rect[q][1]) < kd.rect[q][3] * 0.5)
-                out = true;
-        // next step's packed record
-        float4 pv;
-        float2 ph;
+        const double* rt = (tab_lds ? l_rect : rect_tab) + (size_t)dk.key * RECT_TAB;
+        const int nrect = (int)rt[0];
+        for (int q = 0; q < nrect; ++q)
+            if (fabs(nx - rt[1 + 4 * q]) < rt[3 + 4 * q] * 0.5 && fabs(ny - rt[2 + 4 * q]) < rt[4 + 4 * q] * 0.5) out = true;
         if (out) {
-            status[i] = 0;
-            S.ppos[k] = make_double2(1e300, 1e300);
-            S.pvel[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            S.phead[k] = make_float2(1.f, 0.f);
-            S.pidx[k] = -1;
+            A.status[i] = 0;
+            C.ppos[k] = make_double2(1e300, 1e300);
+            C.pvel[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            C.phead[k] = make_float2(1.f, 0.f);
+            C.pidx[k] = -1;
         } else {
+            float4 pv;
+            float2 ph;
             make_record(P, nvx, nvy, pv, ph);
-            S.ppos[k] = make_double2(nx, ny);
-            S.pvel[k] = pv;
-            S.phead[k] = ph;
-            need = wall_prepare(P, kd, X0, Y0, nx, ny, (double)pv.z, k, we);
+            C.ppos[k] = make_double2(nx, ny);
+            C.pvel[k] = pv;
+            C.phead[k] = ph;
+            S.pvd[k] = make_double2(nvx, nvy);
         }
-        S.widx[k] = -1;
     }
     const bool stay = act && !out;
-    // counters: one atomic per wavefront (100k same-address atomics cost > 1 ms)
-    unsigned long long m_out = __ballot(out), m_in = __ballot(stay);
-    const int lane = threadIdx.x;
-    if (m_out && lane == __ffsll((long long)m_out) - 1) atomicAdd(&cnt_out[C_EXIT], __popcll(m_out));
-    if (m_in && lane == __ffsll((long long)m_in) - 1) atomicAdd(&cnt_out[C_ACTIVE], __popcll(m_in));
-    wall_list_push(need, we, S.wall_list[nxt], &S.ctrl[C_WCOUNT + nxt]);
+    // counters: only exits touch them (one word takes ~88 atomics per us: 1563 tiles adding to one counter every step
+    // would cost more than the rest of this kernel)
+    const unsigned long long m_out = __ballot(out);
     // tile box of the new positions + validity of the neighbour lists
-    double mnx = wmin(stay ? nx : INFINITY), mny = wmin(stay ? ny : INFINITY);
-    double mxx = wmax(stay ? nx : -INFINITY), mxy = wmax(stay ? ny : -INFINITY);
+    const double mnx = wmin(stay ? nx : INFINITY), mny = wmin(stay ? ny : INFINITY);
+    const double mxx = wmax(stay ? nx : -INFINITY), mxy = wmax(stay ? ny : -INFINITY);
     if (lane == 0) {
-        S.tile_box[blockIdx.x] = make_double4(mnx, mny, mxx, mxy);
-        const double4 b0 = S.tile_box0[blockIdx.x];
+        if (it == 0) {                              // IndexError-band flag raised by the lookups of k_forces
+            A.cnt_out[C_ERR] = S.ctrl[C_ERR + 8];
+            S.ctrl[C_ERR + 8] = 0;
+        }
+        if (m_out) {
+            const int n = __popcll(m_out);
+            atomicAdd(&A.cnt_out[C_EXIT], n);
+            atomicSub(&A.cnt_out[C_ACTIVE], n);
+            atomicSub(&S.ctrl[C_NACTIVE], n);
+        }
+        C.tile_box[it] = make_double4(mnx, mny, mxx, mxy);
+        const double4 b0 = S.tile_box0[it];
         const double D = P.drift;
         if (mnx <= mxx && (mnx < b0.x - D || mny < b0.y - D || mxx > b0.z + D || mxy > b0.w + D)) S.ctrl[C_INVALID] = 1;
     }
 }
 
 // ---------------------------------------------------------------------------------- diagnostics (single-shot exports)
-__global__ void k_lookup_diag(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
-                              const int32_t* __restrict__ key_of, const double* __restrict__ v_des, int step,
+__global__ void k_lookup_diag(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, int cur, int step,
                               int32_t* err) {
+    const Snap& C = S.snap[cur];
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= S.Np) return;
-    int i = S.pidx[k];
+    int i = C.pidx[k];
     double2 d = make_double2(0.0, 0.0);
     if (i >= 0) {
-        double2 p = S.ppos[k];
-        d = lookup(P, keys[key_of[i]], p.x, p.y, v_des[i], step, i, err);
+        double2 p = C.ppos[k];
+        const PDK dk = S.pdk[k];
+        d = lookup(P, keys[dk.key], p.x, p.y, dk.v_des, step, i, err);
     }
     S.des[k] = d;
 }
 
-__global__ void k_wall_force_diag(GcfmParams P, Scratch S, const double* __restrict__ vx, const double* __restrict__ vy,
-                                  const double* __restrict__ v_des, const Axis X0,
-                                  const Axis Y0) {
+__global__ void k_wall_force_diag(GcfmParams P, Scratch S, int cur, const Axis X0, const Axis Y0) {
+    const Snap& C = S.snap[cur];
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= S.Np) return;
-    int i = S.pidx[k];
+    int i = C.pidx[k];
     double2 out = make_double2(0.0, 0.0);
     if (i >= 0) {
-        double2 p = S.ppos[k];
-        out = wall_force_of(P, S.widx[k], p.x, p.y, vx[i], vy[i], v_des[i], X0, Y0);
+        double2 p = C.ppos[k];
+        const double2 v = S.pvd[k];
+        out = wall_force_of(P, S.widx[k], p.x, p.y, v.x, v.y, S.pdk[k].v_des, X0, Y0);
     }
     S.f_wall[k] = out;
 }
@@ -1203,9 +1275,10 @@ int carve(oc_handle* h, int N, Scratch* S) {
     int Np = ((N + 63) / 64) * 64;
     if (Np == 0) Np = 64;
     const int nt = Np / 64;
-    size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + sizeof(double2) + sizeof(float4) + sizeof(float2) +
-                 sizeof(int32_t) + (2 + PAIR_SPLIT_MAX) * sizeof(double2) + sizeof(long long) + 2 * sizeof(WEntry);
-    size_t need = per * (size_t)Np + (2 * sizeof(double4) + (NB_MAX + 1) * sizeof(int32_t)) * (size_t)nt + 64 + 8192;
+    const size_t per_snap = sizeof(double2) + sizeof(float4) + sizeof(float2) + sizeof(int32_t);
+    const size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + 2 * per_snap + sizeof(double2) + sizeof(PDK) +
+                       3 * sizeof(double2) + sizeof(long long);
+    size_t need = per * (size_t)Np + (3 * sizeof(double4) + (NB_MAX + 1) * sizeof(int32_t)) * (size_t)nt + 64 + 16384;
     if (need > h->gcfm_bytes) {
         if (h->gcfm_buf) OC_HIP_CHECK(hipFree(h->gcfm_buf));
         h->gcfm_buf = nullptr;
@@ -1219,22 +1292,24 @@ int carve(oc_handle* h, int N, Scratch* S) {
         p += (bytes + 255) & ~(size_t)255;
         return (void*)q;
     };
-    S->ppos = (double2*)take(sizeof(double2) * Np);
-    S->pvel = (float4*)take(sizeof(float4) * Np);
-    S->f_pair = (double2*)take(sizeof(double2) * Np * PAIR_SPLIT_MAX);     // one slab per share of a tile
+    for (int b = 0; b < 2; ++b) {
+        S->snap[b].ppos = (double2*)take(sizeof(double2) * Np);
+        S->snap[b].pvel = (float4*)take(sizeof(float4) * Np);
+        S->snap[b].phead = (float2*)take(sizeof(float2) * Np);
+        S->snap[b].pidx = (int32_t*)take(sizeof(int32_t) * Np);
+        S->snap[b].tile_box = (double4*)take(sizeof(double4) * nt);
+    }
+    S->pvd = (double2*)take(sizeof(double2) * Np);
+    S->pdk = (PDK*)take(sizeof(PDK) * Np);
+    S->f_pair = (double2*)take(sizeof(double2) * Np);
     S->f_wall = (double2*)take(sizeof(double2) * Np);
     S->des = (double2*)take(sizeof(double2) * Np);
-    S->tile_box = (double4*)take(sizeof(double4) * nt);
     S->tile_box0 = (double4*)take(sizeof(double4) * nt);
     S->widx = (long long*)take(sizeof(long long) * Np);
-    S->phead = (float2*)take(sizeof(float2) * Np);
     S->keys_a = (uint32_t*)take(sizeof(uint32_t) * Np);
     S->keys_b = (uint32_t*)take(sizeof(uint32_t) * Np);
     S->vals_a = (int32_t*)take(sizeof(int32_t) * Np);
     S->vals_b = (int32_t*)take(sizeof(int32_t) * Np);
-    S->pidx = (int32_t*)take(sizeof(int32_t) * Np);
-    S->wall_list[0] = (WEntry*)take(sizeof(WEntry) * Np);
-    S->wall_list[1] = (WEntry*)take(sizeof(WEntry) * Np);
     S->nb_list = (int32_t*)take(sizeof(int32_t) * (NB_MAX + 1) * (size_t)nt);
     S->ctrl = (int32_t*)take(64);
     S->Np = Np;
@@ -1262,10 +1337,19 @@ int upload_keys(oc_handle* h, hipStream_t s) {
         d.nrect = h->rects[k].n;
         memcpy(d.rect, h->rects[k].r, sizeof(d.rect));
     }
-    if (!h->key_tables_dev) OC_HIP_CHECK(hipMalloc(&h->key_tables_dev, sizeof(KeyDev) * nk));
+    std::vector<double> rt(nk * RECT_TAB, 0.0);       // compact exit-rectangle table for k_finish
+    for (size_t k = 0; k < nk; ++k) {
+        rt[k * RECT_TAB] = (double)h->rects[k].n;
+        memcpy(&rt[k * RECT_TAB + 1], h->rects[k].r, sizeof(double) * 4 * OC_MAX_TARGET_RECTS);
+    }
+    if (!h->key_tables_dev) {
+        OC_HIP_CHECK(hipMalloc(&h->key_tables_dev, sizeof(KeyDev) * nk));
+        OC_HIP_CHECK(hipMalloc(&h->rect_tab_dev, sizeof(double) * nk * RECT_TAB));
+    }
     // synchronous copy of a small table: happens only when a field / target / wall map changed
     OC_HIP_CHECK(hipStreamSynchronize(s));
     OC_HIP_CHECK(hipMemcpy(h->key_tables_dev, host.data(), sizeof(KeyDev) * nk, hipMemcpyHostToDevice));
+    OC_HIP_CHECK(hipMemcpy(h->rect_tab_dev, rt.data(), sizeof(double) * nk * RECT_TAB, hipMemcpyHostToDevice));
     h->key_tables_dirty = false;
     return OC_OK;
 }
@@ -1283,7 +1367,7 @@ bool wallmaps_ready(const oc_handle* h) {
     return true;
 }
 
-// re-sort + full pack of the current state + neighbour lists + wall work-list
+// re-sort + full pack of the current state into snapshot buffer h->snap_parity + neighbour lists
 int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hipStream_t s) {
     const int N = a->N;
     OC_HIP_CHECK(hipMemsetAsync(S->ctrl, 0, 64, s));
@@ -1293,9 +1377,8 @@ int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hi
         int rc = oc_sort_pairs(h, S->keys_a, S->keys_b, S->vals_a, S->vals_b, N, 30, s);
         if (rc) return rc;
     }
-    const KeyDev* kd = wallmaps_ready(h) ? (const KeyDev*)h->key_tables_dev : nullptr;
-    hipLaunchKernelGGL(k_pack, dim3(S->ntiles), dim3(64), 0, s, a->x, a->y, a->vx, a->vy, a->status, a->key, S->vals_b, N,
-                       P, *S, kd, axis_x(h), axis_y(h), h->wl_parity);
+    hipLaunchKernelGGL(k_pack, dim3(S->ntiles), dim3(64), 0, s, a->x, a->y, a->vx, a->vy, a->v_des, a->status, a->key,
+                       S->vals_b, N, P, *S, h->snap_parity);
     hipLaunchKernelGGL(k_tile_lists, dim3(S->ntiles), dim3(64), 0, s, P, *S);
     h->steps_since_sort = 0;
     h->packed_x = a->x;
@@ -1368,11 +1451,12 @@ extern "C" int oc_field_lookup(oc_handle* h, const oc_agents* a, int32_t simu_st
     GcfmParams P;
     if ((rc = prepare(h, a, &S, &P, s))) return rc;
     h->packed_valid = false;
+    const int cur = h->snap_parity;
     OC_HIP_CHECK(hipMemsetAsync(des, 0, sizeof(double) * 2 * (size_t)a->N, s));
     if (err_flag) OC_HIP_CHECK(hipMemsetAsync(err_flag, 0, sizeof(int32_t) * 2, s));
     hipLaunchKernelGGL(k_lookup_diag, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, (const KeyDev*)h->key_tables_dev,
-                       a->key, a->v_des, simu_step, err_flag);
-    hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.des, S.pidx, S.Np,
+                       cur, simu_step, err_flag);
+    hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.des, S.snap[cur].pidx, S.Np,
                        (double2*)des);
     OC_HIP_CHECK(hipGetLastError());
     return OC_OK;
@@ -1388,19 +1472,19 @@ extern "C" int oc_wall_force(oc_handle* h, const oc_agents* a, int64_t* index_ou
     GcfmParams P;
     if ((rc = prepare(h, a, &S, &P, s))) return rc;
     h->packed_valid = false;
-    hipLaunchKernelGGL(k_wall, dim3(S.ntiles), dim3(64), 0, s, P, S, (const KeyDev*)h->key_tables_dev, a->key,
-                       axis_x(h), axis_y(h), h->wl_parity);
-    hipLaunchKernelGGL(k_wall_force_diag, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, a->vx, a->vy, a->v_des,
-                       axis_x(h), axis_y(h));
+    const int cur = h->snap_parity;
+    hipLaunchKernelGGL(k_wall, dim3(S.ntiles), dim3(64), 0, s, P, S, (const KeyDev*)h->key_tables_dev, axis_x(h),
+                       axis_y(h), cur);
+    hipLaunchKernelGGL(k_wall_force_diag, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, cur, axis_x(h), axis_y(h));
     if (index_out) {
         OC_HIP_CHECK(hipMemsetAsync(index_out, 0xFF, sizeof(int64_t) * (size_t)a->N, s));
-        hipLaunchKernelGGL(k_scatter<long long>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.widx, S.pidx, S.Np,
-                           (long long*)index_out);
+        hipLaunchKernelGGL(k_scatter<long long>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.widx, S.snap[cur].pidx,
+                           S.Np, (long long*)index_out);
     }
     if (force_out) {
         OC_HIP_CHECK(hipMemsetAsync(force_out, 0, sizeof(double) * 2 * (size_t)a->N, s));
-        hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_wall, S.pidx, S.Np,
-                           (double2*)force_out);
+        hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_wall, S.snap[cur].pidx,
+                           S.Np, (double2*)force_out);
     }
     OC_HIP_CHECK(hipGetLastError());
     return OC_OK;
@@ -1416,11 +1500,10 @@ extern "C" int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out
     GcfmParams P;
     if ((rc = prepare(h, a, &S, &P, s))) return rc;
     h->packed_valid = false;
-    oc_timer_begin(h, "gcfm_pair", s);
-    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, a->v_des);
-    oc_timer_end(h, "gcfm_pair", s);
+    const int cur = h->snap_parity;
+    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, cur);
     OC_HIP_CHECK(hipMemsetAsync(force_out, 0, sizeof(double) * 2 * (size_t)a->N, s));
-    hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_pair, S.pidx, S.Np,
+    hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_pair, S.snap[cur].pidx, S.Np,
                        (double2*)force_out);
     OC_HIP_CHECK(hipGetLastError());
     return OC_OK;
@@ -1441,22 +1524,28 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     if (!h->packed_valid || h->packed_x != a->x || h->packed_N != a->N || h->steps_since_sort >= h->resort_every) {
         if ((rc = repack(h, a, &S, P, s))) return rc;
     }
+    StepArgs A;
+    A.x = a->x; A.y = a->y; A.vx = a->vx; A.vy = a->vy;
+    A.status = a->status;
+    A.agent_time = a->agent_time;
+    A.noise = noise;
+    A.seed = seed;
+    A.step = simu_step;
+    A.cnt_out = counters ? counters : S.ctrl;
     const KeyDev* kd = (const KeyDev*)h->key_tables_dev;
-    const int cur = h->wl_parity, nxt = 1 - cur;
-    int32_t* cnt = counters ? counters : S.ctrl;
-    oc_timer_begin(h, "gcfm_pair", s);
-    const int nsplit = h->pair_split;
-    const int npair = (S.ntiles * nsplit + 3) / 4, nwall = std::min(std::max(S.ntiles / 8, 1), h->wall_blocks);
-    auto kf = nsplit == 4 ? k_forces<4> : (nsplit == 2 ? k_forces<2> : k_forces<1>);
-    hipLaunchKernelGGL(kf, dim3(nwall + npair), dim3(256), 0, s, P, S, a->v_des, kd, a->key, axis_x(h), axis_y(h), cur,
-                       nxt, cnt, nwall);
-    oc_timer_end(h, "gcfm_pair", s);
+    const int cur = h->snap_parity;
+    const int ns = h->pair_split, tpb = 4 / ns;
+    const int npair = (S.ntiles + tpb - 1) / tpb, nprep = std::min(std::max(S.ntiles / 4, 1), h->prep_blocks);
+    auto kf = ns == 4 ? k_forces<4> : (ns == 2 ? k_forces<2> : k_forces<1>);
+    oc_timer_begin(h, "gcfm_forces", s);
+    hipLaunchKernelGGL(kf, dim3(nprep + npair), dim3(256), 0, s, P, S, kd, simu_step, axis_x(h), axis_y(h), cur, nprep,
+                       A.cnt_out);
+    oc_timer_end(h, "gcfm_forces", s);
     oc_timer_begin(h, "gcfm_finish", s);
-    hipLaunchKernelGGL(k_finish, dim3(S.ntiles), dim3(64), 0, s, P, S, kd, a->key, a->x, a->y, a->vx, a->vy, a->v_des,
-                       a->status, a->agent_time, noise, seed, simu_step, axis_x(h), axis_y(h), nxt, cnt, nsplit);
+    hipLaunchKernelGGL(k_finish, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
+                       (int)h->fields.size(), A, cur);
     oc_timer_end(h, "gcfm_finish", s);
     OC_HIP_CHECK(hipGetLastError());
-    h->wl_parity = nxt;
     h->packed_valid = true;
     ++h->steps_since_sort;
     ++h->prof_tick;

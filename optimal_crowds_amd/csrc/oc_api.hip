@@ -55,9 +55,6 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
     OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * 2 * h->red_blocks));
     OC_HIP_CHECK(hipMalloc(&h->red_out, sizeof(double) * 16));
     OC_HIP_CHECK(hipHostMalloc(&h->red_host, sizeof(double) * 2 * OC_MAX_WORLD));
-    OC_HIP_CHECK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-    OC_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    OC_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     *out = h;
     return OC_OK;
 }
@@ -78,11 +75,9 @@ extern "C" int oc_destroy(oc_handle* h) {
         (void)hipFree(w.gap8);
     }
     (void)hipFree(h->key_tables_dev);
+    (void)hipFree(h->rect_tab_dev);
     (void)hipFree(h->gcfm_buf);
     (void)hipFree(h->sort_tmp);
-    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (auto& kv : h->timers)
         for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
     delete h;
@@ -195,9 +190,9 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     if (!strcmp(name, "pair_split")) {
         OC_REQUIRE(value == 1 || value == 2 || value == 4, "pair_split must be 1, 2 or 4");
         h->pair_split = value;
-    } else if (!strcmp(name, "wall_blocks")) {
-        OC_REQUIRE(value >= 1 && value <= 4096, "wall_blocks out of range");
-        h->wall_blocks = value;
+    } else if (!strcmp(name, "prep_blocks")) {
+        OC_REQUIRE(value >= 1 && value <= 65536, "prep_blocks out of range");
+        h->prep_blocks = value;
     } else {
         oc_set_error("oc_set_tuning: unknown knob '%s'", name);
         return OC_ERR_ARG;

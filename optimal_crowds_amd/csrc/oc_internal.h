@@ -78,6 +78,7 @@ struct oc_handle {
     std::vector<oc_wallmap> wallmaps;
     std::vector<oc_key_rects> rects;
     void* key_tables_dev = nullptr;  // device copy of per-key descriptors for the step kernels
+    void* rect_tab_dev = nullptr;    // compact exit-rectangle table (gcfm.hip: RECT_TAB doubles per key)
     bool key_tables_dirty = true;
     // ---- GCFM scratch
     int32_t resort_every = 16;
@@ -86,11 +87,9 @@ struct oc_handle {
     bool packed_valid = false;  // the packed snapshot matches the caller's state arrays
     const void* packed_x = nullptr;
     int32_t packed_N = -1;
-    int pair_split = 2;         // pair wavefronts per i-tile (1, 2 or 4): occupancy of k_forces (gcfm.hip)
-    int wall_blocks = 128;      // blocks of k_forces that sweep the wall work-list
-    hipStream_t aux_stream = nullptr;   // k_wall runs here, beside k_pair
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int wl_parity = 0;          // which wall work-list the next step consumes
+    int pair_split = 2;         // pair wavefronts per tile (1, 2 or 4): occupancy / balance of k_forces (gcfm.hip)
+    int prep_blocks = 256;      // blocks of k_forces that do the wall search / field lookup of the tiles
+    int snap_parity = 0;        // which buffer of the packed snapshot is current
     void* gcfm_buf = nullptr;   // carved in gcfm.hip
     size_t gcfm_bytes = 0;
     void* sort_tmp = nullptr;

@@ -1,4 +1,4 @@
-# PMC passes over k_forces (run on the GPU box from the repo root): bash tools/pmc_forces.sh <tag> [bench flags]
+# PMC passes over k_forces|k_finish (run on the GPU box from the repo root): bash tools/pmc_forces.sh <tag> [bench flags]
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 out=gpurun_out/pmc_$tag
