@@ -190,7 +190,7 @@ int oc_reset_kernel_stats(oc_handle* h);
 /* 0 = fused HJB kernels (default), 1 = simple one-array-pass kernels (cross-check). */
 int oc_set_hjb_variant(oc_handle* h, int variant);
 /* Launch-shape knobs of the step kernels (results do not depend on them beyond float64 summation order):
- *   "pair_split"  1, 2 or 4 pair wavefronts per tile of 64 agents (default 2)
+ *   "pair_split"  1, 2 or 4 pair wavefronts per tile of 64 agents (default 4)
  *   "prep_blocks" blocks of the force kernel that do the wall search / field lookup of the tiles (default 256) */
 int oc_set_tuning(oc_handle* h, const char* name, int value);
 

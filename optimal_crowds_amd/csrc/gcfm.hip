@@ -86,6 +86,8 @@ struct Scratch {
     PDK* pdk;
     double4* tile_box0;
     int32_t* nb_list;       // [ntiles][NB_MAX + 1]: count (or -1 = overflow) then tile ids
+    int32_t* tile_work;     // candidate-list entries each tile processed in the last step (its pair work)
+    int32_t* tile_order;    // tiles by decreasing work: k_forces dispatches the heavy ones first
     double2 *f_pair, *f_wall, *des;     // single-shot diagnostic exports only
     long long* widx;
     int32_t* ctrl;
@@ -369,7 +371,7 @@ __device__ __forceinline__ bool box_hit(const double4& a, const double4& b, doub
 }
 
 // neighbour-tile lists from the sort-time boxes: one wavefront per tile
-__global__ void __launch_bounds__(64) k_tile_lists(GcfmParams P, Scratch S) {
+__global__ void __launch_bounds__(64) k_tile_lists(GcfmParams P, Scratch S, int have_work) {
     const int it = blockIdx.x, lane = threadIdx.x;
     const double4 bi = S.tile_box0[it];
     const double c = P.cutoff + 2.0 * P.drift;
@@ -383,7 +385,14 @@ __global__ void __launch_bounds__(64) k_tile_lists(GcfmParams P, Scratch S) {
         if (hit && pos < NB_MAX) out[1 + pos] = t;
         cnt += __popcll(m);
     }
-    if (lane == 0) out[0] = (cnt <= NB_MAX) ? cnt : -1;
+    if (lane == 0) {
+        out[0] = (cnt <= NB_MAX) ? cnt : -1;
+        // sort key for the dispatch order (ascending sort -> decreasing work): the tile's measured work of the last
+        // step (same place along the curve, nearly the same agents), or its neighbour count before any step ran
+        const int est = have_work ? S.tile_work[it] : cnt;
+        S.keys_a[it] = 0x00FFFFFFu - (uint32_t)min(max(est, 0), 0x00FFFFFF);
+        S.vals_a[it] = it;
+    }
 }
 
 // ---------------------------------------------------------------------------------- pair forces
@@ -454,11 +463,11 @@ struct PairLds {
     float4 li_vel[TPB][64];
     float4 li_aux[TPB][64];     // (hx, hy, 1/b_i^2, 1/v_des_i)
     double accx[TPB][64], accy[TPB][64];
-    double2 l_pos[4][NJ];
-    float4 l_vel[4][NJ];
-    float2 l_head[4][NJ];
-    alignas(16) float l_rx[4][NJ];
-    alignas(16) float l_ry[4][NJ];
+    double2 l_pos[4][64];       // per wavefront: the staged virtual j-tile (64 records)
+    float4 l_vel[4][64];
+    float2 l_head[4][64];
+    alignas(16) float l_rx[4][64];
+    alignas(16) float l_ry[4][64];
     uint32_t list[4][PAIR_LIST_CAP];
 };
 
@@ -484,27 +493,30 @@ __device__ __forceinline__ void pair_load_tile(const GcfmParams& P, const Snap& 
     L.accy[tl][lane] = 0.0;
 }
 
+
 // One WAVEFRONT per (i-tile, share).  The NS wavefronts of a tile sit in one block and share the tile's i records
-// and force sums in LDS; share `sub` takes the j = sub*64/NS .. (sub+1)*64/NS - 1 of EVERY candidate j-tile, so the
-// shares of a tile carry equal work whatever the geometry.  Splitting exists for occupancy and balance: a tile's
+// and force sums in LDS; share `sub` owns the records j = sub*64/NS .. (sub+1)*64/NS - 1 of EVERY candidate j-tile, so
+// the shares of a tile carry equal work whatever the geometry.  Splitting exists for occupancy and balance: a tile's
 // work is one long chain, the chip holds only ~1.5 tiles per SIMD, and the launch ends with its slowest wavefront.
-// Per j-tile:
-//   stage    this share's NJ = 64/NS packed records go to wave-private LDS; the next tile's records are already being
-//            loaded (register prefetch) while this one is processed;
-//   phase 1  per lane (= agent i) an NJ-bit candidate mask from a conservative float32 distance test on box-relative
+// A share gathers its 64/NS records of NS candidate tiles at a time into one VIRTUAL j-tile of 64 records, so the
+// per-tile overheads (staging wait, prefix scan, barriers, short chunks) are paid once per 64 records whatever NS.
+// Per virtual j-tile:
+//   stage    its 64 packed records go to wave-private LDS; the next one's records are already being loaded
+//            (register prefetch) while this one is processed;
+//   phase 1  per lane (= agent i) a 64-bit candidate mask from a conservative float32 distance test on box-relative
 //            coordinates: packed float2 math, sign bits collected with v_alignbit (3 VALU per j);
 //   compact  candidates are appended, two per entry, to a wave-private LDS list, lane-major (sorted by agent); dense
-//            tile pairs (more than PAIR_LIST_CAP entries) are taken in rounds of 32 j each;
+//            tile pairs (more than PAIR_LIST_CAP entries) are taken in two rounds of 32 records;
 //   phase 2  every lane walks a contiguous chunk of the list: exact float64 cutoff decision, packed float32 force,
 //            float64 LDS atomic accumulation when the agent changes.
 // The caller brackets this with block barriers (i records loaded before, sums complete after).
 template <int NS>
 __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S, const Snap& C, PairLds<NS>& L, int it,
                                            int tl, int sub, int w, int lane) {
-    constexpr int NJ = 64 / NS;                   // j records of a tile handled by this share
-    constexpr int NW = (NJ + 31) / 32;            // 32-bit mask words per lane
-    constexpr int WB = NJ < 32 ? NJ : 32;         // bits used per word
-    constexpr int NROUND = NW;                    // rounds of 32 j for a dense tile pair
+    constexpr int NJ = 64 / NS;                   // records of a real tile owned by this share
+    constexpr int NW = 2;                         // 32-bit mask words per lane (64 records)
+    constexpr int WB = 32;
+    constexpr int NROUND = 2;                     // rounds of 32 records for a dense virtual tile
     const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
     const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
     const double c = P.cutoff, c2 = c * c;
@@ -516,6 +528,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
     const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
     const f2v xi2 = {xi_f, xi_f}, yi2 = {yi_f, yi_f};
     uint32_t* lst = L.list[w];
+    int work = 0;                                   // list entries processed: the tile's measured work
     const int j0 = sub * NJ;                        // this share's records of a j-tile: j0 .. j0 + NJ - 1
     const int jl = lane & (NJ - 1);                 // lanes >= NJ duplicate the loads of lanes < NJ (same cache lines)
 
@@ -531,44 +544,56 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
         const bool hit = (t >= 0) && box_hit(bi, C.tile_box[t], c);
         unsigned long long tmask = __ballot(hit);
         if (!tmask) continue;
-        // prefetch the first hit of this chunk
-        int jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
-        tmask &= tmask - 1;
+        // next virtual tile: the NS lowest remaining hits; lane l fetches record j0 + l % NJ of hit l / NJ
+        int jts[NS];
         JRec cur;
-        cur.pos = C.ppos[jt * 64 + j0 + jl];
-        cur.vel = C.pvel[jt * 64 + j0 + jl];
-        cur.head = C.phead[jt * 64 + j0 + jl];
-        double4 bj = C.tile_box[jt];
-        for (;;) {
-            // ---- stage this share of tile jt (registers -> wave-private LDS; LDS ops of one wavefront complete in
-            // order, so the single buffer is safe: the previous tile's reads were issued before these writes)
-            if (lane < NJ) {
-                L.l_pos[w][lane] = cur.pos;
-                L.l_rx[w][lane] = (float)(cur.pos.x - ox);
-                L.l_ry[w][lane] = (float)(cur.pos.y - oy);
-                L.l_vel[w][lane] = cur.vel;
-                L.l_head[w][lane] = cur.head;
+        float ext = 0.f;
+        auto fetch = [&]() {
+            ext = 0.f;
+            int jt_l = -1;
+#pragma unroll
+            for (int b = 0; b < NS; ++b) {
+                jts[b] = -1;
+                if (tmask) {
+                    jts[b] = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
+                    tmask &= tmask - 1;
+                    // conservative float32 bound: rounding of the relative coordinates scales with the boxes' extent
+                    const double4 bj = C.tile_box[jts[b]];
+                    ext = fmaxf(ext, (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
+                                             fmax(fmax(bi.w, bj.w) - oy, oy - fmin(bi.y, bj.y))));
+                }
+                if (lane / NJ == b) jt_l = jts[b];
             }
-            // conservative float32 bound: rounding of the relative coordinates scales with the boxes' extent
-            const float ext = (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
-                                      fmax(fmax(bi.w, bj.w) - oy, oy - fmin(bi.y, bj.y)));
+            cur.pos = make_double2(1e300, 1e300);
+            cur.vel = make_float4(0.f, 0.f, 0.f, 0.f);
+            cur.head = make_float2(1.f, 0.f);
+            if (jt_l >= 0) {
+                cur.pos = C.ppos[jt_l * 64 + j0 + jl];
+                cur.vel = C.pvel[jt_l * 64 + j0 + jl];
+                cur.head = C.phead[jt_l * 64 + j0 + jl];
+            }
+        };
+        fetch();
+        for (;;) {
+            // ---- stage the virtual tile (registers -> wave-private LDS; LDS ops of one wavefront complete in order,
+            // so the single buffer is safe: the previous tile's reads were issued before these writes)
+            L.l_pos[w][lane] = cur.pos;
+            L.l_rx[w][lane] = (float)(cur.pos.x - ox);
+            L.l_ry[w][lane] = (float)(cur.pos.y - oy);
+            L.l_vel[w][lane] = cur.vel;
+            L.l_head[w][lane] = cur.head;
             const float c2f = (float)c2 * 1.00001f + 1e-6f * ext * (ext + (float)c);
             const f2v nc2 = {-c2f, -c2f};
-            const int jt_now = jt;
-            // ---- start loading the next hit while this tile is processed
+            int bself = -1;                                 // position of the i-tile itself in this virtual tile
+#pragma unroll
+            for (int b = 0; b < NS; ++b) bself = (jts[b] == it) ? b : bself;
+            // ---- start loading the next virtual tile while this one is processed
             const bool more = tmask != 0ull;
-            if (more) {
-                jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
-                tmask &= tmask - 1;
-                cur.pos = C.ppos[jt * 64 + j0 + jl];
-                cur.vel = C.pvel[jt * 64 + j0 + jl];
-                cur.head = C.phead[jt * 64 + j0 + jl];
-                bj = C.tile_box[jt];
-            }
+            if (more) fetch();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- phase 1: sign(d^2 - c2f) of local j = 0..NJ-1; local j = 32*h + q sits at bit 31 - q of word h
+            // ---- phase 1: sign(d^2 - c2f) of records 0..63; record 32*h + q sits at bit 31 - q of word h
             uint32_t mw[NW];
 #pragma unroll
             for (int h = 0; h < NW; ++h) {
@@ -588,7 +613,10 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 }
                 mw[h] = acc << (32 - WB);
             }
-            if (jt_now == it && (lane / NJ) == sub) mw[jl >> 5] &= ~(0x80000000u >> (jl & 31));        // j != i
+            if (bself >= 0 && (lane / NJ) == sub) {                                           // j != i
+                const int rs = bself * NJ + jl;
+                mw[rs >> 5] &= ~(0x80000000u >> (rs & 31));
+            }
             if (i < 0) {
 #pragma unroll
                 for (int h = 0; h < NW; ++h) mw[h] = 0u;
@@ -622,6 +650,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 }
                 const int total = __builtin_amdgcn_readlane(incl, 63);
                 if (total == 0) continue;
+                work += total;
                 {   // entry: agent lane << 16 | B valid << 14 | jB << 7 | jA
                     int off = incl - cntl;
                     int prev = -1;
@@ -697,6 +726,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
             if (!more) break;
         }
     }
+    if (lane == 0) atomicAdd(&S.tile_work[it], work);
 }
 
 // ---------------------------------------------------------------------------------- nearest-wall-cell search
@@ -1055,9 +1085,13 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
             prep_tile(P, S, C, keys, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8]);
         return;
     }
-    const int tl = w / NS, sub = w % NS, it = ((int)blockIdx.x - nprep) * (4 / NS) + tl;
-    const bool live = it < S.ntiles;
-    if (live && sub == 0) pair_load_tile<NS>(P, C, S.pdk, L, it, tl, lane);
+    const int tl = w / NS, sub = w % NS, ord = ((int)blockIdx.x - nprep) * (4 / NS) + tl;
+    const bool live = ord < S.ntiles;
+    const int it = live ? S.tile_order[ord] : 0;    // heavy tiles first: the launch ends with its slowest wavefront
+    if (live && sub == 0) {
+        if (lane == 0) S.tile_work[it] = 0;
+        pair_load_tile<NS>(P, C, S.pdk, L, it, tl, lane);
+    }
     __syncthreads();
     if (live) pair_share<NS>(P, S, C, L, it, tl, sub, w, lane);
     __syncthreads();
@@ -1278,13 +1312,14 @@ int carve(oc_handle* h, int N, Scratch* S) {
     const size_t per_snap = sizeof(double2) + sizeof(float4) + sizeof(float2) + sizeof(int32_t);
     const size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + 2 * per_snap + sizeof(double2) + sizeof(PDK) +
                        3 * sizeof(double2) + sizeof(long long);
-    size_t need = per * (size_t)Np + (3 * sizeof(double4) + (NB_MAX + 1) * sizeof(int32_t)) * (size_t)nt + 64 + 16384;
+    size_t need = per * (size_t)Np + (3 * sizeof(double4) + (NB_MAX + 3) * sizeof(int32_t)) * (size_t)nt + 64 + 16384;
     if (need > h->gcfm_bytes) {
         if (h->gcfm_buf) OC_HIP_CHECK(hipFree(h->gcfm_buf));
         h->gcfm_buf = nullptr;
         OC_HIP_CHECK(hipMalloc(&h->gcfm_buf, need));
         h->gcfm_bytes = need;
         h->packed_valid = false;
+        h->work_valid = false;
     }
     char* p = (char*)h->gcfm_buf;
     auto take = [&](size_t bytes) {
@@ -1311,6 +1346,8 @@ int carve(oc_handle* h, int N, Scratch* S) {
     S->vals_a = (int32_t*)take(sizeof(int32_t) * Np);
     S->vals_b = (int32_t*)take(sizeof(int32_t) * Np);
     S->nb_list = (int32_t*)take(sizeof(int32_t) * (NB_MAX + 1) * (size_t)nt);
+    S->tile_work = (int32_t*)take(sizeof(int32_t) * nt);
+    S->tile_order = (int32_t*)take(sizeof(int32_t) * nt);
     S->ctrl = (int32_t*)take(64);
     S->Np = Np;
     S->ntiles = nt;
@@ -1379,7 +1416,13 @@ int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hi
     }
     hipLaunchKernelGGL(k_pack, dim3(S->ntiles), dim3(64), 0, s, a->x, a->y, a->vx, a->vy, a->v_des, a->status, a->key,
                        S->vals_b, N, P, *S, h->snap_parity);
-    hipLaunchKernelGGL(k_tile_lists, dim3(S->ntiles), dim3(64), 0, s, P, *S);
+    const bool have_work = h->work_valid && h->work_tiles == S->ntiles;
+    if (!have_work) OC_HIP_CHECK(hipMemsetAsync(S->tile_work, 0, sizeof(int32_t) * S->ntiles, s));
+    hipLaunchKernelGGL(k_tile_lists, dim3(S->ntiles), dim3(64), 0, s, P, *S, have_work ? 1 : 0);
+    {   // dispatch order of the tiles: decreasing work
+        int rc = oc_sort_pairs(h, S->keys_a, S->keys_b, S->vals_a, S->tile_order, S->ntiles, 24, s);
+        if (rc) return rc;
+    }
     h->steps_since_sort = 0;
     h->packed_x = a->x;
     h->packed_N = N;
@@ -1541,6 +1584,8 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     hipLaunchKernelGGL(kf, dim3(nprep + npair), dim3(256), 0, s, P, S, kd, simu_step, axis_x(h), axis_y(h), cur, nprep,
                        A.cnt_out);
     oc_timer_end(h, "gcfm_forces", s);
+    h->work_valid = true;
+    h->work_tiles = S.ntiles;
     oc_timer_begin(h, "gcfm_finish", s);
     hipLaunchKernelGGL(k_finish, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
                        (int)h->fields.size(), A, cur);

@@ -87,8 +87,10 @@ struct oc_handle {
     bool packed_valid = false;  // the packed snapshot matches the caller's state arrays
     const void* packed_x = nullptr;
     int32_t packed_N = -1;
-    int pair_split = 2;         // pair wavefronts per tile (1, 2 or 4): occupancy / balance of k_forces (gcfm.hip)
+    int pair_split = 4;         // pair wavefronts per tile (1, 2 or 4): occupancy / balance of k_forces (gcfm.hip)
     int prep_blocks = 256;      // blocks of k_forces that do the wall search / field lookup of the tiles
+    bool work_valid = false;    // tile_work holds a step's measured pair work (for the dispatch order)
+    int work_tiles = -1;
     int snap_parity = 0;        // which buffer of the packed snapshot is current
     void* gcfm_buf = nullptr;   // carved in gcfm.hip
     size_t gcfm_bytes = 0;
