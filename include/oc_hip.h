@@ -187,7 +187,8 @@ int oc_density(oc_handle* h, int dtype, const oc_agents* a, double sigma, const 
 int oc_set_profiling(oc_handle* h, int mode);
 int oc_kernel_stats(oc_handle* h, const char* name, int64_t* launches, double* total_ms, double* total_bytes);
 int oc_reset_kernel_stats(oc_handle* h);
-/* 0 = fused HJB kernels (default), 1 = simple one-array-pass kernels (cross-check). */
+/* 0 = three RK stages per launch (default), 1 = simple one-array-pass kernels (cross-check),
+ * 2 = one fused launch per stage (the arithmetic of all three is identical). */
 int oc_set_hjb_variant(oc_handle* h, int variant);
 /* Launch-shape knobs of the step kernels (results do not depend on them beyond float64 summation order):
  *   "pair_split"  1, 2 or 4 pair wavefronts per tile of 64 agents (default 4)

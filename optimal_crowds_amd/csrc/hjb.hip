@@ -430,6 +430,149 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
     }
 }
 
+// ---- three RK stages per launch ---------------------------------------------------------------------------------
+// One RK attempt is 6 right-hand sides, each needing the previous ones on a 1-cell halo.  k_stage3 evaluates THREE of
+// them on a 64 x 32 tile in one launch: the inputs (y, the earlier K's, coef) are read once on the tile + a 3-cell
+// halo (70 x 38 cells), every intermediate stays in registers, and only the stage's working value y + h sum a_sj K_j
+// goes through LDS for the stencil, on a region that shrinks by one ring per stage.  Two launches per attempt:
+//   A  reads y, K0, coef                 writes K1, K2, K3               6 array passes
+//   B  reads y, K0..K3, coef             writes K4, K5, y_new, K6        10 array passes (+ the error norm)
+// against 39 passes for one launch per stage; the halo re-reads (1.3x) are served by L2.  The arithmetic per cell is
+// the sequence of k_stage, so the results are bit-identical.  Cells are dealt to threads round-robin over the region
+// (cell = thread + F3_NT m), all loops unrolled.
+#ifndef F3_X
+#define F3_X 64
+#endif
+#ifndef F3_Y
+#define F3_Y 32
+#endif
+#define F3_H 3
+#define F3_RW (F3_X + 2 * F3_H)
+#define F3_RH (F3_Y + 2 * F3_H)
+#define F3_LS (F3_RW + 2)
+#define F3_NCELL (F3_RW * F3_RH)
+#ifndef F3_NT
+#define F3_NT 1024              // threads per tile: 3 cells each -> ~64 registers, full occupancy (the launch is latency-
+#endif                          // bound per block: load burst, three short stencil rounds, store burst)
+#define F3_NC ((F3_NCELL + F3_NT - 1) / F3_NT)
+
+template <typename T>
+struct Stage3Args {
+    const T* y;
+    const T* kin[4];        // K0 .. K_{S0-1}
+    const T* coef;
+    T* kout[3];             // the three new stage derivatives
+    T* ynew;                // FINAL only
+    T c[3][6];              // stage q of the launch: h * a_{s,j} for slot j (inputs first, then the new K's; 0 = unused)
+    T he[7];                // FINAL: h * E_j for K0..K6
+    T atol, rtol, a_lap;
+    double* partial;
+    int Ny, Nx;
+    int row_lo, row_hi;     // rows whose error / max|y| this launch accounts for
+};
+
+template <typename T, int S0, bool FINAL>
+__global__ void __launch_bounds__(F3_NT) k_stage3(Stage3Args<T> A) {
+    __shared__ T buf[2][F3_RH][F3_LS];
+    const int Ny = A.Ny, Nx = A.Nx;
+    const int nbx = (Nx + F3_X - 1) / F3_X, nby = (Ny + F3_Y - 1) / F3_Y, nb = nbx * nby;
+    const int per = (nb + 7) / 8;
+    const int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);        // XCD-aware order (tile_of_block)
+    if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
+    const int i0 = (logical / nbx) * F3_Y - F3_H, j0 = (logical % nbx) * F3_X - F3_H;   // region origin
+    T yv[F3_NC], kv[S0 + 3][F3_NC], cf[F3_NC], tq[F3_NC];
+    int row[F3_NC], col[F3_NC], ring[F3_NC];        // ring < 0: not a cell of the room
+#pragma unroll
+    for (int m = 0; m < F3_NC; ++m) {
+        const int c = (int)threadIdx.x + F3_NT * m;
+        row[m] = c / F3_RW;
+        col[m] = c - row[m] * F3_RW;
+        const int gi = i0 + row[m], gj = j0 + col[m];
+        const bool in = c < F3_NCELL && gi >= 0 && gi < Ny && gj >= 0 && gj < Nx;
+        ring[m] = in ? min(min(row[m], F3_RH - 1 - row[m]), min(col[m], F3_RW - 1 - col[m])) : -1;
+        yv[m] = cf[m] = tq[m] = (T)0;
+#pragma unroll
+        for (int j = 0; j < S0 + 3; ++j) kv[j][m] = (T)0;
+        if (in) {
+            const int64_t idx = (int64_t)gi * Nx + gj;
+            yv[m] = A.y[idx];
+#pragma unroll
+            for (int j = 0; j < S0; ++j) kv[j][m] = A.kin[j][idx];
+            if (ring[m] >= 1) cf[m] = A.coef[idx];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        // the stage's working value on the region that is still complete: rings >= q
+#pragma unroll
+        for (int m = 0; m < F3_NC; ++m) {
+            if (ring[m] >= q) {
+                T t = (T)0;
+#pragma unroll
+                for (int j = 0; j < S0 + q; ++j) t += A.c[q][j] * kv[j][m];
+                t = yv[m] + t;
+                tq[m] = t;
+                buf[q & 1][row[m]][col[m]] = t;
+            }
+        }
+        __syncthreads();
+        // its right-hand side one ring further in; mirror ghosts at the room border (optimals.py:149-152)
+#pragma unroll
+        for (int m = 0; m < F3_NC; ++m) {
+            if (ring[m] >= q + 1) {
+                const int gi = i0 + row[m], gj = j0 + col[m];
+                const int ru = (gi == 0) ? row[m] + 1 : row[m] - 1, rd = (gi == Ny - 1) ? row[m] - 1 : row[m] + 1;
+                const int cl = (gj == 0) ? col[m] + 1 : col[m] - 1, cr = (gj == Nx - 1) ? col[m] - 1 : col[m] + 1;
+                const T C = tq[m];
+                const T sum = buf[q & 1][ru][col[m]] + buf[q & 1][rd][col[m]] + buf[q & 1][row[m]][cl] +
+                              buf[q & 1][row[m]][cr] - (T)4 * C;
+                kv[S0 + q][m] = (cf[m] != cf[m]) ? (T)0 : A.a_lap * sum - cf[m] * C;
+            }
+        }
+    }
+    double esum = 0.0, ymax = 0.0;
+#pragma unroll
+    for (int m = 0; m < F3_NC; ++m) {
+        if (ring[m] >= F3_H) {
+            const int gi = i0 + row[m], gj = j0 + col[m];
+            const int64_t idx = (int64_t)gi * Nx + gj;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) A.kout[q][idx] = kv[S0 + q][m];
+            if (FINAL) {
+                A.ynew[idx] = tq[m];
+                if (gi >= A.row_lo && gi < A.row_hi) {
+                    T e = A.he[6] * kv[S0 + 2][m];
+#pragma unroll
+                    for (int j = 0; j < S0 + 2; ++j) e += A.he[j] * kv[j][m];
+                    const T sc = A.atol + fmax(fabs(yv[m]), fabs(tq[m])) * A.rtol;
+                    const T qq = e / sc;
+                    esum += (double)qq * (double)qq;
+                    ymax = fmax(ymax, (double)fabs(tq[m]));
+                }
+            }
+        }
+    }
+    if (FINAL) {
+        __shared__ double ls[F3_NT / 64], lm[F3_NT / 64];
+        esum = wave_sum(esum);
+        ymax = wave_max(ymax);
+        if ((threadIdx.x & 63) == 0) {
+            ls[threadIdx.x >> 6] = esum;
+            lm[threadIdx.x >> 6] = ymax;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0, b = 0.0;
+            for (int q = 0; q < F3_NT / 64; ++q) {
+                a += ls[q];
+                b = fmax(b, lm[q]);
+            }
+            A.partial[2 * logical] = a;
+            A.partial[2 * logical + 1] = b;
+        }
+    }
+}
+
 // Dense output + direction field for every t_eval point of one accepted step, in one pass: the quartic
 // interpolant's coefficients Q = K^T P (scipy rk.py:178-180) stay in registers, each slice's phi goes through a
 // double-buffered LDS tile, and vels (optimals.py:168-186) writes the slice of the (padded) direction field.
@@ -688,6 +831,44 @@ void launch_stages_fused(Solver<T>& S, double hh, T atol_s, T rtol) {
     hipLaunchKernelGGL((k_stage<T, 5, true>), dim3(S.fused_grid()), dim3(256), 0, S.s, A);
 }
 
+// the six RHS evaluations of one RK attempt as two launches of three stages each (k_stage3)
+template <typename T>
+int launch_stages_fused3(Solver<T>& S, double hh, T atol_s, T rtol) {
+    Stage3Args<T> A;
+    memset(&A, 0, sizeof(A));
+    A.y = S.y;
+    A.coef = S.coef;
+    A.Ny = S.Ny;
+    A.Nx = S.Nx;
+    A.a_lap = S.a_lap;
+    A.atol = atol_s;
+    A.rtol = rtol;
+    A.partial = S.h->red_partial;
+    A.row_lo = S.sh ? S.sh->own_lo : 0;
+    A.row_hi = S.sh ? S.sh->own_hi : S.Ny;
+    const int nb = ((S.Nx + F3_X - 1) / F3_X) * ((S.Ny + F3_Y - 1) / F3_Y);
+    const dim3 grid(8 * ((nb + 7) / 8));
+    // launch A: stages 1..3 from K0
+    A.kin[0] = S.K[0];
+    for (int q = 0; q < 3; ++q) {
+        for (int j = 0; j < 6; ++j) A.c[q][j] = j < 1 + q ? (T)(RK_A[1 + q][j] * hh) : (T)0;
+        A.kout[q] = S.K[1 + q];
+    }
+    hipLaunchKernelGGL((k_stage3<T, 1, false>), grid, dim3(F3_NT), 0, S.s, A);
+    // launch B: stages 4, 5 and y_new / K6 / error from K0..K3
+    for (int j = 0; j < 4; ++j) A.kin[j] = S.K[j];
+    for (int q = 0; q < 2; ++q) {
+        for (int j = 0; j < 6; ++j) A.c[q][j] = j < 4 + q ? (T)(RK_A[4 + q][j] * hh) : (T)0;
+        A.kout[q] = S.K[4 + q];
+    }
+    for (int j = 0; j < 6; ++j) A.c[2][j] = (T)(RK_B[j] * hh);
+    A.kout[2] = S.K[6];
+    A.ynew = S.ynew;
+    for (int j = 0; j < 7; ++j) A.he[j] = (T)(RK_E[j] * hh);
+    hipLaunchKernelGGL((k_stage3<T, 4, true>), grid, dim3(F3_NT), 0, S.s, A);
+    return nb;
+}
+
 // dense output of every t_eval point in (t_new, t] + direction field slices, <= OUT_MAXS slices per launch
 template <typename T>
 int emit_slices_fused(Solver<T>& S, const std::vector<double>& te, int nt, int& k_next, double t, double t_new,
@@ -768,7 +949,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
     const int64_t n = S.n;
     const double rtol = c.rtol, atol0 = c.atol;
     const int RB = 1024;
-    const bool use_fused = (h->hjb_variant == 0) && (c.Nx % 4 == 0);   // vector kernels need 16-byte rows
+    const bool use_fused = (h->hjb_variant != 1) && (c.Nx % 4 == 0);   // vector kernels need 16-byte rows
     if (sh && !use_fused) {
         oc_set_error("hjb_solve_rows needs the fused kernels (Nx %% 4 == 0, hjb variant 0)");
         return OC_ERR_ARG;
@@ -861,7 +1042,10 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
             int nred = RB;
             double atol_s = atol0 * scale_of();
             oc_timer_begin(h, "hjb_stage", s);
-            if (use_fused) {
+            if (use_fused && h->hjb_variant == 0) {
+                nred = launch_stages_fused3(S, hh, (T)atol_s, (T)rtol);
+                S.nfev += 6;
+            } else if (use_fused) {
                 launch_stages_fused(S, hh, (T)atol_s, (T)rtol);
                 S.nfev += 6;
                 nred = S.fused_blocks();
