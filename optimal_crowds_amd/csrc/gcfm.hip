@@ -4,19 +4,21 @@
 //
 // Layout: caller-owned SoA state in agent order (float64 x,y,vx,vy,v_des; uint8 status; int32 key).
 // The library keeps a packed snapshot in SLOT order (agents sorted along a Hilbert curve over 2 m coarse cells; a
-// tile = 64 slots = one wavefront), double-buffered because a step reads the old one while it writes the new one:
+// tile = 64 slots = one wavefront):
 //   ppos  double2 (x,y)      pvel  float4 (vx,vy,|v|,1/a^2)     phead float2 (unit heading, (1,0) if v=0)
 //   tile_box double4 (minx,miny,maxx,maxy) of a tile's active agents;  nb_list: tiles that can come within the
 //   cutoff before the next re-sort (boxes at sort time, cutoff + 2D margin; validity is re-checked every step)
 //   pvd double2 (float64 velocity), pdk (v_des, key): slot-ordered copies, so a step gathers nothing by agent index
-// One step = ONE launch, k_step: a block carries 4/NS tiles and NS wavefronts per tile.
-//   pair     the NS wavefronts of a tile share its candidate j-tiles by j-range (equal work): phase 1 builds per-lane
-//            candidate masks with a conservative float32 test, the candidates are compacted into an LDS list (two
-//            per entry), phase 2 walks the list: exact float64 cutoff decision (the reference's
-//            sqrt(dx^2+dy^2) < cutoff), packed float32 force, float64 sums in LDS shared by the tile's wavefronts;
-//   finish   after a block barrier the tile's first wavefront does, per agent in float64: exact nearest-wall-cell
-//            search (one lane per agent), floor-field lookup, wall force, noisy relaxation step, speed clamp, exit
-//            test; then it writes the NEXT snapshot (other buffer), the tile box and the step counters.
+// One step = 2 launches:
+//   k_forces  blocks of 4 wavefronts.  PAIR blocks carry 4/NS tiles, NS wavefronts per tile sharing the tile's i
+//             records and float64 force sums in LDS; a wavefront takes its j-range of the candidate j-tiles (equal work
+//             per share), NS tiles at a time as one 64-record virtual j-tile: phase 1 builds per-lane candidate masks
+//             with a conservative float32 test, the candidates are compacted into an LDS list (two per entry), phase 2
+//             walks the list: exact float64 cutoff decision (the reference's sqrt(dx^2+dy^2) < cutoff), packed float32
+//             force.  PREP blocks do what does not need the pair sums, one lane per agent: exact nearest-wall-cell
+//             search + wall force, floor-field lookup -- chains of dependent loads that hide beside the pair work.
+//   k_finish  per agent, float64, one level of slot-ordered loads: noisy relaxation step, speed clamp, exit test; then
+//             the next step's packed record and tile box.
 #include "oc_internal.h"
 #include <cmath>
 #include <algorithm>
@@ -65,7 +67,7 @@ struct WEntry {
     int32_t prune_ok;       // column-gap bounds valid (agent within one cell of column jx)
 };
 
-struct Snap {               // one buffer of the packed snapshot
+struct Snap {               // the packed snapshot
     double2* ppos;
     float4* pvel;
     float2* phead;
@@ -81,7 +83,7 @@ struct PDK {                // per slot, fixed between re-sorts
 struct Scratch {
     uint32_t *keys_a, *keys_b;
     int32_t *vals_a, *vals_b;
-    Snap snap[2];
+    Snap snap;
     double2* pvd;           // float64 velocity per slot (only the tile's own finisher touches it: single buffer)
     PDK* pdk;
     double4* tile_box0;
@@ -328,8 +330,8 @@ __global__ void __launch_bounds__(64) k_pack(const double* __restrict__ x, const
                                              const double* __restrict__ vx, const double* __restrict__ vy,
                                              const double* __restrict__ v_des, const uint8_t* __restrict__ status,
                                              const int32_t* __restrict__ key_of, const int32_t* __restrict__ order,
-                                             int N, GcfmParams P, Scratch S, int cur) {
-    const Snap& C = S.snap[cur];
+                                             int N, GcfmParams P, Scratch S) {
+    const Snap& C = S.snap;
     int k = blockIdx.x * 64 + threadIdx.x;
     int i = (k < N) ? order[k] : -1;
     bool act = (i >= 0) && status[i];
@@ -905,8 +907,8 @@ __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEnt
 
 // standalone wall search (diagnostic exports): one lane per slot
 __global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, const Axis X0,
-                                             const Axis Y0, int cur) {
-    const Snap& C = S.snap[cur];
+                                             const Axis Y0) {
+    const Snap& C = S.snap;
     const int k = blockIdx.x * 64 + threadIdx.x;
     WEntry we = {};
     bool go = false;
@@ -918,9 +920,9 @@ __global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyD
 }
 
 // standalone pair forces (diagnostic exports): 4 tiles per block, one wavefront each
-__global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S, int cur) {
+__global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S) {
     __shared__ PairLds<1> L;
-    const Snap& C = S.snap[cur];
+    const Snap& C = S.snap;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, it = blockIdx.x * 4 + w;
     const bool live = it < S.ntiles;
     if (live) pair_load_tile<1>(P, C, S.pdk, L, it, w, lane);
@@ -1071,10 +1073,10 @@ __device__ __forceinline__ void prep_tile(const GcfmParams& P, const Scratch& S,
 // CU resident.
 template <int NS>
 __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, int step,
-                                                const Axis X0, const Axis Y0, int cur, int nprep,
+                                                const Axis X0, const Axis Y0, int nprep,
                                                 int32_t* __restrict__ cnt_out) {
     __shared__ PairLds<NS> L;
-    const Snap& C = S.snap[cur];
+    const Snap& C = S.snap;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if ((int)blockIdx.x < nprep) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {     // this step's counters (k_finish updates them later in the stream)
@@ -1104,9 +1106,9 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
 // simulations.py:303-332 for the 64 agents of a tile, float64, then the next step's packed snapshot in place.
 // Everything is read by slot and was prepared by k_forces: one level of loads.
 __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const double* __restrict__ rect_tab, int nkeys,
-                                               StepArgs A, int cur) {
+                                               StepArgs A) {
     __shared__ double l_rect[RECT_KEYS_LDS * RECT_TAB];
-    const Snap& C = S.snap[cur];
+    const Snap& C = S.snap;
     const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
     const bool tab_lds = nkeys <= RECT_KEYS_LDS;
     if (tab_lds)
@@ -1199,9 +1201,9 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
 }
 
 // ---------------------------------------------------------------------------------- diagnostics (single-shot exports)
-__global__ void k_lookup_diag(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, int cur, int step,
+__global__ void k_lookup_diag(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, int step,
                               int32_t* err) {
-    const Snap& C = S.snap[cur];
+    const Snap& C = S.snap;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= S.Np) return;
     int i = C.pidx[k];
@@ -1214,8 +1216,8 @@ __global__ void k_lookup_diag(GcfmParams P, Scratch S, const KeyDev* __restrict_
     S.des[k] = d;
 }
 
-__global__ void k_wall_force_diag(GcfmParams P, Scratch S, int cur, const Axis X0, const Axis Y0) {
-    const Snap& C = S.snap[cur];
+__global__ void k_wall_force_diag(GcfmParams P, Scratch S, const Axis X0, const Axis Y0) {
+    const Snap& C = S.snap;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= S.Np) return;
     int i = C.pidx[k];
@@ -1310,9 +1312,9 @@ int carve(oc_handle* h, int N, Scratch* S) {
     if (Np == 0) Np = 64;
     const int nt = Np / 64;
     const size_t per_snap = sizeof(double2) + sizeof(float4) + sizeof(float2) + sizeof(int32_t);
-    const size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + 2 * per_snap + sizeof(double2) + sizeof(PDK) +
+    const size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + per_snap + sizeof(double2) + sizeof(PDK) +
                        3 * sizeof(double2) + sizeof(long long);
-    size_t need = per * (size_t)Np + (3 * sizeof(double4) + (NB_MAX + 3) * sizeof(int32_t)) * (size_t)nt + 64 + 16384;
+    size_t need = per * (size_t)Np + (2 * sizeof(double4) + (NB_MAX + 3) * sizeof(int32_t)) * (size_t)nt + 64 + 16384;
     if (need > h->gcfm_bytes) {
         if (h->gcfm_buf) OC_HIP_CHECK(hipFree(h->gcfm_buf));
         h->gcfm_buf = nullptr;
@@ -1327,13 +1329,11 @@ int carve(oc_handle* h, int N, Scratch* S) {
         p += (bytes + 255) & ~(size_t)255;
         return (void*)q;
     };
-    for (int b = 0; b < 2; ++b) {
-        S->snap[b].ppos = (double2*)take(sizeof(double2) * Np);
-        S->snap[b].pvel = (float4*)take(sizeof(float4) * Np);
-        S->snap[b].phead = (float2*)take(sizeof(float2) * Np);
-        S->snap[b].pidx = (int32_t*)take(sizeof(int32_t) * Np);
-        S->snap[b].tile_box = (double4*)take(sizeof(double4) * nt);
-    }
+    S->snap.ppos = (double2*)take(sizeof(double2) * Np);
+    S->snap.pvel = (float4*)take(sizeof(float4) * Np);
+    S->snap.phead = (float2*)take(sizeof(float2) * Np);
+    S->snap.pidx = (int32_t*)take(sizeof(int32_t) * Np);
+    S->snap.tile_box = (double4*)take(sizeof(double4) * nt);
     S->pvd = (double2*)take(sizeof(double2) * Np);
     S->pdk = (PDK*)take(sizeof(PDK) * Np);
     S->f_pair = (double2*)take(sizeof(double2) * Np);
@@ -1404,7 +1404,7 @@ bool wallmaps_ready(const oc_handle* h) {
     return true;
 }
 
-// re-sort + full pack of the current state into snapshot buffer h->snap_parity + neighbour lists
+// re-sort + full pack of the current state + neighbour lists + dispatch order
 int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hipStream_t s) {
     const int N = a->N;
     OC_HIP_CHECK(hipMemsetAsync(S->ctrl, 0, 64, s));
@@ -1415,7 +1415,7 @@ int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hi
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_pack, dim3(S->ntiles), dim3(64), 0, s, a->x, a->y, a->vx, a->vy, a->v_des, a->status, a->key,
-                       S->vals_b, N, P, *S, h->snap_parity);
+                       S->vals_b, N, P, *S);
     const bool have_work = h->work_valid && h->work_tiles == S->ntiles;
     if (!have_work) OC_HIP_CHECK(hipMemsetAsync(S->tile_work, 0, sizeof(int32_t) * S->ntiles, s));
     hipLaunchKernelGGL(k_tile_lists, dim3(S->ntiles), dim3(64), 0, s, P, *S, have_work ? 1 : 0);
@@ -1494,12 +1494,11 @@ extern "C" int oc_field_lookup(oc_handle* h, const oc_agents* a, int32_t simu_st
     GcfmParams P;
     if ((rc = prepare(h, a, &S, &P, s))) return rc;
     h->packed_valid = false;
-    const int cur = h->snap_parity;
     OC_HIP_CHECK(hipMemsetAsync(des, 0, sizeof(double) * 2 * (size_t)a->N, s));
     if (err_flag) OC_HIP_CHECK(hipMemsetAsync(err_flag, 0, sizeof(int32_t) * 2, s));
     hipLaunchKernelGGL(k_lookup_diag, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, (const KeyDev*)h->key_tables_dev,
-                       cur, simu_step, err_flag);
-    hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.des, S.snap[cur].pidx, S.Np,
+                       simu_step, err_flag);
+    hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.des, S.snap.pidx, S.Np,
                        (double2*)des);
     OC_HIP_CHECK(hipGetLastError());
     return OC_OK;
@@ -1515,18 +1514,17 @@ extern "C" int oc_wall_force(oc_handle* h, const oc_agents* a, int64_t* index_ou
     GcfmParams P;
     if ((rc = prepare(h, a, &S, &P, s))) return rc;
     h->packed_valid = false;
-    const int cur = h->snap_parity;
     hipLaunchKernelGGL(k_wall, dim3(S.ntiles), dim3(64), 0, s, P, S, (const KeyDev*)h->key_tables_dev, axis_x(h),
-                       axis_y(h), cur);
-    hipLaunchKernelGGL(k_wall_force_diag, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, cur, axis_x(h), axis_y(h));
+                       axis_y(h));
+    hipLaunchKernelGGL(k_wall_force_diag, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, axis_x(h), axis_y(h));
     if (index_out) {
         OC_HIP_CHECK(hipMemsetAsync(index_out, 0xFF, sizeof(int64_t) * (size_t)a->N, s));
-        hipLaunchKernelGGL(k_scatter<long long>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.widx, S.snap[cur].pidx,
+        hipLaunchKernelGGL(k_scatter<long long>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.widx, S.snap.pidx,
                            S.Np, (long long*)index_out);
     }
     if (force_out) {
         OC_HIP_CHECK(hipMemsetAsync(force_out, 0, sizeof(double) * 2 * (size_t)a->N, s));
-        hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_wall, S.snap[cur].pidx,
+        hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_wall, S.snap.pidx,
                            S.Np, (double2*)force_out);
     }
     OC_HIP_CHECK(hipGetLastError());
@@ -1543,10 +1541,9 @@ extern "C" int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out
     GcfmParams P;
     if ((rc = prepare(h, a, &S, &P, s))) return rc;
     h->packed_valid = false;
-    const int cur = h->snap_parity;
-    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S, cur);
+    hipLaunchKernelGGL(k_pair, dim3((S.ntiles + 3) / 4), dim3(256), 0, s, P, S);
     OC_HIP_CHECK(hipMemsetAsync(force_out, 0, sizeof(double) * 2 * (size_t)a->N, s));
-    hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_pair, S.snap[cur].pidx, S.Np,
+    hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.f_pair, S.snap.pidx, S.Np,
                        (double2*)force_out);
     OC_HIP_CHECK(hipGetLastError());
     return OC_OK;
@@ -1576,19 +1573,18 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     A.step = simu_step;
     A.cnt_out = counters ? counters : S.ctrl;
     const KeyDev* kd = (const KeyDev*)h->key_tables_dev;
-    const int cur = h->snap_parity;
     const int ns = h->pair_split, tpb = 4 / ns;
     const int npair = (S.ntiles + tpb - 1) / tpb, nprep = std::min(std::max(S.ntiles / 4, 1), h->prep_blocks);
     auto kf = ns == 4 ? k_forces<4> : (ns == 2 ? k_forces<2> : k_forces<1>);
     oc_timer_begin(h, "gcfm_forces", s);
-    hipLaunchKernelGGL(kf, dim3(nprep + npair), dim3(256), 0, s, P, S, kd, simu_step, axis_x(h), axis_y(h), cur, nprep,
+    hipLaunchKernelGGL(kf, dim3(nprep + npair), dim3(256), 0, s, P, S, kd, simu_step, axis_x(h), axis_y(h), nprep,
                        A.cnt_out);
     oc_timer_end(h, "gcfm_forces", s);
     h->work_valid = true;
     h->work_tiles = S.ntiles;
     oc_timer_begin(h, "gcfm_finish", s);
     hipLaunchKernelGGL(k_finish, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
-                       (int)h->fields.size(), A, cur);
+                       (int)h->fields.size(), A);
     oc_timer_end(h, "gcfm_finish", s);
     OC_HIP_CHECK(hipGetLastError());
     h->packed_valid = true;

@@ -91,7 +91,6 @@ struct oc_handle {
     int prep_blocks = 256;      // blocks of k_forces that do the wall search / field lookup of the tiles
     bool work_valid = false;    // tile_work holds a step's measured pair work (for the dispatch order)
     int work_tiles = -1;
-    int snap_parity = 0;        // which buffer of the packed snapshot is current
     void* gcfm_buf = nullptr;   // carved in gcfm.hip
     size_t gcfm_bytes = 0;
     void* sort_tmp = nullptr;
