@@ -26,11 +26,12 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-WORKLOADS = {   # name -> (room, grid_step, T)
-    "metro_station": ("metro_station", 0.1, 20.0),
-    "slalom": ("slalom", 0.1, 20.0),
-    "exit_opposite": ("exit_opposite", 0.1, 20.0),
-    "room_test": ("room_test", 0.05, 20.0),
+WORKLOADS = {   # name -> (room, grid_step, T, recompute)
+    "metro_station": ("metro_station", 0.1, 20.0, False),
+    "slalom": ("slalom", 0.1, 20.0, False),
+    "exit_opposite": ("exit_opposite", 0.1, 20.0, False),
+    "room_test": ("room_test", 0.05, 20.0, False),
+    "open_room": ("open_room", 0.1, 20.0, True),      # configs[4] on ONE GPU: 4096^2, 500k agents, recompute=True
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -39,12 +40,12 @@ def build_sim(workload, seed=20240807, wall_search_radius=-1.0):
     import io
     import contextlib
     from optimal_crowds_amd import host, simulations
-    room, gs, T = WORKLOADS[workload]
+    room, gs, T, recompute = WORKLOADS[workload]
     cfg = copy.deepcopy(host.load_config(os.path.join(REPO, "optimal_crowds_amd", "config.json")))
     cfg["grid_step"] = gs
     np.random.seed(seed)
     with contextlib.redirect_stdout(io.StringIO()):
-        sim = simulations.simulation(room, T, config=cfg, noise="device", seed=seed, record=False, history=False,
+        sim = simulations.simulation(room, T, recompute, config=cfg, noise="device", seed=seed, record=False, history=False,
                                      wall_search_radius=wall_search_radius)
     return sim, cfg
 
@@ -62,11 +63,19 @@ def run_steps(sim, K, nt, timed_stats=None):
     eng = sim._engine
     done = 0
     while done < K:
-        if done % nt == 0:
+        s = done % nt
+        if s == 0:
             st = solve_round(sim)
             if timed_stats is not None:
                 timed_stats.append(st)
-        eng.step(done % nt, noise=None, seed=sim._seed + done // nt, sync=False)
+        elif sim.recompute and s % sim.recompute_step == 0:
+            # run() with recompute=True (simulations.py:432-435): density of the current crowd, then every key again
+            # on the shrunken horizon nt = round((T - t) / dt)  (quirk Q9)
+            m = sim._density_dev(sim.sigma_convolution)
+            st = [eng.solve(k, sim.T, round((sim.T - s * sim.dt) / sim.dt), m=m)[0] for k in range(len(sim._key_names))]
+            if timed_stats is not None:
+                timed_stats.append(st)
+        eng.step(s, noise=None, seed=sim._seed + done // nt, sync=False)
         done += 1
 
 
@@ -235,8 +244,9 @@ def main():
         "value": world * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s %dx%d grid, %d agents, %d keys, T=%g (nt=%d), recompute=False"
-                               % (args.workload, sim.Nx, sim.Ny, sim.N, len(sim._key_names), sim.T, nt),
+        "config": {"workload": "%s %dx%d grid, %d agents, %d keys, T=%g (nt=%d)"
+                               % (args.workload, sim.Nx, sim.Ny, sim.N, len(sim._key_names), sim.T, nt)
+                   + (", recompute=True" if sim.recompute else ""),
                    "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
                    "noise": "device Philox", "agent_state": "f64", "pair_math": "f32", "hjb_state": "f32"},
         "roofline": roof,
