@@ -26,9 +26,10 @@ def short(name):
               "k_rhs", "k_lincomb", "k_scale", "k_fill", "k_make_coef", "k_norm_scaled", "k_density"):
         if k + "<" in name or k + "(" in name:
             return k
-    if "k_stage" in name:
-        a = name.index("k_stage<")
-        return name[a:name.index(">", a) + 1].replace("float, ", "").replace(" ", "")
+    for k in ("k_stage3<", "k_stage<"):
+        if k in name:
+            a = name.index(k)
+            return name[a:name.index(">", a) + 1].replace("float, ", "").replace(" ", "")
     return name[:48]
 
 
