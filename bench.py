@@ -11,8 +11,9 @@ ceil(K/nt) solve rounds.  Inputs (potentials, agent state) are resident in HBM w
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload metro_station|slalom|exit_opposite|room_test]
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs an independent replica of the
-workload ("replicas only"): value = N * K / max-over-ranks time, scaling = weak.
+For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its own member of an ensemble of the
+workload (own initial placement and noise seed; "replicas only"): value = N * K /
+max-over-ranks time, scaling = weak.
 """
 import argparse
 import copy
@@ -188,7 +189,8 @@ def main():
 
     import optimal_crowds_amd.engine  # noqa: F401  (fails loudly without the HIP library)
     t_init = time.perf_counter()
-    sim, cfg = build_sim(args.workload, wall_search_radius=args.wall_radius)
+    # N > 1: an ensemble -- every rank simulates its own member (own placement and noise seed) of the same workload
+    sim, cfg = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius)
     t_init = time.perf_counter() - t_init
     eng = sim._engine
     for kv in filter(None, args.tune.split(",")):
@@ -247,7 +249,7 @@ def main():
         "config": {"workload": "%s %dx%d grid, %d agents, %d keys, T=%g (nt=%d)"
                                % (args.workload, sim.Nx, sim.Ny, sim.N, len(sim._key_names), sim.T, nt)
                    + (", recompute=True" if sim.recompute else ""),
-                   "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
+                   "parallelism": "ensemble of %d replicas, one per GPU" % world if world > 1 else "single GPU",
                    "noise": "device Philox", "agent_state": "f64", "pair_math": "f32", "hjb_state": "f32"},
         "roofline": roof,
         "breakdown": {"hjb_solve_s_total": t_hjb, "hjb_solves": sum(len(r) for r in stats),
