@@ -126,6 +126,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OcError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(there is no CPU fallback)" % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime (libamdhip64.so in torch/lib).  Load it first so that liboc_hip.so binds
+    # to the SAME runtime instance as the tensors it is handed: with /opt/rocm's copy loaded first the process ends up
+    # with two runtimes and the second one reports "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
