@@ -141,6 +141,34 @@ def cpu_baseline(sim, cfg, n_attempt, budget_s=20.0):
             "t_hjb_solve_s": t_hjb, "t_step_s": t_step}
 
 
+def gcfm_work(sim, cfg, t_forces_s, t_step_s):
+    """SURVEY 8d's algorithmic work of one GCFM step on the state the run ended with (untimed): ordered pairs
+    P = N_a (N_a - 1), of which P_near lie within the cutoff (counted here with torch on the GPU, float64), nominal
+    8 flop per far pair and 60 per near pair; 88 B of state traffic per active agent.  The far pairs are never
+    visited (tile boxes and neighbour lists cull them), so the all-pairs figure is an equivalent rate, not executed
+    flops; the near-pair figure is what the pair kernel really evaluates."""
+    import torch
+    a = sim._engine.agents
+    act = a["status"].bool()
+    x, y = a["x"][act], a["y"][act]
+    na = int(x.numel())
+    c2 = float(cfg["repulsion_cutoff"]) ** 2
+    near = 0
+    for i0 in range(0, na, 2048):
+        dx = x[i0:i0 + 2048, None] - x[None, :]
+        dy = y[i0:i0 + 2048, None] - y[None, :]
+        near += int(((dx * dx + dy * dy).sqrt() < float(cfg["repulsion_cutoff"])).sum().item())
+    near -= na                                              # the agent itself
+    P = na * (na - 1)
+    f_all = 8.0 * (P - near) + 60.0 * near
+    return {"active_agents": na, "ordered_pairs": P, "near_pairs": near,
+            "flop_all_pairs_equivalent": f_all, "flop_near_pairs": 60.0 * near,
+            "all_pairs_equivalent_TFLOPs": f_all / t_forces_s / 1e12,
+            "near_pair_TFLOPs": 60.0 * near / t_forces_s / 1e12,
+            "near_pair_frac_of_fp32_vector_peak": 60.0 * near / t_forces_s / 157.3e12,
+            "state_bytes_frac_of_hbm_peak": 88.0 * na / t_step_s / (HBM_PEAK_GBS * 1e9)}
+
+
 def pmc_traffic(workload):
     """HBM bytes per k_out launch from the committed PMC summary (profiles/rNN_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command, gfx950 FETCH_SIZE x2 correction applied by
@@ -256,6 +284,10 @@ def main():
                       "gcfm_ms_per_step": 1e3 * (elapsed - t_hjb) / K, "nfev": nfev, "rk_attempts": n_att,
                       "rk_accepted": n_acc, "kernels": kstats, "init_s": t_init, "active_agents_end": int(eng.counters.cpu()[2])},
     }
+    kf = kstats.get("gcfm_forces", {})
+    if rank == 0 and kf.get("avg_ms"):
+        result["breakdown"]["gcfm_work"] = gcfm_work(sim, cfg, kf["avg_ms"] * 1e-3,
+                                                     result["breakdown"]["gcfm_ms_per_step"] * 1e-3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(sim, cfg, n_att)
         result["cpu_baseline"]["host_cpus"] = os.cpu_count()
