@@ -155,7 +155,7 @@ extern "C" int oc_reset_kernel_stats(oc_handle* h) {
 }
 
 extern "C" int oc_set_hjb_variant(oc_handle* h, int variant) {
-    OC_REQUIRE(h && (variant == 0 || variant == 1), "bad argument");
+    OC_REQUIRE(h && variant >= 0 && variant <= 2, "bad argument");
     h->hjb_variant = variant;
     return OC_OK;
 }

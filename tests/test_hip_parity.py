@@ -288,6 +288,37 @@ def test_fused_and_simple_hjb_kernels_agree(golden):
     assert np.allclose(out[0][2], out[1][2], atol=1e-8) and np.allclose(out[0][3], out[1][3], atol=1e-8)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_three_stage_and_one_stage_launches_agree(dtype):
+    """k_stage3 (three RK stages per launch, default) applies the arithmetic of k_stage (one stage per launch) cell by
+    cell; only the partial sums of the error norm are grouped differently, which may move a step size in its last
+    bits.  On an obstacle room (walls, hole, cylinders, border targets) at a grid the tiles do not divide evenly:
+    same step counts, phi and direction field equal to round-off."""
+    import torch
+    out = []
+    for variant in (0, 2):
+        eng, room, cfg, X0, Y0 = _engine("gold_b", dtype, n_keys=1)
+        X, Y = np.meshgrid(X0, Y0)
+        key = " or ".join(list(room["initial_boxes"].values())[0][5:])
+        V = oc.finalize_potential(oc.create_potential(room, key.split(" or "), X, Y), cfg)
+        eng.set_hjb_variant(variant)
+        T, nt = 3.0, 150
+        eng.set_potential(0, V, _rects(room, key))
+        eng.alloc_field(0, nt - 1)
+        rng = np.random.RandomState(3)
+        m = torch.as_tensor(np.abs(rng.normal(size=V.shape)) * 2.0)
+        st, phi = eng.solve(0, T, nt, m=m, keep=[0, 60, 149])
+        vx, vy = eng.field_interior(0)
+        out.append((st, phi.cpu().numpy(), vx.double().cpu().numpy(), vy.double().cpu().numpy()))
+        eng.close()
+    a, b = out
+    assert a[0]["n_accept"] == b[0]["n_accept"] and a[0]["n_attempt"] == b[0]["n_attempt"] and a[0]["nfev"] == b[0]["nfev"]
+    rtol = 1e-6 if dtype == "float32" else 1e-13
+    assert np.allclose(a[1], b[1], rtol=rtol, atol=0)
+    assert np.abs(a[2] - b[2]).max() <= 1e-5 and np.abs(a[3] - b[3]).max() <= 1e-5
+    assert (np.hypot(a[2], a[3]) > 0.5).mean() == pytest.approx((np.hypot(b[2], b[3]) > 0.5).mean(), abs=1e-4)
+
+
 def test_wall_auto_radius_drops_only_negligible_forces(golden):
     """wall_search_radius < 0: agents search only as far as their wall force can exceed 1e-12 m/s."""
     g = golden("G6_forces.npz")
