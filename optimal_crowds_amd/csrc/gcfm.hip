@@ -1083,6 +1083,9 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
             cnt_out[C_EXIT] = cnt_out[3] = 0;
             cnt_out[C_ACTIVE] = S.ctrl[C_NACTIVE];
         }
+        // prep wavefronts mostly wait on memory; when they can issue they go first, so that their chains end (and their
+        // blocks' slots are free for pair blocks) as early as possible
+        __builtin_amdgcn_s_setprio(3);
         for (int t = blockIdx.x * 4 + w; t < S.ntiles; t += nprep * 4)
             prep_tile(P, S, C, keys, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8]);
         return;
