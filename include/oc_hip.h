@@ -133,6 +133,12 @@ int oc_hjb_vels(oc_handle* h, int dtype, const void* phi, double scale, void* vx
 /* Register the direction field of key `key`: arrays as written by oc_hjb_solve; nt_opt = current horizon
  * (optimals.nt_opt), nslice_alloc = allocated slices (nt0-1).  Replaces attribute access optimals.vx_opt. */
 int oc_set_field(oc_handle* h, int key, int dtype, const void* vx, const void* vy, int32_t nslice_alloc, int32_t nt_opt);
+/* The same for a ROW BLOCK of the field, as written by oc_hjb_solve_rows: arrays (nslice_alloc, rows, Nx) whose local
+ * row 0 is grid row `row0`; this rank answers lookups whose first cell lies in grid rows [own_lo, own_hi) (the rows
+ * it owns; the block carries the margin the second cell may need) and returns zero for the others -- see
+ * oc_gcfm_step_sharded.  simulations.py:281 / optimals.py:212-250 on a domain-decomposed field. */
+int oc_set_field_rows(oc_handle* h, int key, int dtype, const void* vx, const void* vy, int32_t nslice_alloc,
+                      int32_t nt_opt, int32_t row0, int32_t rows, int32_t own_lo, int32_t own_hi);
 /* Exit rectangles (cx,cy,w,h) of a key's possible targets: pedestrians.py:132-136. rects: HOST (n,4) float64. */
 int oc_set_key_targets(oc_handle* h, int key, const double* rects, int32_t n);
 /* Nearest-"wall"-cell structure of Vs[key] for pedestrians.py:311-315.  V: float32 device (Ny,Nx);
@@ -167,6 +173,19 @@ int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out, void* str
  * Rebuilds the spatial order every `resort_every` steps (0 = library default). */
 int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise, uint64_t seed,
                  int32_t* counters, void* stream);
+/* The step on `world` GPUs with REPLICATED agents: every rank holds the whole agent state and calls this
+ * with the same arguments.  Rank r computes the pair forces and the wall forces of its contiguous share of the tiles
+ * (against all agents) and the desired velocities of the agents whose floor-field rows it holds (oc_set_field_rows;
+ * with oc_set_field every rank holds everything and rank 0 answers), writes them -- zeros elsewhere -- into `xchg`
+ * (float64, 6 * oc_padded_agents(N) values, caller-owned), calls `allreduce_sum(user, xchg, count)`, which must SUM
+ * the buffer over the ranks in place on `stream` (RCCL all-reduce; every element has one non-zero contribution, so the
+ * result does not depend on the reduction order), and then every rank finishes ALL agents from the reduced buffer:
+ * the replicated states stay bit-identical without another exchange.  counters[1] (IndexError band) is the local
+ * rank's view. */
+int64_t oc_padded_agents(int32_t N);
+int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise, uint64_t seed,
+                         int32_t* counters, int32_t rank, int32_t world, double* xchg,
+                         int (*allreduce_sum)(void* user, double* buf, int64_t count), void* user, void* stream);
 int oc_set_resort_every(oc_handle* h, int32_t steps);
 /* Between consecutive oc_gcfm_step calls the library reuses the packed snapshot it wrote itself; call this after
  * modifying the state arrays in place from outside (new array pointers are detected automatically). */

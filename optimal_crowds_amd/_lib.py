@@ -43,6 +43,7 @@ class OcHjbStats(C.Structure):
 
 
 HALO_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)     # int (*)(void* user)
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)     # int (*)(void* user, double* buf, int64 n)
 
 
 class OcHjbShard(C.Structure):
@@ -81,6 +82,8 @@ SIGNATURES = {
                                     C.POINTER(OcHjbStats), C.c_void_p]),
     "oc_hjb_vels": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "oc_set_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "oc_set_field_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "oc_set_key_targets": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]),
     "oc_wallmap_build": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
     "oc_field_lookup": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -88,6 +91,9 @@ SIGNATURES = {
     "oc_pair_force": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_void_p, C.c_void_p]),
     "oc_gcfm_step": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p,
                                C.c_void_p]),
+    "oc_padded_agents": (C.c_int64, [C.c_int32]),
+    "oc_gcfm_step_sharded": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p,
+                                       C.c_int32, C.c_int32, C.c_void_p, ALLREDUCE_CB, C.c_void_p, C.c_void_p]),
     "oc_set_resort_every": (C.c_int, [C.c_void_p, C.c_int32]),
     "oc_agents_changed": (C.c_int, [C.c_void_p]),
     "oc_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(OcAgents), C.c_double, C.c_void_p, C.c_double,

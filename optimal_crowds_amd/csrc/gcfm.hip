@@ -34,6 +34,7 @@ struct KeyDev {
     double off;
     double edt_cap;
     int32_t dtype, nslice_alloc, nt_opt, nrect;
+    int32_t row0, rows, own_lo, own_hi;     // row block of the field held here / grid rows whose lookups are answered here
     double rect[OC_MAX_TARGET_RECTS][4];
 };
 
@@ -967,12 +968,15 @@ __device__ __forceinline__ double py_floordiv(double vx, double wx) {
 template <typename T>
 __device__ __forceinline__ double2 field_fetch(const KeyDev& kd, int step, int i0, int i1, int j0, int j1, int Nx,
                                                int Ny) {
-    // slices are stored padded as (Ny, Nx); the reference's (Ny-2, Nx-2) array is the interior block
+    // slices are stored padded as (rows, Nx), rows = Ny or a row block starting at grid row kd.row0; the reference's
+    // (Ny-2, Nx-2) array is the interior block: interior index i is grid row i + 1
     const size_t W = (size_t)Nx;
-    const T* fx = (const T*)kd.vx + (size_t)step * W * Ny + W + 1;
-    const T* fy = (const T*)kd.vy + (size_t)step * W * Ny + W + 1;
-    double ax = (double)fx[(size_t)i0 * W + j0], bx = (double)fx[(size_t)i1 * W + j1];
-    double ay = (double)fy[(size_t)i0 * W + j0], by = (double)fy[(size_t)i1 * W + j1];
+    const int rows = kd.rows < 0 ? Ny : kd.rows;
+    const T* fx = (const T*)kd.vx + (size_t)step * W * rows + 1;
+    const T* fy = (const T*)kd.vy + (size_t)step * W * rows + 1;
+    const size_t r0 = (size_t)(i0 + 1 - kd.row0), r1 = (size_t)(i1 + 1 - kd.row0);
+    double ax = (double)fx[r0 * W + j0], bx = (double)fx[r1 * W + j1];
+    double ay = (double)fy[r0 * W + j0], by = (double)fy[r1 * W + j1];
     return make_double2((ax + bx) / 2, (ay + by) / 2);
 }
 
@@ -1009,6 +1013,10 @@ __device__ __forceinline__ double2 lookup(const GcfmParams& P, const KeyDev& kd,
     fix(i1, Ny - 2);
     if (bad && err) atomicMax(err, agent + 1);
     if (step >= kd.nslice_alloc) return make_double2(0.0, 0.0);
+    // domain-decomposed field: the rank that owns the first cell's grid row answers (its block carries the next row)
+    if (i0 + 1 < kd.own_lo || i0 + 1 >= kd.own_hi) return make_double2(0.0, 0.0);
+    if (kd.rows >= 0 && (i1 + 1 < kd.row0 || i1 + 1 >= kd.row0 + kd.rows)) i1 = i0;   // (a wrapped negative index of an
+                                                                                      // agent outside the room)
     double2 d = (kd.dtype == OC_F32) ? field_fetch<float>(kd, step, i0, i1, j0, j1, Nx, Ny)
                                      : field_fetch<double>(kd, step, i0, i1, j0, j1, Nx, Ny);
     return make_double2(vdes * d.x, vdes * d.y);
@@ -1047,7 +1055,7 @@ struct StepArgs {               // caller-owned state (agent order) and the step
 // of loads.
 __device__ __forceinline__ void prep_tile(const GcfmParams& P, const Scratch& S, const Snap& C,
                                           const KeyDev* __restrict__ keys, int step, const Axis X0, const Axis Y0,
-                                          int it, int lane, int32_t* err) {
+                                          int it, int lane, int32_t* err, bool do_wall, bool do_lookup) {
     const int k = it * 64 + lane;
     const int i = C.pidx[k];
     const bool act = i >= 0;
@@ -1055,16 +1063,28 @@ __device__ __forceinline__ void prep_tile(const GcfmParams& P, const Scratch& S,
     const double2 v = S.pvd[k];
     const PDK dk = S.pdk[k];
     const KeyDev& kd = keys[act ? dk.key : 0];
-    double2 ds = make_double2(0.0, 0.0);
-    if (act) ds = lookup(P, kd, p.x, p.y, dk.v_des, step, i, err);          // its loads fly during the search
-    WEntry we = {};
-    const bool need = act && wall_prepare(P, kd, X0, Y0, p.x, p.y, (double)C.pvel[k].z, we);
-    const long long widx = wall_search(P, we, need, X0, Y0);
-    double2 fw = make_double2(0.0, 0.0);
-    if (act) fw = wall_force_of(P, widx, p.x, p.y, v.x, v.y, dk.v_des, X0, Y0);
-    S.des[k] = ds;
-    S.f_wall[k] = fw;
+    // (sharded step: the tile's owner does the wall part; the lookup is answered by the owner of the field rows, or by
+    // the tile's owner when every rank holds the whole field; what a rank does not compute stays zero for the sum)
+    if (do_lookup) {
+        double2 ds = make_double2(0.0, 0.0);
+        if (act) ds = lookup(P, kd, p.x, p.y, dk.v_des, step, i, err);      // its loads fly during the search
+        S.des[k] = ds;
+    }
+    if (do_wall) {
+        WEntry we = {};
+        const bool need = act && wall_prepare(P, kd, X0, Y0, p.x, p.y, (double)C.pvel[k].z, we);
+        const long long widx = wall_search(P, we, need, X0, Y0);
+        double2 fw = make_double2(0.0, 0.0);
+        if (act) fw = wall_force_of(P, widx, p.x, p.y, v.x, v.y, dk.v_des, X0, Y0);
+        S.f_wall[k] = fw;
+    }
 }
+
+struct TileShare {              // which tiles this launch works on (the whole step: 0, ntiles, 1, 0)
+    int32_t lo, hi;             // pair forces and wall forces: tiles lo .. hi - 1
+    int32_t by_work;            // dispatch the pair blocks by decreasing work (tile_order) instead of by index
+    int32_t lookup_all;         // do the floor-field lookup of every tile (the field's row blocks decide who answers)
+};
 
 // The step's force kernel.  Blocks of 4 wavefronts.  The first `nprep` blocks sweep the tiles with prep_tile (they
 // are dispatched first; their wavefronts mostly wait on memory).  Every other block carries 4/NS tiles: barrier 1,
@@ -1073,7 +1093,7 @@ __device__ __forceinline__ void prep_tile(const GcfmParams& P, const Scratch& S,
 // CU resident.
 template <int NS>
 __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, int step,
-                                                const Axis X0, const Axis Y0, int nprep,
+                                                const Axis X0, const Axis Y0, int nprep, TileShare sh,
                                                 int32_t* __restrict__ cnt_out) {
     __shared__ PairLds<NS> L;
     const Snap& C = S.snap;
@@ -1086,13 +1106,17 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
         // prep wavefronts mostly wait on memory; when they can issue they go first, so that their chains end (and their
         // blocks' slots are free for pair blocks) as early as possible
         __builtin_amdgcn_s_setprio(3);
-        for (int t = blockIdx.x * 4 + w; t < S.ntiles; t += nprep * 4)
-            prep_tile(P, S, C, keys, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8]);
+        for (int t = blockIdx.x * 4 + w; t < S.ntiles; t += nprep * 4) {
+            const bool mine = t >= sh.lo && t < sh.hi;
+            if (mine || sh.lookup_all)
+                prep_tile(P, S, C, keys, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8], mine, mine || sh.lookup_all);
+        }
         return;
     }
     const int tl = w / NS, sub = w % NS, ord = ((int)blockIdx.x - nprep) * (4 / NS) + tl;
-    const bool live = ord < S.ntiles;
-    const int it = live ? S.tile_order[ord] : 0;    // heavy tiles first: the launch ends with its slowest wavefront
+    const bool live = ord < sh.hi - sh.lo;
+    // heavy tiles first: the launch ends with its slowest wavefront
+    const int it = live ? (sh.by_work ? S.tile_order[ord] : sh.lo + ord) : 0;
     if (live && sub == 0) {
         if (lane == 0) S.tile_work[it] = 0;
         pair_load_tile<NS>(P, C, S.pdk, L, it, tl, lane);
@@ -1369,6 +1393,10 @@ int upload_keys(oc_handle* h, hipStream_t s) {
         d.dtype = h->fields[k].dtype;
         d.nslice_alloc = h->fields[k].nslice_alloc;
         d.nt_opt = h->fields[k].vx ? h->fields[k].nt_opt : 0;
+        d.row0 = h->fields[k].row0;
+        d.rows = h->fields[k].rows;
+        d.own_lo = h->fields[k].own_lo;
+        d.own_hi = h->fields[k].own_hi;
         d.lr = (const int2*)h->wallmaps[k].left;
         d.edt = (const float*)h->wallmaps[k].right;
         d.gap8 = (const int32_t*)h->wallmaps[k].gap8;
@@ -1552,6 +1580,43 @@ extern "C" int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out
     return OC_OK;
 }
 
+// one step, or one rank's part of it: k_forces on the tiles of `share`, [the caller's sum over the ranks], k_finish
+static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmParams& P, int32_t simu_step,
+                       const double* noise, uint64_t seed, int32_t* counters, TileShare share,
+                       int (*allreduce_sum)(void*, double*, int64_t), void* user, double* xchg, hipStream_t s) {
+    StepArgs A;
+    A.x = a->x; A.y = a->y; A.vx = a->vx; A.vy = a->vy;
+    A.status = a->status;
+    A.agent_time = a->agent_time;
+    A.noise = noise;
+    A.seed = seed;
+    A.step = simu_step;
+    A.cnt_out = counters ? counters : S.ctrl;
+    const KeyDev* kd = (const KeyDev*)h->key_tables_dev;
+    const int ns = h->pair_split, tpb = 4 / ns, ntl = share.hi - share.lo;
+    const int npair = (ntl + tpb - 1) / tpb, nprep = std::min(std::max(S.ntiles / 4, 1), h->prep_blocks);
+    auto kf = ns == 4 ? k_forces<4> : (ns == 2 ? k_forces<2> : k_forces<1>);
+    oc_timer_begin(h, "gcfm_forces", s);
+    hipLaunchKernelGGL(kf, dim3(nprep + npair), dim3(256), 0, s, P, S, kd, simu_step, axis_x(h), axis_y(h), nprep, share,
+                       A.cnt_out);
+    oc_timer_end(h, "gcfm_forces", s);
+    h->work_valid = share.by_work != 0;     // (a rank's share measures only its own tiles)
+    h->work_tiles = S.ntiles;
+    if (allreduce_sum && allreduce_sum(user, xchg, 6 * (int64_t)S.Np) != 0) {
+        oc_set_error("oc_gcfm_step_sharded: the allreduce_sum callback failed");
+        return OC_ERR_STATE;
+    }
+    oc_timer_begin(h, "gcfm_finish", s);
+    hipLaunchKernelGGL(k_finish, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
+                       (int)h->fields.size(), A);
+    oc_timer_end(h, "gcfm_finish", s);
+    OC_HIP_CHECK(hipGetLastError());
+    h->packed_valid = true;
+    ++h->steps_since_sort;
+    ++h->prof_tick;
+    return OC_OK;
+}
+
 extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise, uint64_t seed,
                             int32_t* counters, void* stream) {
     int rc = check_agents(h, a);
@@ -1567,31 +1632,41 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     if (!h->packed_valid || h->packed_x != a->x || h->packed_N != a->N || h->steps_since_sort >= h->resort_every) {
         if ((rc = repack(h, a, &S, P, s))) return rc;
     }
-    StepArgs A;
-    A.x = a->x; A.y = a->y; A.vx = a->vx; A.vy = a->vy;
-    A.status = a->status;
-    A.agent_time = a->agent_time;
-    A.noise = noise;
-    A.seed = seed;
-    A.step = simu_step;
-    A.cnt_out = counters ? counters : S.ctrl;
-    const KeyDev* kd = (const KeyDev*)h->key_tables_dev;
-    const int ns = h->pair_split, tpb = 4 / ns;
-    const int npair = (S.ntiles + tpb - 1) / tpb, nprep = std::min(std::max(S.ntiles / 4, 1), h->prep_blocks);
-    auto kf = ns == 4 ? k_forces<4> : (ns == 2 ? k_forces<2> : k_forces<1>);
-    oc_timer_begin(h, "gcfm_forces", s);
-    hipLaunchKernelGGL(kf, dim3(nprep + npair), dim3(256), 0, s, P, S, kd, simu_step, axis_x(h), axis_y(h), nprep,
-                       A.cnt_out);
-    oc_timer_end(h, "gcfm_forces", s);
-    h->work_valid = true;
-    h->work_tiles = S.ntiles;
-    oc_timer_begin(h, "gcfm_finish", s);
-    hipLaunchKernelGGL(k_finish, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
-                       (int)h->fields.size(), A);
-    oc_timer_end(h, "gcfm_finish", s);
-    OC_HIP_CHECK(hipGetLastError());
-    h->packed_valid = true;
-    ++h->steps_since_sort;
-    ++h->prof_tick;
-    return OC_OK;
+    const TileShare all = {0, S.ntiles, 1, 0};
+    return launch_step(h, a, S, P, simu_step, noise, seed, counters, all, nullptr, nullptr, nullptr, s);
+}
+
+extern "C" int64_t oc_padded_agents(int32_t N) {
+    int64_t Np = ((int64_t)N + 63) / 64 * 64;
+    return Np == 0 ? 64 : Np;
+}
+
+extern "C" int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise,
+                                    uint64_t seed, int32_t* counters, int32_t rank, int32_t world, double* xchg,
+                                    int (*allreduce_sum)(void* user, double* buf, int64_t count), void* user,
+                                    void* stream) {
+    int rc = check_agents(h, a);
+    if (rc) return rc;
+    if ((rc = require_wallmaps(h))) return rc;
+    OC_REQUIRE(world >= 1 && rank >= 0 && rank < world && xchg && allreduce_sum, "bad shard arguments");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scratch S;
+    if ((rc = carve(h, a->N, &S))) return rc;
+    GcfmParams P = make_params(h);
+    if ((rc = upload_keys(h, s))) return rc;
+    // every rank re-sorts the same replicated state at the same steps: identical slot orders everywhere
+    if (!h->packed_valid || h->packed_x != a->x || h->packed_N != a->N || h->steps_since_sort >= h->resort_every) {
+        if ((rc = repack(h, a, &S, P, s))) return rc;
+    }
+    // pair sums, wall forces and desired velocities live in the caller's exchange buffer: zero, then each rank's part
+    S.f_pair = (double2*)xchg;
+    S.f_wall = S.f_pair + S.Np;
+    S.des = S.f_wall + S.Np;
+    OC_HIP_CHECK(hipMemsetAsync(xchg, 0, sizeof(double) * 6 * (size_t)S.Np, s));
+    bool rows = false;
+    for (const auto& f : h->fields) rows = rows || f.rows >= 0;
+    const TileShare mine = {(int32_t)((int64_t)S.ntiles * rank / world), (int32_t)((int64_t)S.ntiles * (rank + 1) / world), 0,
+                            rows ? 1 : 0};
+    return launch_step(h, a, S, P, simu_step, noise, seed, counters, mine, allreduce_sum, user, xchg, s);
 }

@@ -170,7 +170,25 @@ extern "C" int oc_set_field(oc_handle* h, int key, int dtype, const void* vx, co
     f.vy = vy;
     f.nslice_alloc = nslice_alloc;
     f.nt_opt = nt_opt;
+    f.row0 = 0;
+    f.rows = -1;
+    f.own_lo = 0;
+    f.own_hi = 1 << 30;
     h->key_tables_dirty = true;
+    return OC_OK;
+}
+
+extern "C" int oc_set_field_rows(oc_handle* h, int key, int dtype, const void* vx, const void* vy, int32_t nslice_alloc,
+                                 int32_t nt_opt, int32_t row0, int32_t rows, int32_t own_lo, int32_t own_hi) {
+    int rc = oc_set_field(h, key, dtype, vx, vy, nslice_alloc, nt_opt);
+    if (rc) return rc;
+    OC_REQUIRE(row0 >= 0 && rows > 0 && row0 + rows <= h->cfg.Ny, "row block outside the grid");
+    OC_REQUIRE(own_lo >= row0 && own_hi <= row0 + rows && own_lo < own_hi, "owned rows outside the row block");
+    oc_field_desc& f = h->fields[key];
+    f.row0 = row0;
+    f.rows = rows;
+    f.own_lo = own_lo;
+    f.own_hi = own_hi;
     return OC_OK;
 }
 

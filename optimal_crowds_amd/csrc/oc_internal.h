@@ -35,6 +35,8 @@ struct oc_field_desc {
     const void* vy = nullptr;
     int32_t nslice_alloc = 0;
     int32_t nt_opt = 0;
+    int32_t row0 = 0, rows = -1;            // row block held locally (rows < 0: the whole grid)
+    int32_t own_lo = 0, own_hi = 1 << 30;   // grid rows whose lookups this rank answers
 };
 
 struct oc_wallmap {

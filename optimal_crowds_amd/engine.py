@@ -204,6 +204,17 @@ class Engine:
         check(rc)
         return stats.as_dict(), (vx, vy), phi_keep
 
+    def set_field_rows(self, key, vx, vy, nt, shard):
+        """Register a ROW BLOCK of key's direction field (as returned by solve_rows on `shard`, a parallel.RowShard):
+        this rank answers the lookups whose first cell lies in the rows it owns (oc_set_field_rows)."""
+        if shard.world > 1 and shard.field_margin < 1:
+            raise ValueError("a lookup's second cell may lie one row beyond the owned rows: the row block needs "
+                             "halo >= 7 (the field is exact halo - 6 rows beyond the block)")
+        nslice = int(vx.shape[0])
+        self.fields[key] = [vx, vy, nslice, int(nt)]
+        check(self.lib.oc_set_field_rows(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt), int(shard.row0),
+                                         int(shard.Ny_local), int(shard.g0), int(shard.g1)))
+
     def set_field_horizon(self, key, nt):
         vx, vy, nslice, _ = self.fields[key]
         self.fields[key][3] = nt
@@ -274,6 +285,28 @@ class Engine:
             noise = torch.as_tensor(np.ascontiguousarray(noise, dtype=np.float64)).to(self.device)
         check(self.lib.oc_gcfm_step(self.h, C.byref(self._astruct), int(simu_step), _ptr(noise),
                                     C.c_uint64(int(seed)), _ptr(self.counters), self.stream()))
+        if sync:
+            c = self.counters.cpu().numpy()
+            return int(c[0]), int(c[1]), int(c[2])
+        return None
+
+    def step_sharded(self, simu_step, comm, noise=None, seed=0, sync=True):
+        """One synchronous GCFM step on comm.world ranks with replicated agents (oc_gcfm_step_sharded): this rank does
+        the pair / wall forces of its share of the tiles and the lookups its field rows cover, `comm` (parallel
+        .DistStepComm or ThreadStepComm) sums the exchange buffer over the ranks, every rank finishes all agents."""
+        if noise is not None and not torch.is_tensor(noise):
+            noise = torch.as_tensor(np.ascontiguousarray(noise, dtype=np.float64)).to(self.device)
+        n = 6 * int(self.lib.oc_padded_agents(int(self.agents["N"])))
+        if getattr(self, "_xchg", None) is None or self._xchg.numel() != n:
+            self._xchg = torch.zeros(n, dtype=torch.float64, device=self.device)
+        comm.bind(self._xchg)
+        rc = self.lib.oc_gcfm_step_sharded(self.h, C.byref(self._astruct), int(simu_step), _ptr(noise),
+                                           C.c_uint64(int(seed)), _ptr(self.counters), int(comm.rank), int(comm.world),
+                                           _ptr(self._xchg), comm.callback, None, self.stream())
+        if comm.error is not None:
+            err, comm.error = comm.error, None
+            raise err
+        check(rc)
         if sync:
             c = self.counters.cpu().numpy()
             return int(c[0]), int(c[1]), int(c[2])

@@ -1,0 +1,232 @@
+"""The GCFM step on several ranks with replicated agents (oc_gcfm_step_sharded): every rank does the pair /
+wall forces of its share of the tiles and the floor-field lookups its rows cover, ONE sum over the ranks, every rank
+finishes all agents.  Virtual ranks = threads of one process on cuda:0, one engine (library handle) each; the collective
+is parallel.ThreadStepComm (parallel.DistStepComm is the same callback over torch.distributed / RCCL).
+
+Against the single-GPU step: every force is computed by exactly one rank with the single-GPU arithmetic and the sum
+adds zeros, so the states agree to the order in which a tile's wavefronts add their float64 partial sums (1e-12)."""
+import copy
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oc_oracle as oc                     # noqa: E402  (checker only)
+from optimal_crowds_amd import room_library            # noqa: E402
+from tests.test_hip_parity import _engine, _rects      # noqa: E402
+from tests.test_hip_step_shapes import _big            # noqa: E402
+
+T, NT = 1.0, 50
+
+
+def _potentials(room, cfg, X0, Y0):
+    X, Y = np.meshgrid(X0, Y0)
+    names = []
+    for box in room["initial_boxes"].values():
+        k = " or ".join(box[5:])
+        if k not in names:
+            names.append(k)
+    return names, [oc.finalize_potential(oc.create_potential(room, n.split(" or "), X, Y), cfg) for n in names]
+
+
+def _state(room, nkeys, n=6000, seed=5):
+    rng = np.random.RandomState(seed)
+    L, H = room["room_length"], room["room_height"]
+    x, y = rng.uniform(0.8, L - 0.8, n), rng.uniform(0.8, H - 0.8, n)
+    vx, vy = rng.normal(0, 0.6, n), rng.normal(0, 0.6, n)
+    vdes = rng.normal(1.34, 0.2, n).clip(0.6, 2.0)
+    key = rng.randint(0, nkeys, n).astype(np.int32)
+    status = rng.rand(n) > 0.03
+    return x, y, vx, vy, vdes, key, status
+
+
+def _new(room_name):
+    eng, room, cfg, X0, Y0 = _engine(room_name, "float32", n_keys=2, max_agents=8192, cfg=_big(), wall_search_radius=0.0)
+    names, Vs = _potentials(room, cfg, X0, Y0)
+    for k, name in enumerate(names):
+        eng.set_potential(k, Vs[k], _rects(room, name))
+    return eng, room, cfg, names
+
+
+def _run_ranks(world, body):
+    from optimal_crowds_amd import parallel
+    tw = parallel.ThreadWorld(world)
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            out[rank] = body(rank, tw)
+        except BaseException as e:      # noqa: BLE001
+            errs.append((rank, e))
+            tw.barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    if errs:
+        raise errs[0][1]
+    return out
+
+
+def _reference(room_name, state, noise, steps):
+    eng, room, cfg, names = _new(room_name)
+    for k in range(len(names)):
+        eng.alloc_field(k, NT - 1)
+        eng.solve(k, T, NT)
+    x, y, vx, vy, vdes, key, status = state
+    eng.set_agents(x, y, vx, vy, vdes, key, status=status)
+    eng.set_resort_every(2)
+    outs = [eng.step(s, noise=noise[s]) for s in range(steps)]
+    st = eng.get_state()
+    eng.close()
+    return st, outs
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_step_with_replicated_fields(world):
+    from optimal_crowds_amd import parallel
+    room = room_library.ROOMS["exit_opposite"]()
+    state = _state(room, 2)
+    n = len(state[0])
+    steps = 4
+    noise = np.random.RandomState(1).normal(size=(steps, n, 2))
+    ref, ref_out = _reference("exit_opposite", state, noise, steps)
+
+    def body(rank, tw):
+        eng, room_, cfg, names = _new("exit_opposite")
+        for k in range(len(names)):
+            eng.alloc_field(k, NT - 1)
+            eng.solve(k, T, NT)                      # every rank holds the whole field: the tile's owner looks up
+        x, y, vx, vy, vdes, key, status = state
+        eng.set_agents(x, y, vx, vy, vdes, key, status=status)
+        eng.set_resort_every(2)
+        comm = parallel.ThreadStepComm(rank, tw)
+        tw.barrier.wait(timeout=120)
+        outs = [eng.step_sharded(s, comm, noise=noise[s]) for s in range(steps)]
+        st = eng.get_state()
+        eng.close()
+        return st, outs, comm.n_allreduce
+
+    res = _run_ranks(world, body)
+    for st, outs, nred in res:
+        assert nred == steps
+        assert [(o[0], o[2]) for o in outs] == [(o[0], o[2]) for o in ref_out]        # exits, active agents
+        assert np.array_equal(st["status"], ref["status"])
+        for f in ("x", "y", "vx", "vy"):
+            assert np.array_equal(st[f], res[0][0][f])                               # replicas stay bit-identical
+            assert np.abs(st[f] - ref[f]).max() <= 1e-11, f
+
+
+def test_sharded_step_with_row_block_fields():
+    """The direction field domain-decomposed by rows (oc_hjb_solve_rows -> oc_set_field_rows): a lookup is answered by
+    the rank that owns the first cell's row.  Against the single-GPU run: the two solves differ by float32 round-off in
+    the step controller's error sums (test_hjb_rows), so the desired velocities agree to 1e-4 on all but a few cells at
+    the unit-or-zero threshold."""
+    import torch
+    from optimal_crowds_amd import parallel
+    world, halo = 2, 8
+    room = room_library.ROOMS["exit_opposite"]()
+    state = _state(room, 2)
+    n = len(state[0])
+    steps = 3
+    noise = np.random.RandomState(2).normal(size=(steps, n, 2))
+    ref, ref_out = _reference("exit_opposite", state, noise, steps)
+
+    def body(rank, tw):
+        eng, room_, cfg, names = _new("exit_opposite")
+        sh = parallel.RowShard(eng.Ny, rank, world, halo)
+        hcomm = parallel.ThreadHaloComm(sh, eng.Nx, eng.tdtype, eng.device, tw)
+        tw.barrier.wait(timeout=120)
+        for k in range(len(names)):
+            _, (vx_, vy_), _ = eng.solve_rows(k, T, NT, hcomm)
+            eng.set_field_rows(k, vx_, vy_, NT, sh)
+        x, y, vx, vy, vdes, key, status = state
+        eng.set_agents(x, y, vx, vy, vdes, key, status=status)
+        eng.set_resort_every(2)
+        tw.comms = [None] * world                       # the step's collective replaces the solve's in the registry
+        tw.barrier.wait(timeout=120)
+        comm = parallel.ThreadStepComm(rank, tw)
+        tw.barrier.wait(timeout=120)
+        outs = [eng.step_sharded(s, comm, noise=noise[s]) for s in range(steps)]
+        st = eng.get_state()
+        eng.close()
+        return st, outs
+
+    res = _run_ranks(world, body)
+    for st, outs in res:
+        assert np.array_equal(st["status"], ref["status"])
+        for f in ("x", "y", "vx", "vy"):
+            assert np.array_equal(st[f], res[0][0][f])
+        d = np.hypot(st["x"] - ref["x"], st["y"] - ref["y"])
+        assert np.median(d) <= 1e-7 and (d > 1e-4).mean() <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ two processes, gloo
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dist_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from optimal_crowds_amd import parallel
+    try:
+        parallel.init_distributed("gloo")
+        room = room_library.ROOMS["exit_opposite"]()
+        state = _state(room, 2, n=3000, seed=8)
+        n = len(state[0])
+        steps = 3
+        noise = np.random.RandomState(3).normal(size=(steps, n, 2))
+        eng, room_, cfg, names = _new("exit_opposite")
+        sh = parallel.RowShard(eng.Ny, rank, world, halo=8)
+        hcomm = parallel.DistHaloComm(sh, eng.Nx, eng.tdtype, eng.device)
+        for k in range(len(names)):
+            _, (vx_, vy_), _ = eng.solve_rows(k, T, NT, hcomm)
+            eng.set_field_rows(k, vx_, vy_, NT, sh)
+        x, y, vx, vy, vdes, key, status = state
+        eng.set_agents(x, y, vx, vy, vdes, key, status=status)
+        comm = parallel.DistStepComm()
+        outs = [eng.step_sharded(s, comm, noise=noise[s]) for s in range(steps)]
+        res = dict(rank=rank, st=eng.get_state(), outs=outs, nred=comm.n_allreduce)
+        if rank == 0:
+            ref, ref_out = _reference("exit_opposite", state, noise, steps)
+            res.update(ref=ref, ref_out=ref_out)
+        q.put(res)
+        dist.barrier()
+        eng.close()
+        dist.destroy_process_group()
+    except BaseException as e:      # noqa: BLE001
+        q.put(dict(rank=rank, error=repr(e)))
+        raise
+
+
+def test_sharded_step_two_processes_gloo():
+    """World-size-2 torch.distributed run (gloo, both ranks on cuda:0): row-block solve, row-block fields, sharded
+    steps -- the code path of a multi-GPU node with the backend swapped (nccl = RCCL moves device tensors directly)."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=300) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    for r in res:
+        assert "error" not in r, r
+    res.sort(key=lambda r: r["rank"])
+    ref = res[0]["ref"]
+    for r in res:
+        assert r["nred"] == 3
+        assert np.array_equal(r["st"]["status"], ref["status"])
+        for f in ("x", "y", "vx", "vy"):
+            assert np.array_equal(r["st"][f], res[0]["st"][f])                       # replicas bit-identical
+        d = np.hypot(r["st"]["x"] - ref["x"], r["st"]["y"] - ref["y"])
+        assert np.median(d) <= 1e-7 and (d > 1e-4).mean() <= 2e-3
