@@ -37,7 +37,7 @@ WORKLOADS = {   # name -> (room, grid_step, T, recompute)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def build_sim(workload, seed=20240807, wall_search_radius=-1.0):
+def build_sim(workload, seed=20240807, wall_search_radius=-1.0, sharding=None):
     import io
     import contextlib
     from optimal_crowds_amd import host, simulations
@@ -47,7 +47,7 @@ def build_sim(workload, seed=20240807, wall_search_radius=-1.0):
     np.random.seed(seed)
     with contextlib.redirect_stdout(io.StringIO()):
         sim = simulations.simulation(room, T, recompute, config=cfg, noise="device", seed=seed, record=False, history=False,
-                                     wall_search_radius=wall_search_radius)
+                                     wall_search_radius=wall_search_radius, sharding=sharding)
     return sim, cfg
 
 
@@ -197,6 +197,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wall-radius", type=float, default=-1.0,
                     help="diagnostic: wall search radius in m (default -1: per-agent radius from the 1e-12 m/s force bound)")
+    ap.add_argument("--mode", default="ensemble", choices=["ensemble", "sharded"],
+                    help="N > 1: ensemble = one independent simulation per GPU (default, weak scaling); sharded = ONE "
+                         "simulation on N GPUs: HJB grid in row blocks, agents replicated, one all-reduce per step "
+                         "(strong scaling; DESIGN.md section 7)")
     ap.add_argument("--tune", default="", help="launch-shape knobs, e.g. pair_split=4 (oc_set_tuning)")
     args = ap.parse_args()
 
@@ -217,8 +221,11 @@ def main():
 
     import optimal_crowds_amd.engine  # noqa: F401  (fails loudly without the HIP library)
     t_init = time.perf_counter()
-    # N > 1: an ensemble -- every rank simulates its own member (own placement and noise seed) of the same workload
-    sim, cfg = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius)
+    sharded = world > 1 and args.mode == "sharded"
+    if sharded:     # one simulation on all ranks: same seed everywhere (replicated agents), row blocks of the HJB grid
+        sim, cfg = build_sim(args.workload, wall_search_radius=args.wall_radius, sharding=parallel.dist_sharding())
+    else:           # N > 1: an ensemble -- every rank simulates its own member (own placement and noise seed)
+        sim, cfg = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius)
     t_init = time.perf_counter() - t_init
     eng = sim._engine
     for kv in filter(None, args.tune.split(",")):
@@ -271,13 +278,15 @@ def main():
                 "algorithmic_GB_per_launch": ko["algorithmic_GB_per_launch"]}
     result = {
         "metric": "sim steps/sec (HJB sweep + GCFM update), 2048^2 grid x 100k agents",
-        "value": world * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": (1 if sharded else world) * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong" if sharded else "weak",
+        "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %dx%d grid, %d agents, %d keys, T=%g (nt=%d)"
                                % (args.workload, sim.Nx, sim.Ny, sim.N, len(sim._key_names), sim.T, nt)
                    + (", recompute=True" if sim.recompute else ""),
-                   "parallelism": "ensemble of %d replicas, one per GPU" % world if world > 1 else "single GPU",
+                   "parallelism": ("one simulation on %d GPUs: HJB row blocks + replicated agents" % world if sharded else
+                                   "ensemble of %d replicas, one per GPU" % world) if world > 1 else "single GPU",
                    "noise": "device Philox", "agent_state": "f64", "pair_math": "f32", "hjb_state": "f32"},
         "roofline": roof,
         "breakdown": {"hjb_solve_s_total": t_hjb, "hjb_solves": sum(len(r) for r in stats),

@@ -115,10 +115,26 @@ class Engine:
         r = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
         check(self.lib.oc_set_key_targets(self.h, key, r.ctypes.data_as(C.c_void_p), len(r)))
 
+    # ------------------------------------------------------------------ several GPUs
+    def enable_sharding(self, halo_comm, step_comm):
+        """From now on this engine is one rank of a multi-GPU simulation with REPLICATED agents: `solve` solves this
+        rank's row block of the HJB grid (oc_hjb_solve_rows through halo_comm, a parallel.DistHaloComm /
+        ThreadHaloComm on a RowShard) and keeps only that block of the direction field, `step` does this rank's share
+        of the forces and lookups and sums them over the ranks (oc_gcfm_step_sharded through step_comm).  Every rank
+        must make the same calls with the same arguments; the agent states stay bit-identical across the ranks."""
+        if halo_comm.shard.world > 1 and halo_comm.shard.field_margin < 1:
+            raise ValueError("sharded lookups need halo >= 7")
+        self._halo_comm, self._step_comm = halo_comm, step_comm
+
+    @property
+    def sharded(self):
+        return getattr(self, "_halo_comm", None) is not None
+
     def alloc_field(self, key, nslice):
         # slices are stored padded as (Ny, Nx) so that every row is 16-byte aligned for the vector kernels;
         # the reference's (Ny-2, Nx-2) array is the interior block [1:-1, 1:-1] (see field_interior)
-        shape = (max(nslice, 0), self.Ny, self.Nx)
+        rows = self._halo_comm.shard.Ny_local if self.sharded else self.Ny       # sharded: this rank's row block
+        shape = (max(nslice, 0), rows, self.Nx)
         vx = torch.zeros(shape, dtype=self.tdtype, device=self.device)
         vy = torch.zeros(shape, dtype=self.tdtype, device=self.device)
         self.fields[key] = [vx, vy, nslice, 0]
@@ -154,6 +170,15 @@ class Engine:
         vx, vy, nslice, _ = self.fields[key]
         if nt - 1 > nslice:
             raise ValueError("horizon exceeds allocated field slices")
+        if self.sharded:
+            if want_steps:
+                raise ValueError("want_steps is not available on a sharded engine")
+            st, _, phi_keep = self.solve_rows(key, T, nt, self._halo_comm, m=m, keep=keep, field=(vx, vy))
+            self.fields[key][3] = nt
+            sh = self._halo_comm.shard
+            check(self.lib.oc_set_field_rows(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt),
+                                             int(sh.row0), int(sh.Ny_local), int(sh.g0), int(sh.g1)))
+            return st, phi_keep
         self.make_coef(key, m)
         stats = OcHjbStats()
         keep_arr = phi_keep = None
@@ -218,6 +243,11 @@ class Engine:
     def set_field_horizon(self, key, nt):
         vx, vy, nslice, _ = self.fields[key]
         self.fields[key][3] = nt
+        if self.sharded:
+            sh = self._halo_comm.shard
+            check(self.lib.oc_set_field_rows(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt),
+                                             int(sh.row0), int(sh.Ny_local), int(sh.g0), int(sh.g1)))
+            return
         check(self.lib.oc_set_field(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt)))
 
     # ------------------------------------------------------------------ agents
@@ -281,6 +311,8 @@ class Engine:
 
     def step(self, simu_step, noise=None, seed=0, sync=True):
         """One synchronous GCFM step in place.  noise: (N,2) float64 tensor/array or None (device Philox)."""
+        if self.sharded:
+            return self.step_sharded(simu_step, self._step_comm, noise=noise, seed=seed, sync=sync)
         if noise is not None and not torch.is_tensor(noise):
             noise = torch.as_tensor(np.ascontiguousarray(noise, dtype=np.float64)).to(self.device)
         check(self.lib.oc_gcfm_step(self.h, C.byref(self._astruct), int(simu_step), _ptr(noise),

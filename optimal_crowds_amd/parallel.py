@@ -305,3 +305,21 @@ class ThreadStepComm(_StepComm):
         self.tw.sync()
         self.buf.copy_(self.tw.comms[0]._total)
         self.tw.sync()                                  # rank 0 keeps _total until everybody has copied it
+
+
+# ---------------------------------------------------------------------------------------------- one call for a façade
+def dist_sharding(halo=8, group=None):
+    """`sharding=` argument of simulations.simulation for a torch.distributed job (one process per GPU): row blocks of
+    the HJB grid with `halo` rows (>= 7), collectives over the group's backend (nccl = RCCL over xGMI, or gloo)."""
+    def make(eng):
+        sh = RowShard(eng.Ny, dist.get_rank(group), dist.get_world_size(group), halo)
+        return (DistHaloComm(sh, eng.Nx, eng.tdtype, eng.device, group=group), DistStepComm(group))
+    return make
+
+
+def thread_sharding(rank, tw_solve, tw_step, halo=8):
+    """The same for virtual ranks in threads of one process (tests): two ThreadWorld registries, one per collective."""
+    def make(eng):
+        sh = RowShard(eng.Ny, rank, tw_solve.world, halo)
+        return (ThreadHaloComm(sh, eng.Nx, eng.tdtype, eng.device, tw_solve), ThreadStepComm(rank, tw_step))
+    return make

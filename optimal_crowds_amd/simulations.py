@@ -53,7 +53,10 @@ class _History(dict):
 
 class simulation:
     def __init__(self, room, T, recompute=False, *, config=None, device="cuda:0", dtype="float32",
-                 noise=None, seed=20240807, history=None, record=None, wall_search_radius=None):
+                 noise=None, seed=20240807, history=None, record=None, wall_search_radius=None, sharding=None):
+        """sharding: None (one GPU) or a callable engine -> (halo_comm, step_comm), e.g. parallel.dist_sharding():
+        this process is then one rank of a multi-GPU simulation with replicated agents (Engine.enable_sharding);
+        every rank constructs the same simulation (same room, config, seed) and makes the same calls."""
         self.recompute = recompute
         var_config = host.load_config(config)
         var_room = host.load_room(room)
@@ -121,6 +124,8 @@ class simulation:
                               len(key_names), self.N, device=device, dtype=dtype,
                               wall_search_radius=wall_search_radius)
         eng = self._engine
+        if sharding is not None:
+            eng.enable_sharding(*sharding(eng))
         self.targets = {}
         for k, key in enumerate(key_names):
             rects = np.array([var_room["targets"][t] for t in self._possible[key]], dtype=np.float64)

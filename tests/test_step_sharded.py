@@ -230,3 +230,61 @@ def test_sharded_step_two_processes_gloo():
             assert np.array_equal(r["st"][f], res[0]["st"][f])                       # replicas bit-identical
         d = np.hypot(r["st"]["x"] - ref["x"], r["st"]["y"] - ref["y"])
         assert np.median(d) <= 1e-7 and (d > 1e-4).mean() <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ the façade, sharded
+def test_simulation_run_sharded_matches_single_gpu():
+    """simulations.simulation(..., sharding=...).run() on 2 virtual ranks with recompute=True (density, re-solves on
+    the shrinking horizon, sharded steps) against the same run on one engine: same exits, positions to 1e-6 m on all
+    but a few agents (the row-block and the single solve differ by float32 round-off in the step controller)."""
+    import contextlib
+    import io
+    from optimal_crowds_amd import host, parallel, simulations
+    cfg = copy.deepcopy(host.load_config())
+    cfg["grid_step"] = 0.1
+    Tsim = 3.0
+
+    def make(sharding):
+        np.random.seed(7)
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim = simulations.simulation("room_test", Tsim, True, config=cfg, noise="device", seed=11, record=False,
+                                         history=False, wall_search_radius=0.0, sharding=sharding)
+            sim.run()
+        st = sim._engine.get_state()
+        out = (st, sim.inside, sim.simu_step, [sim.targets[k].nt_opt for k in sim.targets])
+        sim._engine.close()
+        return out
+
+    ref = make(None)
+    world = 2
+    tw_solve, tw_step = parallel.ThreadWorld(world), parallel.ThreadWorld(world)
+    # np.random is process-global: the ranks construct one after the other (same seed -> same placement), then run
+    lock = threading.Lock()
+    sims = [None] * world
+
+    def body(rank, tw):
+        with lock:
+            np.random.seed(7)
+            with contextlib.redirect_stdout(io.StringIO()):
+                sims[rank] = simulations.simulation("room_test", Tsim, True, config=cfg, noise="device", seed=11,
+                                                    record=False, history=False, wall_search_radius=0.0,
+                                                    sharding=parallel.thread_sharding(rank, tw_solve, tw_step))
+        tw.barrier.wait(timeout=120)
+        sim = sims[rank]
+        buf = io.StringIO()
+        # (redirect_stdout is process-wide; one rank's redirection covers both, harmless)
+        with contextlib.redirect_stdout(buf):
+            sim.run()
+        st = sim._engine.get_state()
+        out = (st, sim.inside, sim.simu_step, [sim.targets[k].nt_opt for k in sim.targets])
+        sim._engine.close()
+        return out
+
+    res = _run_ranks(world, body)
+    for st, inside, nstep, nts in res:
+        assert (inside, nstep, nts) == (ref[1], ref[2], ref[3])
+        assert np.array_equal(st["status"], ref[0]["status"])
+        for f in ("x", "y", "vx", "vy"):
+            assert np.array_equal(st[f], res[0][0][f])
+        d = np.hypot(st["x"] - ref[0]["x"], st["y"] - ref[0]["y"])
+        assert np.median(d) <= 1e-6 and (d > 1e-3).mean() <= 0.1
