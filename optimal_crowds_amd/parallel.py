@@ -1,10 +1,14 @@
 """Multi-GPU plumbing for the path (one process per GPU, torch.distributed; backend "nccl" = RCCL on ROCm).
 
-The bench's default for N > 1 is independent replicas.  What shards is the HJB grid, by row
-blocks: `RowShard` is the geometry of one rank's block, `DistHaloComm` carries the two collectives of
-`oc_hjb_solve_rows` (include/oc_hip.h) over torch.distributed -- RCCL point-to-point on device tensors, or gloo with
-host staging for tests -- and `ThreadHaloComm` runs several virtual ranks inside one process on one GPU (tests).
-The numerics stay in the HIP library; this module only moves tensors.
+The bench's default for N > 1 is an ensemble of independent simulations.  This module carries the
+other mode, ONE simulation on N GPUs as SURVEY 8e lays it out:
+* the HJB grid in row blocks: `RowShard` is the geometry of one rank's block, `DistHaloComm` carries the two
+  collectives of `oc_hjb_solve_rows` (include/oc_hip.h) -- halo rows to the neighbours, all-gather of the error norm;
+* replicated agents: `DistStepComm` carries the one sum-all-reduce per step of `oc_gcfm_step_sharded`;
+* `dist_sharding()` is the `sharding=` argument that switches a whole `simulations.simulation` to this mode;
+* `ThreadHaloComm` / `ThreadStepComm` / `thread_sharding` run several virtual ranks inside one process on one GPU (tests).
+Over nccl the collectives move device tensors (RCCL over xGMI) on the launch stream; over gloo they are staged through
+host memory.  The numerics stay in the HIP library; this module only moves tensors.
 """
 import ctypes as C
 import os
