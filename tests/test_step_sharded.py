@@ -84,7 +84,7 @@ def _reference(room_name, state, noise, steps):
     return st, outs
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3])
 def test_sharded_step_with_replicated_fields(world):
     from optimal_crowds_amd import parallel
     room = room_library.ROOMS["exit_opposite"]()
