@@ -432,19 +432,19 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
 
 // ---- three RK stages per launch ---------------------------------------------------------------------------------
 // One RK attempt is 6 right-hand sides, each needing the previous ones on a 1-cell halo.  k_stage3 evaluates THREE of
-// them on a 64 x 32 tile in one launch: the inputs (y, the earlier K's, coef) are read once on the tile + a 3-cell
-// halo (70 x 38 cells), every intermediate stays in registers, and only the stage's working value y + h sum a_sj K_j
+// them on a 64 x 16 tile in one launch: the inputs (y, the earlier K's, coef) are read once on the tile + a 3-cell
+// halo (70 x 22 cells), every intermediate stays in registers, and only the stage's working value y + h sum a_sj K_j
 // goes through LDS for the stencil, on a region that shrinks by one ring per stage.  Two launches per attempt:
 //   A  reads y, K0, coef                 writes K1, K2, K3               6 array passes
 //   B  reads y, K0..K3, coef             writes K4, K5, y_new, K6        10 array passes (+ the error norm)
-// against 39 passes for one launch per stage; the halo re-reads (1.3x) are served by L2.  The arithmetic per cell is
+// against 39 passes for one launch per stage; the halo re-reads (1.5x) are served by L2.  The arithmetic per cell is
 // the sequence of k_stage, so the results are bit-identical.  Cells are dealt to threads round-robin over the region
 // (cell = thread + F3_NT m), all loops unrolled.
 #ifndef F3_X
 #define F3_X 64
 #endif
 #ifndef F3_Y
-#define F3_Y 32
+#define F3_Y 16
 #endif
 #define F3_H 3
 #define F3_RW (F3_X + 2 * F3_H)
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
 #define F3_LS (F3_RW + 2)
 #define F3_NCELL (F3_RW * F3_RH)
 #ifndef F3_NT
-#define F3_NT 1024              // threads per tile: 3 cells each -> ~64 registers, full occupancy (the launch is latency-
+#define F3_NT 512               // threads per tile: 3-4 cells each -> ~64 registers, full occupancy (the launch is latency-
 #endif                          // bound per block: load burst, three short stencil rounds, store burst)
 #define F3_NC ((F3_NCELL + F3_NT - 1) / F3_NT)
 
