@@ -221,9 +221,12 @@ def main():
 
     import optimal_crowds_amd.engine  # noqa: F401  (fails loudly without the HIP library)
     t_init = time.perf_counter()
-    sharded = world > 1 and args.mode == "sharded"
+    sharded = args.mode == "sharded"
     if sharded:     # one simulation on all ranks: same seed everywhere (replicated agents), row blocks of the HJB grid
-        sim, cfg = build_sim(args.workload, wall_search_radius=args.wall_radius, sharding=parallel.dist_sharding())
+        # (N = 1: the same code path with a one-rank "world", to see what the sharded path itself costs)
+        shd = parallel.dist_sharding() if world > 1 else parallel.thread_sharding(0, parallel.ThreadWorld(1),
+                                                                                  parallel.ThreadWorld(1))
+        sim, cfg = build_sim(args.workload, wall_search_radius=args.wall_radius, sharding=shd)
     else:           # N > 1: an ensemble -- every rank simulates its own member (own placement and noise seed)
         sim, cfg = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius)
     t_init = time.perf_counter() - t_init
