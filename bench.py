@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="metro_station", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-work-count", action="store_true",
+                    help="skip breakdown.gcfm_work (its torch kernels clutter a rocprofv3 kernel-stats run)")
     ap.add_argument("--wall-radius", type=float, default=-1.0,
                     help="diagnostic: wall search radius in m (default -1: per-agent radius from the 1e-12 m/s force bound)")
     ap.add_argument("--mode", default="ensemble", choices=["ensemble", "sharded"],
@@ -297,7 +299,7 @@ def main():
                       "rk_accepted": n_acc, "kernels": kstats, "init_s": t_init, "active_agents_end": int(eng.counters.cpu()[2])},
     }
     kf = kstats.get("gcfm_forces", {})
-    if rank == 0 and kf.get("avg_ms"):
+    if rank == 0 and kf.get("avg_ms") and not args.no_work_count:
         result["breakdown"]["gcfm_work"] = gcfm_work(sim, cfg, kf["avg_ms"] * 1e-3,
                                                      result["breakdown"]["gcfm_ms_per_step"] * 1e-3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
