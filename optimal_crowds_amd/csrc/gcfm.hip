@@ -943,8 +943,10 @@ __global__ void __launch_bounds__(256) k_edt(const int2* __restrict__ lr, int Nx
     long long flat;
     double d2;
     wall_scan(X0[j], Y0[i], lr, Nx, Ny, hx, hy, X0, Y0, 0.0, cap * cap, INFINITY, flat, d2);
-    double d = (flat >= 0) ? sqrt(d2) : cap;
-    edt[(size_t)i * Nx + j] = (float)fmin(d, cap);
+    // nodes farther than the cap from every site store +inf: a float-rounded cap must never pass for a distance (it
+    // would become an upper bound on the nearest-site distance in wall_needed and prune the real site)
+    double d = (flat >= 0) ? sqrt(d2) : INFINITY;
+    edt[(size_t)i * Nx + j] = (d < cap) ? (float)d : INFINITY;
 }
 
 // ---------------------------------------------------------------------------------- lookup

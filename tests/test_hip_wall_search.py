@@ -1,0 +1,74 @@
+"""The nearest-wall-cell search (gcfm.hip: wall_search -- blocks of 8 rows pruned by a column-gap table, two passes per
+visited block, ties by flat index) against the reference's definition, np.argmin(sqrt((X-x)^2+(Y-y)^2) + V*10e3) over
+the FULL grid (pedestrians.py:311-315), on wall layouts made to stress the pruning: thin and thick walls, isolated
+cells, sites only far away, no site at all, agents on nodes, on cell edges (ties), outside the room, and both wall
+classes of a finalised potential (-100 walls beat 0 / +1 cells by the 10e3 weight)."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oc_oracle as oc                     # noqa: E402  (checker only)
+
+
+def _grid(L, H, gs):
+    Nx, Ny = oc.grid_dims(L, H, gs)
+    X0, Y0 = oc.axes(L, H, Nx, Ny)
+    return Nx, Ny, X0, Y0
+
+
+def _layouts(Ny, Nx, rng):
+    out = {}
+    V = np.zeros((Ny, Nx)); V[:, :3] = -100; V[:, -3:] = -100; V[:2] = -100; V[-2:] = -100
+    out["border"] = V
+    V = np.zeros((Ny, Nx)); V[Ny // 3, Nx // 4: 3 * Nx // 4] = -100; V[Ny // 3: 2 * Ny // 3, Nx // 2] = -100
+    out["thin_cross"] = V
+    V = np.zeros((Ny, Nx))
+    for _ in range(12):
+        V[rng.randint(Ny), rng.randint(Nx)] = -100
+    out["isolated_cells"] = V
+    V = np.zeros((Ny, Nx)); V[-1, -1] = -100
+    out["one_far_corner_cell"] = V
+    V = np.zeros((Ny, Nx))
+    yy, xx = np.mgrid[0:Ny, 0:Nx]
+    for _ in range(6):
+        cy, cx, r = rng.randint(Ny), rng.randint(Nx), rng.randint(2, 9)
+        V[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = -100
+    V[Ny // 2 - 1: Ny // 2 + 2, : Nx // 3] = -100
+    out["pillars_and_slab"] = V
+    V = np.zeros((Ny, Nx)); V[10:14, 20:60] = 1.0
+    out["no_wall_only_target"] = V              # minimum class is 0: every non-target cell is a "site"
+    out["all_zero"] = np.zeros((Ny, Nx))
+    V = rng.choice([-100.0, 0.0], size=(Ny, Nx), p=[0.02, 0.98])
+    out["random_2pct"] = V
+    return out
+
+
+@pytest.mark.parametrize("gs,L,H", [(0.1, 16.35, 11.15), (0.05, 6.0, 7.9)])
+def test_wall_search_is_the_full_grid_argmin(gs, L, H):
+    from optimal_crowds_amd.engine import Engine
+    cfg = copy.deepcopy(oc.DEFAULT_CONFIG)
+    cfg["grid_step"] = gs
+    Nx, Ny, X0, Y0 = _grid(L, H, gs)
+    X, Y = np.meshgrid(X0, Y0)
+    rng = np.random.RandomState(12)
+    n = 1500
+    # probes: uniform, on nodes, on cell edges / centres (ties), just outside the room
+    px = rng.uniform(-0.3, L + 0.3, n)
+    py = rng.uniform(-0.3, H + 0.3, n)
+    j, i = rng.randint(0, Nx, 300), rng.randint(0, Ny, 300)
+    px[:300], py[:300] = X0[j], Y0[i]
+    px[300:500] = 0.5 * (X0[j[:200]] + X0[np.minimum(j[:200] + 1, Nx - 1)])
+    py[500:700] = 0.5 * (Y0[i[:200]] + Y0[np.minimum(i[:200] + 1, Ny - 1)])
+    for name, V in _layouts(Ny, Nx, rng).items():
+        eng = Engine(cfg, L, H, Nx, Ny, X0, Y0, 1, 4096, dtype="float32", wall_search_radius=0.0)
+        eng.set_potential(0, V, np.zeros((0, 4)))
+        eng.set_agents(px, py, rng.normal(0, 0.5, n), rng.normal(0, 0.5, n), np.full(n, 1.3), np.zeros(n, dtype=np.int32))
+        idx, _ = eng.wall_force()
+        idx = idx.cpu().numpy()
+        eng.close()
+        for a in range(n):
+            want = int(np.argmin(np.sqrt((X - px[a]) ** 2 + (Y - py[a]) ** 2) + V * 10e3))
+            assert idx[a] == want, (name, a, px[a], py[a], idx[a], want)
