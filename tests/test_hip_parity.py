@@ -333,3 +333,38 @@ def test_wall_auto_radius_drops_only_negligible_forces(golden):
     found = idx.cpu().numpy() >= 0
     assert np.array_equal(idx.cpu().numpy()[found], g["windex"][0][found])
     eng.close()
+
+
+@pytest.mark.parametrize("Nx,Ny", [(8, 5), (12, 17), (68, 33), (132, 49), (64, 16), (72, 130)])
+def test_solve_kernels_agree_on_awkward_grids(Nx, Ny):
+    """Tiles of k_stage3 (64 x 16 + 3-cell halo) and k_out (64 x 16) against grids that are smaller than a tile, not a
+    multiple of it, or one tile exactly: the three kernel variants give the same solve (float64: phi to 1e-12)."""
+    import torch
+    from optimal_crowds_amd.engine import Engine
+    gs = 0.1
+    cfg = copy.deepcopy(oc.DEFAULT_CONFIG)
+    cfg["grid_step"] = gs
+    L, H = (Nx - 1) * gs + 0.04, (Ny - 1) * gs + 0.04
+    assert oc.grid_dims(L, H, gs) == (Nx, Ny)
+    X0, Y0 = oc.axes(L, H, Nx, Ny)
+    rng = np.random.RandomState(Nx * 1000 + Ny)
+    V = np.zeros((Ny, Nx))
+    V[0, :] = V[-1, :] = V[:, 0] = V[:, -1] = -100
+    V[rng.rand(Ny, Nx) < 0.05] = -100
+    V[Ny // 2, 0] = 1.0                                   # a target on the border
+    m = np.abs(rng.normal(size=(Ny, Nx)))
+    T, nt = 1.0, 50
+    out = []
+    for variant in (0, 1, 2):
+        eng = Engine(cfg, L, H, Nx, Ny, X0, Y0, 1, 16, dtype="float64")
+        eng.set_hjb_variant(variant)
+        eng.set_potential(0, V, np.zeros((0, 4)))
+        eng.alloc_field(0, nt - 1)
+        st, phi = eng.solve(0, T, nt, m=torch.as_tensor(m), keep=[0, 25, 49])
+        vx, vy = eng.field_interior(0)
+        out.append((st, phi.cpu().numpy(), vx.cpu().numpy(), vy.cpu().numpy()))
+        eng.close()
+    for o in out[1:]:
+        assert o[0]["n_accept"] == out[0][0]["n_accept"] and o[0]["nfev"] == out[0][0]["nfev"]
+        assert np.allclose(o[1], out[0][1], rtol=1e-12, atol=0)
+        assert np.abs(o[2] - out[0][2]).max() <= 1e-8 and np.abs(o[3] - out[0][3]).max() <= 1e-8
