@@ -167,7 +167,10 @@ __global__ void k_err_norm(const T* __restrict__ y, const T* __restrict__ ynew, 
     block_reduce_store(s, mx, partial);
 }
 
-__global__ void k_reduce_final(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+// `mailbox` (optional): pinned host memory mapped into the device.  The result is also stored there, followed by the
+// sequence number `seq`, so that the host can read it by polling three words instead of a copy + stream synchronise.
+__global__ void k_reduce_final(const double* __restrict__ partial, int nblocks, double* __restrict__ out,
+                               volatile double* mailbox = nullptr, double seq = 0.0) {
     double s = 0.0, m = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
         s += partial[2 * i];
@@ -183,8 +186,16 @@ __global__ void k_reduce_final(const double* __restrict__ partial, int nblocks, 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[0] = ls[0] + ls[1] + ls[2] + ls[3];
-        out[1] = fmax(fmax(lm[0], lm[1]), fmax(lm[2], lm[3]));
+        const double a = ls[0] + ls[1] + ls[2] + ls[3], b = fmax(fmax(lm[0], lm[1]), fmax(lm[2], lm[3]));
+        out[0] = a;
+        out[1] = b;
+        if (mailbox) {
+            mailbox[0] = a;
+            mailbox[1] = b;
+            __threadfence_system();         // the two values reach host memory before the sequence number does
+            mailbox[2] = seq;
+            __threadfence_system();
+        }
     }
 }
 
@@ -748,11 +759,32 @@ struct Solver {
             if (mx) *mx = m;
             return OC_OK;
         }
-        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, h->red_partial, nblocks, h->red_out);
-        OC_HIP_CHECK(hipMemcpyAsync(h->red_host, h->red_out, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-        OC_HIP_CHECK(hipStreamSynchronize(s));
-        *sum = h->red_host[0];
-        if (mx) *mx = h->red_host[1];
+        // the reduction kernel posts (sum, max, sequence number) into pinned host memory; the host polls the sequence
+        // number (a copy + stream synchronise costs ~10 us more per attempt: an extra command and the wake-up)
+        volatile double* mb = h->red_host + 2 * OC_MAX_WORLD;
+        const double seq = (double)(++h->red_seq);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, h->red_partial, nblocks, h->red_out,
+                           (volatile double*)h->red_mailbox_dev, seq);
+        bool got = false;
+        for (long spin = 0; spin < 20000000L; ++spin) {         // ~ a second at worst, then fall back to the stream
+            if (mb[2] == seq) {
+                got = true;
+                break;
+            }
+            if ((spin & 1023) == 1023 && hipStreamQuery(s) == hipSuccess) break;    // (the stream drained: read below)
+        }
+        if (!got) {
+            OC_HIP_CHECK(hipStreamSynchronize(s));
+            if (mb[2] != seq) {             // mapped memory not visible: read the device copy
+                OC_HIP_CHECK(hipMemcpy(h->red_host, h->red_out, 2 * sizeof(double), hipMemcpyDeviceToHost));
+                *sum = h->red_host[0];
+                if (mx) *mx = h->red_host[1];
+                return OC_OK;
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        *sum = mb[0];
+        if (mx) *mx = mb[1];
         return OC_OK;
     }
     // after an accepted step: the `halo` owned rows next to each neighbour of y_new and K6 travel to that

@@ -54,7 +54,9 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
     h->red_blocks = std::max(1024, ((cfg->Nx + 63) / 64) * ((cfg->Ny + 15) / 16));
     OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * 2 * h->red_blocks));
     OC_HIP_CHECK(hipMalloc(&h->red_out, sizeof(double) * 16));
-    OC_HIP_CHECK(hipHostMalloc(&h->red_host, sizeof(double) * 2 * OC_MAX_WORLD));
+    OC_HIP_CHECK(hipHostMalloc(&h->red_host, sizeof(double) * (2 * OC_MAX_WORLD + 8), hipHostMallocMapped));
+    memset(h->red_host, 0, sizeof(double) * (2 * OC_MAX_WORLD + 8));
+    OC_HIP_CHECK(hipHostGetDevicePointer(&h->red_mailbox_dev, h->red_host + 2 * OC_MAX_WORLD, 0));
     *out = h;
     return OC_OK;
 }

@@ -73,7 +73,9 @@ struct oc_handle {
     void* hjb_buf = nullptr;    // y, ynew, ytmp, K0..K6, phi_tmp  (11 arrays)
     double* red_partial = nullptr;   // per-block partial sums
     double* red_out = nullptr;       // device: few doubles
-    double* red_host = nullptr;      // pinned host mirror
+    double* red_host = nullptr;      // pinned host mirror; [2*OC_MAX_WORLD ..+2]: mailbox (sum, max, sequence number)
+    void* red_mailbox_dev = nullptr; // device address of the mailbox
+    long long red_seq = 0;
     int32_t red_blocks = 0;
     // ---- per-key data
     std::vector<oc_field_desc> fields;
