@@ -267,7 +267,7 @@ __device__ __forceinline__ bool wall_needed(const GcfmParams& P, const KeyDev& k
     return true;
 }
 
-// wall_needed + the start of the search (column, nearest row), packed for the work-list
+// wall_needed + the start of the search (column, nearest row): what wall_search needs of one agent
 __device__ __forceinline__ bool wall_prepare(const GcfmParams& P, const KeyDev& kd, const Axis X0, const Axis Y0, double px,
                                              double py, double speed, WEntry& e) {
     double rad2, ub2;
