@@ -78,3 +78,45 @@ def test_pair_sums_match_all_pairs_numpy():
     assert np.any(want[12:] != 0.0) and np.array_equal(got[12:] != 0.0, want[12:] != 0.0)
     assert np.all(np.abs(got - want).max(axis=1) <= 5e-5 * np.maximum(np.abs(want).max(axis=1), 1e-3))
     eng.close()
+
+
+def test_pair_sums_when_every_tile_neighbours_every_tile():
+    """6000 agents in an 8 m x 6 m room (unphysical: 125 per m^2): 94 tiles that all lie within the cutoff of each
+    other, so the neighbour lists overflow (> 63 tiles -> every tile scans all tiles), nearly every pair is a
+    candidate and a virtual j-tile exceeds the candidate list (two rounds of 32 records)."""
+    eng, room, cfg, X0, Y0 = _engine("gold_b", "float32", n_keys=2, max_agents=8192)
+    rng = np.random.RandomState(4)
+    n = 6000
+    x, y = rng.uniform(0.3, room["room_length"] - 0.3, n), rng.uniform(0.3, room["room_height"] - 0.3, n)
+    vx, vy = rng.normal(0, 0.7, n), rng.normal(0, 0.7, n)
+    vdes = rng.normal(1.34, 0.26, n).clip(0.5, 2.2)
+    status = rng.rand(n) > 0.02
+    eng.set_agents(x, y, vx, vy, vdes, np.zeros(n, dtype=np.int32), status=status)
+    got = eng.pair_force().cpu().numpy()
+    want = _all_pairs(x, y, vx, vy, vdes, status, cfg)
+    # sums of ~5000 terms of size <= 4 in float32 chunks: relative to the sum of magnitudes, not to the (cancelling) sum
+    scale = np.maximum(np.abs(want).max(axis=1), 1.0) * 50
+    assert np.all(np.abs(got - want).max(axis=1)[status] <= 5e-5 * scale[status])
+    assert np.all(got[~status] == 0.0)
+    # the same crowd through the step kernels with 1, 2 and 4 wavefronts per tile (virtual j-tiles, shared LDS sums):
+    # one step from identical states; the speed clamp (v_max) maps the huge sums to directions
+    X, Y = np.meshgrid(X0, Y0)
+    names = []
+    for box in room["initial_boxes"].values():
+        k = " or ".join(box[5:])
+        if k not in names:
+            names.append(k)
+    for k, name in enumerate(names):
+        eng.set_potential(k, oc.finalize_potential(oc.create_potential(room, name.split(" or "), X, Y), cfg),
+                          np.zeros((0, 4)))
+    ref = None
+    for split in (1, 2, 4):
+        eng.set_tuning("pair_split", split)
+        eng.set_agents(x, y, vx, vy, vdes, np.zeros(n, dtype=np.int32), status=status)
+        eng.step(0, noise=np.zeros((n, 2)))
+        st = eng.get_state()
+        v = np.stack([st["vx"], st["vy"]], 1)
+        if ref is None:
+            ref = v
+        assert np.abs(v - ref).max() <= 2e-4
+    eng.close()
