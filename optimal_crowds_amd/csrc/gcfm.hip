@@ -259,7 +259,10 @@ __device__ __forceinline__ bool wall_needed(const GcfmParams& P, const KeyDev& k
     const double delta = sqrt(ex * ex + ey * ey) * (1.0 + 1e-12) + 1e-12;
     const double dn = (double)kd.edt[(size_t)in * Nx + jn];
     ub2 = INFINITY;
-    if ((rad > 0) && (dn * (1.0 - 1e-6) - delta > rad)) return false;
+    // a capped node (+inf) only proves "farther than the cap" (a radius beyond it -- an agent faster than v_max --
+    // still gets its search)
+    const double dlow = (dn < kd.edt_cap) ? dn * (1.0 - 1e-6) : kd.edt_cap;
+    if ((rad > 0) && (dlow - delta > rad)) return false;
     if (dn < kd.edt_cap) {
         double ub = dn * (1.0 + 1e-6) + delta + 1e-9;
         ub2 = ub * ub;
