@@ -368,3 +368,45 @@ def test_solve_kernels_agree_on_awkward_grids(Nx, Ny):
         assert o[0]["n_accept"] == out[0][0]["n_accept"] and o[0]["nfev"] == out[0][0]["nfev"]
         assert np.allclose(o[1], out[0][1], rtol=1e-12, atol=0)
         assert np.abs(o[2] - out[0][2]).max() <= 1e-8 and np.abs(o[3] - out[0][3]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 1e-6)])
+def test_lookup_random_positions_vs_oracle(dtype, tol):
+    """choose_optimal_velocity (optimals.py:212-250) for 4000 random positions -- interior, both one-cell strips
+    (x <= dx, x >= L - dx), cell edges (float floor-division), outside the room (numpy's negative-index wrap) -- and
+    steps around the horizon, against the oracle's per-position restatement evaluated on the GPU's own field."""
+    eng, room, cfg, X0, Y0 = _engine("gold_b", dtype, n_keys=1)
+    X, Y = np.meshgrid(X0, Y0)
+    key = " or ".join(list(room["initial_boxes"].values())[0][5:])
+    V = oc.finalize_potential(oc.create_potential(room, key.split(" or "), X, Y), cfg)
+    T, nt = 1.0, 50
+    eng.set_potential(0, V, _rects(room, key))
+    eng.alloc_field(0, nt - 1)
+    eng.solve(0, T, nt)
+    opt = oc.Optimals(V.copy(), T, room["room_length"], room["room_height"], cfg)
+    vx, vy = eng.field_interior(0)
+    opt.vx_opt[:] = vx.double().cpu().numpy()
+    opt.vy_opt[:] = vy.double().cpu().numpy()
+    L, H, gs = room["room_length"], room["room_height"], cfg["grid_step"]
+    rng = np.random.RandomState(6)
+    n = 4000
+    px, py = rng.uniform(-0.2, L + 0.2, n), rng.uniform(-0.2, H + 0.2, n)
+    px[:400] = rng.randint(0, eng.Nx, 400) * gs                      # on cell edges: x // dx in floating point
+    py[400:800] = rng.randint(0, eng.Ny, 400) * gs
+    px[800:1000] = rng.uniform(0, 1.5 * gs, 200)
+    py[1000:1200] = rng.uniform(H - 1.5 * gs, H, 200)
+    vdes = rng.uniform(0.8, 1.8, n)
+    eng.set_agents(px, py, np.zeros(n), np.zeros(n), vdes, np.zeros(n, dtype=np.int32))
+    for step in (0, 17, nt - 3, nt - 2, nt - 1, nt + 4):
+        des, err = eng.lookup(step)
+        des = des.cpu().numpy()
+        n_bad = 0
+        for a in range(n):
+            try:
+                want = vdes[a] * opt.choose_optimal_velocity((px[a], py[a]), step)
+            except IndexError:
+                n_bad += 1
+                continue
+            assert np.abs(des[a] - want).max() <= tol, (step, a, px[a], py[a], des[a], want)
+        assert (err > 0) == (n_bad > 0 and step < nt - 1)
+    eng.close()
