@@ -235,3 +235,42 @@ def test_row_shard_geometry():
         assert prev.g1 == Ny
     with pytest.raises(ValueError):
         parallel.RowShard(40, 0, 8, 6)
+
+
+# ------------------------------------------------------------------------------------------------ sharded-step plumbing
+def _step_comm_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from optimal_crowds_amd import parallel
+    parallel.init_distributed("gloo")
+    # the exchange buffer of oc_gcfm_step_sharded: every element is written by exactly one rank, zeros elsewhere
+    n = 6 * 128
+    owner = np.arange(n) % world
+    vals = np.random.RandomState(5).normal(size=n)
+    buf = torch.as_tensor(np.where(owner == rank, vals, 0.0))
+    comm = parallel.DistStepComm()
+    comm.bind(buf)
+    rc = comm._cb(None, buf.data_ptr(), n)                      # what the library's callback does
+    ok = rc == 0 and comm.error is None and comm.n_allreduce == 1 and np.array_equal(buf.numpy(), vals)
+    # a buffer the library did not announce is refused (and must not raise through the C frames)
+    other = torch.zeros(4, dtype=torch.float64)
+    rc2 = comm._cb(None, other.data_ptr(), 4)
+    refused = rc2 == -1 and isinstance(comm.error, AssertionError)
+    # row-block geometry the sharded lookup relies on: the owned rows tile the grid, halo >= 7 leaves a margin row
+    sh = parallel.RowShard(64, rank, world, halo=8)
+    q.put((rank, ok, refused, (sh.g0, sh.g1, sh.row0, sh.Ny_local, sh.field_margin)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_step_comm_and_row_shards_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_step_comm_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(r[1] and r[2] for r in res)
+    (g0a, g1a, row0a, nla, mga), (g0b, g1b, row0b, nlb, mgb) = res[0][3], res[1][3]
+    assert (g0a, g1a, g0b, g1b) == (0, 32, 32, 64)
+    assert (row0a, nla) == (0, 40) and (row0b, nlb) == (24, 40) and mga == mgb == 2
