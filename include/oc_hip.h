@@ -186,6 +186,11 @@ int64_t oc_padded_agents(int32_t N);
 int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise, uint64_t seed,
                          int32_t* counters, int32_t rank, int32_t world, double* xchg,
                          int (*allreduce_sum)(void* user, double* buf, int64_t count), void* user, void* stream);
+/* For a driver that does not read `counters` after every step (run() enqueues steps and looks every 16th):
+ * out4 (host) = { active agents now, 1 + the step in which the last active agent left (0: somebody is inside),
+ * 1 + index of an agent that was in the IndexError band (0: none), the first step in which it was }.  Synchronises;
+ * reset != 0 clears the last three afterwards.  simulations.py:427 (loop condition), optimals.py:234-239 (IndexError). */
+int oc_run_status(oc_handle* h, int32_t* out4, int reset, void* stream);
 int oc_set_resort_every(oc_handle* h, int32_t steps);
 /* Between consecutive oc_gcfm_step calls the library reuses the packed snapshot it wrote itself; call this after
  * modifying the state arrays in place from outside (new array pointers are detected automatically). */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "oc_padded_agents": (C.c_int64, [C.c_int32]),
     "oc_gcfm_step_sharded": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.c_int32, C.c_int32, C.c_void_p, ALLREDUCE_CB, C.c_void_p, C.c_void_p]),
+    "oc_run_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "oc_set_resort_every": (C.c_int, [C.c_void_p, C.c_int32]),
     "oc_agents_changed": (C.c_int, [C.c_void_p]),
     "oc_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(OcAgents), C.c_double, C.c_void_p, C.c_double,

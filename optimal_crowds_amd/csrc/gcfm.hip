@@ -56,6 +56,11 @@ struct GcfmParams {
 #define C_ACTIVE 2
 #define C_INVALID 6     // neighbour lists no longer cover the tile boxes -> full tile scan (sticky until the re-sort)
 #define C_NACTIVE 7     // active agents (set at the re-sort, decremented by exits): no hot same-address atomics
+// words 12..15 survive the re-sort (oc_run_status): what a driver that does not read the counters every step needs
+#define C_RS_DONE 12    // 1 + the step in which the last active agent left (0: somebody is still inside)
+#define C_RS_ERRA 13    // 1 + an agent that was in the IndexError band, and the (first) step in which it was
+#define C_RS_ERRS 14
+#define CTRL_VOLATILE_BYTES 48      // words 0..11 are reset at every re-sort
 
 // What the nearest-wall search of one agent needs (wall_prepare).
 struct WEntry {
@@ -1216,14 +1221,19 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     const double mxx = wmax(stay ? nx : -INFINITY), mxy = wmax(stay ? ny : -INFINITY);
     if (lane == 0) {
         if (it == 0) {                              // IndexError-band flag raised by the lookups of k_forces
-            A.cnt_out[C_ERR] = S.ctrl[C_ERR + 8];
+            const int e = S.ctrl[C_ERR + 8];
+            A.cnt_out[C_ERR] = e;
             S.ctrl[C_ERR + 8] = 0;
+            if (e && S.ctrl[C_RS_ERRA] == 0) {
+                S.ctrl[C_RS_ERRA] = e;
+                S.ctrl[C_RS_ERRS] = A.step;
+            }
         }
         if (m_out) {
             const int n = __popcll(m_out);
             atomicAdd(&A.cnt_out[C_EXIT], n);
             atomicSub(&A.cnt_out[C_ACTIVE], n);
-            atomicSub(&S.ctrl[C_NACTIVE], n);
+            if (atomicSub(&S.ctrl[C_NACTIVE], n) == n) S.ctrl[C_RS_DONE] = A.step + 1;     // the last ones just left
         }
         C.tile_box[it] = make_double4(mnx, mny, mxx, mxy);
         const double4 b0 = S.tile_box0[it];
@@ -1351,6 +1361,7 @@ int carve(oc_handle* h, int N, Scratch* S) {
         if (h->gcfm_buf) OC_HIP_CHECK(hipFree(h->gcfm_buf));
         h->gcfm_buf = nullptr;
         OC_HIP_CHECK(hipMalloc(&h->gcfm_buf, need));
+        OC_HIP_CHECK(hipMemset(h->gcfm_buf, 0, need));
         h->gcfm_bytes = need;
         h->packed_valid = false;
         h->work_valid = false;
@@ -1443,7 +1454,7 @@ bool wallmaps_ready(const oc_handle* h) {
 // re-sort + full pack of the current state + neighbour lists + dispatch order
 int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hipStream_t s) {
     const int N = a->N;
-    OC_HIP_CHECK(hipMemsetAsync(S->ctrl, 0, 64, s));
+    OC_HIP_CHECK(hipMemsetAsync(S->ctrl, 0, CTRL_VOLATILE_BYTES, s));
     if (N > 0) {
         hipLaunchKernelGGL(k_cell_keys, dim3((N + 255) / 256), dim3(256), 0, s, a->x, a->y, a->status, N, P, S->keys_a,
                            S->vals_a);
@@ -1639,6 +1650,28 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     }
     const TileShare all = {0, S.ntiles, 1, 0};
     return launch_step(h, a, S, P, simu_step, noise, seed, counters, all, nullptr, nullptr, nullptr, s);
+}
+
+extern "C" int oc_run_status(oc_handle* h, int32_t* out4, int reset, void* stream) {
+    OC_REQUIRE(h && out4, "null argument");
+    if (!h->gcfm_buf) {                 // no step has run yet: nothing to report (the scratch is born zeroed)
+        out4[0] = out4[1] = out4[2] = out4[3] = 0;
+        return OC_OK;
+    }
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scratch S;
+    int rc = carve(h, h->packed_N > 0 ? h->packed_N : 0, &S);
+    if (rc) return rc;
+    int32_t w[16];
+    OC_HIP_CHECK(hipMemcpyAsync(w, S.ctrl, sizeof(w), hipMemcpyDeviceToHost, s));
+    OC_HIP_CHECK(hipStreamSynchronize(s));
+    out4[0] = w[C_NACTIVE];
+    out4[1] = w[C_RS_DONE];
+    out4[2] = w[C_RS_ERRA];
+    out4[3] = w[C_RS_ERRS];
+    if (reset) OC_HIP_CHECK(hipMemsetAsync(S.ctrl + C_RS_DONE, 0, 4 * sizeof(int32_t), s));
+    return OC_OK;
 }
 
 extern "C" int64_t oc_padded_agents(int32_t N) {

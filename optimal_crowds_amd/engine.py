@@ -344,6 +344,13 @@ class Engine:
             return int(c[0]), int(c[1]), int(c[2])
         return None
 
+    def run_status(self, reset=False):
+        """(active agents, 1 + step in which the last agent left or 0, 1 + agent in the IndexError band or 0, its step):
+        what run() needs when it does not read the counters after every step (oc_run_status; synchronises)."""
+        out = (C.c_int32 * 4)()
+        check(self.lib.oc_run_status(self.h, out, int(bool(reset)), self.stream()))
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
     def density(self, sigma, V_all=None, trunc_sigmas=6.0, out_dtype=None):
         dt = self.dtype if out_dtype is None else out_dtype
         out = torch.empty((self.Ny, self.Nx), dtype=torch.float32 if dt == OC_F32 else torch.float64,

@@ -44,6 +44,12 @@ class _History(dict):
             dict.__setitem__(self, time, v)
         return v
 
+    def _truncate(self, last_step):
+        """drop the frames marked for steps beyond last_step (run() enqueues a few steps past the last exit)"""
+        for t in [t for t, st in self._steps.items() if st >= last_step]:
+            del self._steps[t]
+            dict.__delitem__(self, t)
+
     def values(self):
         return [self[k] for k in self.keys()]
 
@@ -229,9 +235,52 @@ class simulation:
         for key in self.targets:
             self.targets[key].compute_optimal_velocity(self.time, m)
 
+    def _run_enqueued(self):
+        """The loop of run() without a host round trip per step (device noise, no per-step printing): steps are
+        enqueued and the device-side run status is read every LOOK steps and before every recompute.  The status says
+        in which step the last agent left (or an agent entered the IndexError band), so the loop ends -- and `time`,
+        `simu_step`, the recorder -- stand exactly where the step-by-step loop would have ended: steps enqueued
+        after the last exit change nothing (no active agent) and are not counted."""
+        LOOK = 16
+        eng = self._engine
+        eng.run_status(reset=True)
+        first = self.simu_step
+        while (self.inside > 0) & (self.time < self.T):
+            if self.recompute and (self.simu_step % self.recompute_step == 0) and self.simu_step > 0:
+                print(f"Computing trajectories at time {self.time}")
+                self._solve_all()
+            self.write_history(self.time)
+            eng.step(self.simu_step, noise=None, seed=self._seed, sync=False)
+            self.time += self.dt
+            self.simu_step += 1
+            self._record(self.simu_step)
+            if (self.simu_step - first) % LOOK == 0 or not (self.time < self.T) or \
+                    (self.recompute and self.simu_step % self.recompute_step == 0):
+                active, done, bad, bad_step = eng.run_status()
+                if bad:
+                    # the reference raises inside the offending step (before time / simu_step advance)
+                    self.simu_step, self.time = bad_step, self._time_at(first, bad_step)
+                    raise IndexError("agent %d left the region covered by the floor field (index %d is out of "
+                                     "bounds)" % (bad - 1, bad - 1))
+                self.inside = active
+                if done:
+                    self.simu_step, self.time = done, self._time_at(first, done)
+                    self.history._truncate(done)            # write_history marks the frame BEFORE step s as s
+        self._status_host = eng.agents["status"].cpu().numpy().astype(bool)
+
+    def _time_at(self, first_step, step):
+        """`time` after the loop has advanced from first_step to step, accumulated like the reference does (time += dt)"""
+        t = self._time_first
+        for _ in range(step - first_step):
+            t += self.dt
+        return t
+
     def run(self, verbose=False, draw=False, mode='scatter'):
         print(f"Computing trajectories at time {self.time}")
         self._solve_all()
+        if self._noise_mode == "device" and not verbose and not draw:
+            self._time_first = self.time
+            self._run_enqueued()
         while (self.inside > 0) & (self.time < self.T):
             if self.recompute and (self.simu_step % self.recompute_step == 0) and self.simu_step > 0:
                 print(f"Computing trajectories at time {self.time}")

@@ -120,3 +120,33 @@ def test_single_point_api():
     fr = a.agents_repulsion(pj, vj)
     want = oc.pair_force(a.position(), a.velocity(), a.v_des, pj, vj, _cfg())
     assert np.allclose(fr, want, rtol=5e-5, atol=1e-7)
+
+
+def test_run_without_a_round_trip_per_step_ends_where_the_stepwise_loop_ends():
+    """run() with device noise enqueues the steps and reads the device-side run status every 16 steps; it must stop
+    -- time, simu_step, inside, agent state, history marks -- exactly where the step-by-step loop (verbose=True)
+    stops, also when the evacuation completes between two looks."""
+    import contextlib
+    import io
+    from optimal_crowds_amd import host, simulations
+    cfg = copy.deepcopy(host.load_config())
+    cfg["grid_step"] = 0.1
+    out = []
+    for verbose in (False, True):
+        np.random.seed(3)
+        with contextlib.redirect_stdout(io.StringIO()) as buf:
+            sim = simulations.simulation("room_test", 25.0, config=cfg, noise="device", seed=5, record=True,
+                                         history=True, wall_search_radius=0.0)
+            sim.run(verbose=verbose)
+        st = sim._engine.get_state()
+        out.append((sim.simu_step, sim.time, sim.inside, st, sorted(sim.history.keys()), buf.getvalue().splitlines()[-1],
+                    sim.evac_times() if sim.inside == 0 else None))
+        sim._engine.close()
+    a, b = out
+    assert a[2] == 0 and b[2] == 0, "the crowd should be out well before T = 25 s"
+    assert a[0] == b[0] and a[1] == b[1] and a[0] % 16 != 0          # (ends between two looks)
+    for f in ("x", "y", "vx", "vy", "status", "agent_time"):
+        assert np.array_equal(a[3][f], b[3][f])
+    assert a[4] == b[4]
+    assert a[5] == b[5] and a[5].startswith("Evacuation complete")
+    assert np.array_equal(a[6], b[6])
