@@ -162,28 +162,8 @@ __global__ void k_cell_keys(const double* __restrict__ x, const double* __restri
     vals[i] = i;
 }
 
-// Exact nearest-site query (same cell as numpy's argmin over the full grid, see oracle WallMap for the proof
-// sketch): per grid row only the nearest site left and right of the agent's column can be the row minimum.
-__device__ __forceinline__ void wall_try(double px, double py, int r, int cnd, int Nx, const Axis X0,
-                                         double yr, double off, double& best_d2, double& thr, double& best_f,
-                                         long long& best_flat) {
-    if (cnd < 0 || cnd >= Nx) return;
-    double ddx = X0[cnd] - px, ddy = yr - py;
-    double d2 = ddx * ddx + ddy * ddy;
-    if (d2 > thr) return;
-    double f = sqrt(d2) + off;                  // fl(fl(sqrt) + V*10e3): the reference's objective
-    long long flat = (long long)r * Nx + cnd;
-    if (f < best_f || (f == best_f && flat < best_flat)) {
-        best_f = f;
-        best_flat = flat;
-    }
-    if (d2 < best_d2) {
-        best_d2 = d2;
-        double bd = sqrt(d2);
-        thr = d2 + 4.8e-10 * bd + 1e-19;        // anything farther cannot tie after rounding at ulp(1e6)
-    }
-}
-
+// Exact nearest-site query (same cell as numpy's argmin over the full grid, see oracle WallMap for the proof sketch):
+// per grid row only the nearest site left and right of the agent's column can be the row minimum (wall_search below).
 // search radius when P.wall_radius < 0: beyond it the force 3|R| exp(-(|R| - q)/(eta_w (1 + v_rel))) is below
 // 1e-12 m/s for this agent's own speed (q <= a^2, v_rel <= |v|; 33 = ln(3 * 60 m / 1e-12 m/s) rounded up)
 __device__ __forceinline__ double wall_radius_of(const GcfmParams& P, double s) {
@@ -191,61 +171,6 @@ __device__ __forceinline__ double wall_radius_of(const GcfmParams& P, double s) 
     double a = fmax(P.a_min + P.tau_a * s, P.b_max);        // q <= max(a, b)^2
     return a * a + P.eta_walls * (1.0 + s) * 33.0;
 }
-
-#define WALL_UNROLL 4
-// Scan grid rows outward from the row nearest to py; per row the two candidates bracketing px come from the
-// transposed table lr[jx][row] (rows contiguous: 4 rows = 32 bytes per lane and direction).  Rows stop when
-// their |dy| alone exceeds the best distance (+ tie slack), the search radius, or a known upper bound ub2.
-__device__ __forceinline__ void wall_scan(double px, double py, const int2* __restrict__ lr, int Nx, int Ny, double hx,
-                                          double hy, const Axis X0, const Axis Y0,
-                                          double off, double rad2, double ub2, long long& best_flat, double& best_d2) {
-    int jx = (int)floor(px / hx);
-    jx = jx < 0 ? 0 : (jx > Nx - 1 ? Nx - 1 : jx);
-    while (jx > 0 && X0[jx] > px) --jx;
-    while (jx < Nx - 1 && X0[jx + 1] <= px) ++jx;
-    int r0 = (int)floor(py / hy + 0.5);
-    r0 = r0 < 0 ? 0 : (r0 > Ny - 1 ? Ny - 1 : r0);
-    const int2* __restrict__ col = lr + (size_t)jx * Ny;
-    double thr = INFINITY, best_f = INFINITY;
-    best_d2 = INFINITY;
-    best_flat = -1;
-    const double lim2 = fmin(rad2, ub2);
-    bool up = true, dn = true;
-    for (int o = 0; up || dn; o += WALL_UNROLL) {
-        int rows[2 * WALL_UNROLL];
-        int2 cand[2 * WALL_UNROLL];
-        double yr[2 * WALL_UNROLL];
-#pragma unroll
-        for (int u = 0; u < WALL_UNROLL; ++u) {
-            int ru = r0 + o + u, rd = r0 - o - u;
-            rows[2 * u] = (up && ru < Ny) ? ru : -1;
-            rows[2 * u + 1] = (dn && rd >= 0 && (o + u) > 0) ? rd : -1;
-        }
-#pragma unroll
-        for (int q = 0; q < 2 * WALL_UNROLL; ++q) {
-            int rr = rows[q] >= 0 ? rows[q] : 0;
-            yr[q] = Y0[rr];
-            cand[q] = col[rr];
-        }
-#pragma unroll
-        for (int q = 0; q < 2 * WALL_UNROLL; ++q) {
-            int r = rows[q];
-            if (r < 0) continue;
-            double ady = fabs(yr[q] - py), ady2 = ady * ady;
-            if (ady2 > thr || ady2 > lim2) {
-                // rows only get farther in this direction once they are past the query point
-                if ((q & 1) == 0) { if (yr[q] > py) up = false; }
-                else { if (yr[q] < py) dn = false; }
-                continue;
-            }
-            wall_try(px, py, r, cand[q].x, Nx, X0, yr[q], off, best_d2, thr, best_f, best_flat);
-            wall_try(px, py, r, cand[q].y, Nx, X0, yr[q], off, best_d2, thr, best_f, best_flat);
-        }
-        if (r0 + o + WALL_UNROLL >= Ny) up = false;
-        if (r0 - o - WALL_UNROLL < 0) dn = false;
-    }
-}
-
 
 // Can this agent feel a wall?  Uses the capped distance transform at the nearest grid node:
 // d(node) - |p - node| <= d*(p) <= d(node) + |p - node|.  Returns false when d*(p) provably exceeds the agent's
@@ -914,6 +839,36 @@ __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEnt
     return best_flat;
 }
 
+// capped exact distance transform of the site set on the grid nodes (when a wall map is built): every node is a query of
+// the block-pruned search, radius = cap.
+__global__ void __launch_bounds__(64) k_edt_nodes(GcfmParams P, const int2* __restrict__ lr,
+                                                  const int32_t* __restrict__ gap8, const Axis X0, const Axis Y0,
+                                                  double cap, float* __restrict__ edt) {
+    const int Nx = P.Nx, Ny = P.Ny;
+    const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
+    const bool go = t < (long long)Nx * Ny;
+    const int i = go ? (int)(t / Nx) : 0, j = go ? (int)(t % Nx) : 0;
+    WEntry we;
+    we.px = X0[j];
+    we.py = Y0[i];
+    we.lim2 = cap * cap;
+    we.off = 0.0;
+    we.col = lr + (size_t)j * Ny;
+    we.g8 = gap8 + (size_t)j * ((Ny + 7) >> 3);
+    we.b0 = i >> 3;
+    we.prune_ok = 1;
+    const long long flat = wall_search(P, we, go, X0, Y0);
+    if (!go) return;
+    double d = INFINITY;
+    if (flat >= 0) {
+        const double ddx = X0[(int)(flat % Nx)] - we.px, ddy = Y0[(int)(flat / Nx)] - we.py;
+        d = sqrt(ddx * ddx + ddy * ddy);
+    }
+    // nodes farther than the cap from every site store +inf: a float-rounded cap must never pass for a distance (it
+    // would become an upper bound on the nearest-site distance in wall_needed and prune the real site)
+    edt[t] = (d < cap) ? (float)d : INFINITY;
+}
+
 // standalone wall search (diagnostic exports): one lane per slot
 __global__ void __launch_bounds__(64) k_wall(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, const Axis X0,
                                              const Axis Y0) {
@@ -939,22 +894,6 @@ __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S) {
     if (live) pair_share<1>(P, S, C, L, it, w, 0, w, lane);
     __syncthreads();
     if (live) S.f_pair[it * 64 + lane] = make_double2(L.accx[w][lane], L.accy[w][lane]);
-}
-
-// capped exact distance transform of the site set on the grid nodes (init-time, one thread per node)
-__global__ void __launch_bounds__(256) k_edt(const int2* __restrict__ lr, int Nx, int Ny, double hx, double hy,
-                                             const Axis X0, const Axis Y0, double cap,
-                                             float* __restrict__ edt) {
-    int j = blockIdx.x * 64 + (threadIdx.x & 63);
-    int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i >= Ny || j >= Nx) return;
-    long long flat;
-    double d2;
-    wall_scan(X0[j], Y0[i], lr, Nx, Ny, hx, hy, X0, Y0, 0.0, cap * cap, INFINITY, flat, d2);
-    // nodes farther than the cap from every site store +inf: a float-rounded cap must never pass for a distance (it
-    // would become an upper bound on the nearest-site distance in wall_needed and prune the real site)
-    double d = (flat >= 0) ? sqrt(d2) : INFINITY;
-    edt[(size_t)i * Nx + j] = (d < cap) ? (float)d : INFINITY;
 }
 
 // ---------------------------------------------------------------------------------- lookup
@@ -1504,9 +1443,8 @@ extern "C" int oc_wallmap_build(oc_handle* h, int key, const float* V, float vmi
     double amax = c.a_min + c.tau_a * c.v_max;
     w.edt_cap = amax * amax + c.eta_walls * (1.0 + c.v_max) * 33.0 + 1.0;
     if (c.wall_search_radius > 0) w.edt_cap = std::max(w.edt_cap, c.wall_search_radius + 1.0);
-    hipLaunchKernelGGL(k_edt, dim3((c.Nx + 63) / 64, (c.Ny + 3) / 4), dim3(256), 0, s, (const int2*)w.left, c.Nx, c.Ny,
-                       c.room_length / (c.Nx - 1), c.room_height / (c.Ny - 1), axis_x(h), axis_y(h), w.edt_cap,
-                       (float*)w.right);
+    hipLaunchKernelGGL(k_edt_nodes, dim3((unsigned)(((size_t)c.Nx * c.Ny + 63) / 64)), dim3(64), 0, s, make_params(h),
+                       (const int2*)w.left, (const int32_t*)w.gap8, axis_x(h), axis_y(h), w.edt_cap, (float*)w.right);
     OC_HIP_CHECK(hipGetLastError());
     w.off = (double)vmin * 10e3;
     w.built = true;
