@@ -303,7 +303,7 @@ def main():
         result["breakdown"]["gcfm_work"] = gcfm_work(sim, cfg, kf["avg_ms"] * 1e-3,
                                                      result["breakdown"]["gcfm_ms_per_step"] * 1e-3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(sim, cfg, n_att)
+        result["cpu_baseline"] = cpu_baseline(sim, cfg, n_att, budget_s=float(os.environ.get("OC_BENCH_CPU_BUDGET", "20")))
         result["cpu_baseline"]["host_cpus"] = os.cpu_count()
     if rank == 0:
         print(json.dumps(result))
