@@ -166,3 +166,24 @@ def test_counters_follow_exits_without_per_tile_atomics():
         assert int(st["status"].astype(bool).sum()) == active
     assert total_exits > 0
     eng.close()
+
+
+def test_spatial_resort_period_does_not_change_the_step():
+    """Sortedness is an implementation detail: re-sorting the agents every step, every 3rd or every 16th step (other
+    tiles, other neighbour lists, other summation order) gives the same trajectories to float32 summation noise."""
+    eng, room, cfg, X0, Y0 = _engine("exit_opposite", "float32", n_keys=2, max_agents=8192, cfg=_big(),
+                                     wall_search_radius=0.0)
+    state = _crowd(eng, room, cfg, X0, Y0, n=6000, seed=12)
+    n = len(state[0])
+    noise = np.random.RandomState(2).normal(size=(3, n, 2))
+    ref = None
+    for every in (16, 1, 3):
+        eng.set_resort_every(every)
+        st, out = _run(eng, state, 3, noise)
+        if ref is None:
+            ref = (st, out)
+            continue
+        assert out == ref[1] and np.array_equal(st["status"], ref[0]["status"])
+        for f, tol in (("x", 1e-6), ("y", 1e-6), ("vx", 1e-4), ("vy", 1e-4)):
+            assert np.abs(st[f] - ref[0][f]).max() <= tol, (every, f)
+    eng.close()
