@@ -188,6 +188,26 @@ def pmc_traffic(workload):
     return None
 
 
+def pmc_valu(workload):
+    """Wave-level VALU instructions per k_forces launch from the committed SQ-counter summary
+    (profiles/rNN_pmc_step_kernels.txt, tools/pmc_step.sh: rocprofv3 --pmc passes of this very command); None if
+    absent or for another workload."""
+    import glob
+    import re
+    if workload != "metro_station":
+        return None
+    for f in reversed(sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_step_kernels.txt")))):
+        try:
+            txt = open(f).read()
+            blk = txt[txt.index("k_forces"):]
+            m = re.search(r"SQ_INSTS_VALU\s+n=\d+\s+mean=([0-9.e+]+)", blk)
+            if m:
+                return float(m.group(1))
+        except Exception:
+            pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -299,6 +319,16 @@ def main():
                       "rk_accepted": n_acc, "kernels": kstats, "init_s": t_init, "active_agents_end": int(eng.counters.cpu()[2])},
     }
     kf = kstats.get("gcfm_forces", {})
+    nv = pmc_valu(args.workload)
+    if kf.get("avg_ms") and nv:
+        # the step's dominant kernel is bound by vector-instruction issue, not by HBM or MFMA: a plain (unpacked) VALU
+        # instruction of a wavefront occupies its SIMD for 4 cycles -> peak = 1024 SIMDs x 2.4 GHz / 4
+        peak = 256 * 4 * 2.4e9 / 4
+        ach = nv / (kf["avg_ms"] * 1e-3)
+        result["roofline_valu"] = {"bound": "valu-issue", "kernel": "k_forces (pair forces + wall search + lookup)",
+                                   "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
+                                   "frac": ach / peak, "valu_instructions_per_launch": nv,
+                                   "avg_launch_ms": kf["avg_ms"], "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/)"}
     if rank == 0 and kf.get("avg_ms") and not args.no_work_count:
         result["breakdown"]["gcfm_work"] = gcfm_work(sim, cfg, kf["avg_ms"] * 1e-3,
                                                      result["breakdown"]["gcfm_ms_per_step"] * 1e-3)
