@@ -169,24 +169,39 @@ __global__ void k_err_norm(const T* __restrict__ y, const T* __restrict__ ynew, 
 
 // `mailbox` (optional): pinned host memory mapped into the device.  The result is also stored there, followed by the
 // sequence number `seq`, so that the host can read it by polling three words instead of a copy + stream synchronise.
-__global__ void k_reduce_final(const double* __restrict__ partial, int nblocks, double* __restrict__ out,
-                               volatile double* mailbox = nullptr, double seq = 0.0) {
+__global__ void __launch_bounds__(1024) k_reduce_final(const double* __restrict__ partial, int nblocks,
+                                                        double* __restrict__ out, volatile double* mailbox = nullptr,
+                                                        double seq = 0.0) {
+    // the host waits for this kernel: all loads of a thread are issued before the first is used (4 per round; the
+    // partials were written by other XCDs a moment ago, so each round trip is a full memory latency)
+    const double2* __restrict__ p2 = reinterpret_cast<const double2*>(partial);
     double s = 0.0, m = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
-        s += partial[2 * i];
-        m = fmax(m, partial[2 * i + 1]);
+    const int nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < nblocks; i0 += 4 * nt) {
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i0 + u * nt < nblocks) ? p2[i0 + u * nt] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s += v[u].x;
+            m = fmax(m, v[u].y);
+        }
     }
-    __shared__ double ls[4], lm[4];
+    __shared__ double ls[16], lm[16];
     s = wave_sum(s);
     m = wave_max(m);
-    int w = threadIdx.x >> 6;
+    const int w = threadIdx.x >> 6, nw = (nt + 63) >> 6;
     if ((threadIdx.x & 63) == 0) {
         ls[w] = s;
         lm[w] = m;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double a = ls[0] + ls[1] + ls[2] + ls[3], b = fmax(fmax(lm[0], lm[1]), fmax(lm[2], lm[3]));
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < nw; ++q) {
+            a += ls[q];
+            b = fmax(b, lm[q]);
+        }
         out[0] = a;
         out[1] = b;
         if (mailbox) {
@@ -742,7 +757,7 @@ struct Solver {
         if (sh) {
             // every rank contributes (sum, max) of its owned rows; the caller's collective gathers them (on `s`) and
             // every rank adds them up in rank order, so all ranks take bit-identical controller decisions
-            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, h->red_partial, nblocks, sh->red_local);
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, nblocks, sh->red_local);
             if (sh->allgather_red(sh->user) != 0) {
                 oc_set_error("hjb_solve_rows: the allgather_red callback failed");
                 return OC_ERR_STATE;
@@ -763,7 +778,7 @@ struct Solver {
         // number (a copy + stream synchronise costs ~10 us more per attempt: an extra command and the wake-up)
         volatile double* mb = h->red_host + 2 * OC_MAX_WORLD;
         const double seq = (double)(++h->red_seq);
-        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, h->red_partial, nblocks, h->red_out,
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, nblocks, h->red_out,
                            (volatile double*)h->red_mailbox_dev, seq);
         bool got = false;
         for (long spin = 0; spin < 20000000L; ++spin) {         // ~ a second at worst, then fall back to the stream
