@@ -1095,6 +1095,10 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     double nx = 1e300, ny = 1e300;
     const double2 p = C.ppos[k], v = S.pvd[k], ds = S.des[k], fw = S.f_wall[k], fp = S.f_pair[k];
     const PDK dk = S.pdk[k];
+    // (needed only at the very end, by lane 0: fetched with the rest so that the tail holds no memory round trip)
+    const double4 b0 = S.tile_box0[it];
+    const int err0 = (it == 0) ? S.ctrl[C_ERR + 8] : 0;
+    const double at0 = (act && A.agent_time) ? A.agent_time[i] : 0.0;
     double n0 = 0.0, n1 = 0.0;
     if (act) {      // noise: caller's standard normals, or Philox4x32-10 + Box-Muller (float32)
         if (A.noise) {
@@ -1129,7 +1133,7 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
         A.y[i] = ny;
         A.vx[i] = nvx;
         A.vy[i] = nvy;
-        if (A.agent_time) A.agent_time[i] += dt;
+        if (A.agent_time) A.agent_time[i] = at0 + dt;
         // exit test against the agent's own targets, strict (pedestrians.py:132-136)
         const double* rt = (tab_lds ? l_rect : rect_tab) + (size_t)dk.key * RECT_TAB;
         const int nrect = (int)rt[0];
@@ -1160,7 +1164,7 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     const double mxx = wmax(stay ? nx : -INFINITY), mxy = wmax(stay ? ny : -INFINITY);
     if (lane == 0) {
         if (it == 0) {                              // IndexError-band flag raised by the lookups of k_forces
-            const int e = S.ctrl[C_ERR + 8];
+            const int e = err0;
             A.cnt_out[C_ERR] = e;
             S.ctrl[C_ERR + 8] = 0;
             if (e && S.ctrl[C_RS_ERRA] == 0) {
@@ -1175,7 +1179,6 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
             if (atomicSub(&S.ctrl[C_NACTIVE], n) == n) S.ctrl[C_RS_DONE] = A.step + 1;     // the last ones just left
         }
         C.tile_box[it] = make_double4(mnx, mny, mxx, mxy);
-        const double4 b0 = S.tile_box0[it];
         const double D = P.drift;
         if (mnx <= mxx && (mnx < b0.x - D || mny < b0.y - D || mxx > b0.z + D || mxy > b0.w + D)) S.ctrl[C_INVALID] = 1;
     }
