@@ -219,6 +219,26 @@ int oc_set_hjb_variant(oc_handle* h, int variant);
  *   "prep_blocks" blocks of the force kernel that do the wall search / field lookup of the tiles (default 256) */
 int oc_set_tuning(oc_handle* h, const char* name, int value);
 
+/* Opt-in corrections of reference quirks (SURVEY.md quirk register, section 8f-4).  Default 0: every entry point is
+ * bug-compatible with the reference.  Each bit replaces one documented oddity by what the model intends:
+ *   OC_FIX_LOOKUP        optimals.py:234-248 (Q7, Q8): the desired direction at (x, y) is the bilinear interpolation of
+ *                        the direction field over the four grid NODES around the position (node j at X0[j]); the
+ *                        reference indexes the interior array with grid indices (a one-cell shift), averages the
+ *                        diagonal pair only, and raises IndexError in a band along the far borders -- here positions are
+ *                        clamped to the interior nodes and no error flag is raised.
+ *   OC_FIX_WALL_FORCE    pedestrians.py:328,334 (Q12): q_i = 1/sqrt(.) (the reference omits the root), force
+ *                        -rep * e along the UNIT vector to the nearest wall cell, without the factor 3.
+ *   OC_FIX_PAIR_FORCE    pedestrians.py:280 (Q12): agent repulsion -rep * e along the unit vector (reference: -rep * R).
+ *   OC_FIX_DENSITY_NORM  simulations.py:482 (Q11): Gaussian normaliser 2 pi sigma^2 (reference: 2 pi sigma).
+ * (Q9, the shrinking horizon of a recompute, is host logic: the caller passes the full horizon to oc_hjb_solve --
+ * optimal_crowds_amd.simulations.simulation(fixes=...) does.) */
+#define OC_FIX_LOOKUP 1u
+#define OC_FIX_WALL_FORCE 2u
+#define OC_FIX_PAIR_FORCE 4u
+#define OC_FIX_DENSITY_NORM 8u
+#define OC_FIX_ALL 15u
+int oc_set_fix_flags(oc_handle* h, uint32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(HERE, "liboc_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
 OC_F32, OC_F64 = 0, 1
+# opt-in corrections of reference quirks (oc_hip.h: oc_set_fix_flags); 'horizon' (Q9) is host logic in the facade
+FIX_BITS = {"lookup": 1, "wall_force": 2, "pair_force": 4, "density_norm": 8}
 
 
 class OcConfig(C.Structure):
@@ -105,6 +107,7 @@ SIGNATURES = {
     "oc_reset_kernel_stats": (C.c_int, [C.c_void_p]),
     "oc_set_hjb_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "oc_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "oc_set_fix_flags": (C.c_int, [C.c_void_p, C.c_uint32]),
 }
 
 _lib = None

@@ -1,5 +1,6 @@
 // Gaussian crowd density on the room grid: replaces simulation.gaussian_density, reference simulations.py:453-487.
 //   d[i,j] = sum_{active a} exp(-((X_j-x_a)^2 + (Y_i-y_a)^2) / (2 sigma^2)) / (2 pi sigma);   d[V_all < 0] = 0
+// (the reference's normaliser, quirk Q11; 2 pi sigma^2 with OC_FIX_DENSITY_NORM)
 // Agents are ordered by coarse cells of side R = trunc_sigmas*sigma; an output tile only visits the agents of the
 // coarse cells that intersect tile +- R (row-major keys make each coarse row one contiguous slot range).  Everything
 // inside those cells is summed exactly (no radial test), what is dropped is < exp(-trunc^2/2) relative.
@@ -116,21 +117,21 @@ extern "C" int oc_density(oc_handle* h, int dtype, const oc_agents* a, double si
     P.ncx = (int)(c.room_length / P.cell) + 1;
     P.ncy = (int)(c.room_height / P.cell) + 1;
     P.inv2s2 = 1.0 / (2 * sigma * sigma);
-    P.invC = 1.0 / std::sqrt(4 * M_PI * M_PI * sigma * sigma);
+    P.invC = (h->fix_flags & OC_FIX_DENSITY_NORM) ? 1.0 / (2 * M_PI * sigma * sigma)            // Q11 corrected
+                                                    : 1.0 / std::sqrt(4 * M_PI * M_PI * sigma * sigma);
     const int N = a->N, ncell = P.ncx * P.ncy;
     OC_REQUIRE((int64_t)P.ncx * P.ncy < 0x3FFFFFFF, "too many coarse cells");
     // scratch: keys/vals x2, sorted positions, cell starts
     size_t need = (size_t)N * (2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + sizeof(double2)) +
                   sizeof(int32_t) * (size_t)(ncell + 2) + 4096;
-    static thread_local void* buf = nullptr;
-    static thread_local size_t buf_bytes = 0;
-    if (need > buf_bytes) {
-        if (buf) OC_HIP_CHECK(hipFree(buf));
-        buf = nullptr;
-        OC_HIP_CHECK(hipMalloc(&buf, need));
-        buf_bytes = need;
+    if (need > h->dens_bytes) {
+        if (h->dens_buf) OC_HIP_CHECK(hipFree(h->dens_buf));
+        h->dens_buf = nullptr;
+        h->dens_bytes = 0;
+        OC_HIP_CHECK(hipMalloc(&h->dens_buf, need));
+        h->dens_bytes = need;
     }
-    char* p = (char*)buf;
+    char* p = (char*)h->dens_buf;
     auto take = [&](size_t bytes) {
         char* q = p;
         p += (bytes + 255) & ~(size_t)255;

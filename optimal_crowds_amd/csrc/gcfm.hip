@@ -47,6 +47,7 @@ struct GcfmParams {
     double cell;        // coarse cell size for ordering
     double drift;       // D: how far a tile box may grow beyond its sort-time box before the lists are invalid
     int32_t ncx, ncy, horder;
+    uint32_t fix;       // OC_FIX_* bits (oc_set_fix_flags); 0 = the reference's behaviour
 };
 
 #define NB_MAX 63
@@ -168,8 +169,8 @@ __global__ void k_cell_keys(const double* __restrict__ x, const double* __restri
 // 1e-12 m/s for this agent's own speed (q <= a^2, v_rel <= |v|; 33 = ln(3 * 60 m / 1e-12 m/s) rounded up)
 __device__ __forceinline__ double wall_radius_of(const GcfmParams& P, double s) {
     if (P.wall_radius >= 0) return P.wall_radius;
-    double a = fmax(P.a_min + P.tau_a * s, P.b_max);        // q <= max(a, b)^2
-    return a * a + P.eta_walls * (1.0 + s) * 33.0;
+    double a = fmax(P.a_min + P.tau_a * s, P.b_max);        // q <= max(a, b)^2  (<= max(a, b) with OC_FIX_WALL_FORCE)
+    return ((P.fix & OC_FIX_WALL_FORCE) ? a : a * a) + P.eta_walls * (1.0 + s) * 33.0;
 }
 
 // Can this agent feel a wall?  Uses the capped distance transform at the nearest grid node:
@@ -233,6 +234,7 @@ __device__ __forceinline__ double2 wall_force_of(const GcfmParams& P, long long 
     int r = (int)(flat / P.Nx), cc = (int)(flat % P.Nx);
     double Rx = X0[cc] - px, Ry = Y0[r] - py;
     double rr = sqrt(Rx * Rx + Ry * Ry);
+    if (!(rr > 0.0)) return make_double2(0.0, 0.0);     // D1
     double ex = Rx / rr, ey = Ry / rr;
     double d = vxd * ex + vyd * ey;
     double vrel = 0.5 * (d + fabs(d));
@@ -246,8 +248,10 @@ __device__ __forceinline__ double2 wall_force_of(const GcfmParams& P, long long 
     double b = P.b_max - (P.b_max - P.b_min) * fmin(s / vdes, 1.0);
     double ca = (ex * hx + ey * hy) / a, sb = (hx * ey - hy * ex) / b;
     double q = 1.0 / (ca * ca + sb * sb);                 // Q12: no square root
+    if (P.fix & OC_FIX_WALL_FORCE) q = sqrt(q);
     double dist = rr - q;
     double rep = fmin(exp(-dist / (P.eta_walls * (1.0 + vrel))), 1.0);
+    if (P.fix & OC_FIX_WALL_FORCE) return make_double2(-rep * ex, -rep * ey);
     return make_double2(-3.0 * rep * Rx, -3.0 * rep * Ry);
 }
 
@@ -344,7 +348,7 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void pair_term2(f2v Rx, f2v Ry, float vxi, float vyi, float si, float hxi, float hyi,
                                            float ia2_i, float ib2_i, float inv_vdes_i, f2v vjx, f2v vjy, f2v sj,
                                            f2v ia2_j, f2v hjx, f2v hjy, float b_max, float db,
-                                           float neg_inv_eta_log2e, f2v& fx, f2v& fy) {
+                                           float neg_inv_eta_log2e, bool unit_dir, f2v& fx, f2v& fy) {
     const f2v one = {1.f, 1.f}, zero = {0.f, 0.f};
     const f2v r2 = __builtin_elementwise_fma(Rx, Rx, Ry * Ry);
     const f2v inv_r = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
@@ -377,8 +381,13 @@ __device__ __forceinline__ void pair_term2(f2v Rx, f2v Ry, float vxi, float vyi,
                     (f2v){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
     const f2v ex2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
     const f2v rep = __builtin_elementwise_min(kk * ex2, one);
-    fx = -(rep * Rx);
-    fy = -(rep * Ry);
+    if (unit_dir) {                     // OC_FIX_PAIR_FORCE (wave-uniform): along the unit vector
+        fx = -(rep * ex);
+        fy = -(rep * ey);
+    } else {                            // the reference scales the distance vector (pedestrians.py:280)
+        fx = -(rep * Rx);
+        fy = -(rep * Ry);
+    }
 }
 
 #define PAIR_LIST_CAP 1024      // list entries (two candidates of one agent each): 64 agents x 32 j always fit
@@ -455,6 +464,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
     constexpr int NROUND = 2;                     // rounds of 32 records for a dense virtual tile
     const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
     const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
+    const bool unit_dir = (P.fix & OC_FIX_PAIR_FORCE) != 0;
     const double c = P.cutoff, c2 = c * c;
     const int k = it * 64 + lane;
     const int i = C.pidx[k];
@@ -646,7 +656,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                         pair_term2((f2v){(float)dxA, (float)dxB}, (f2v){(float)dyA, (float)dyB}, va.x, va.y, va.z, aux.x,
                                    aux.y, va.w, aux.z, aux.w, (f2v){vbA.x, vbB.x}, (f2v){vbA.y, vbB.y},
                                    (f2v){vbA.z, vbB.z}, (f2v){vbA.w, vbB.w}, (f2v){hbA.x, hbB.x}, (f2v){hbA.y, hbB.y},
-                                   b_max, db, neg_inv_eta_log2e, fx, fy);
+                                   b_max, db, neg_inv_eta_log2e, unit_dir, fx, fy);
                         const f2v fA = {okA ? fx.x : 0.f, okA ? fy.x : 0.f}, fB = {okB ? fx.y : 0.f, okB ? fy.y : 0.f};
                         sf += fA + fB;
                     }
@@ -929,10 +939,51 @@ __device__ __forceinline__ double2 field_fetch(const KeyDev& kd, int step, int i
     return make_double2((ax + bx) / 2, (ay + by) / 2);
 }
 
+// OC_FIX_LOOKUP: the four grid nodes (r0|r1, c0|c1) around the position, weights (1-fy|fy) x (1-fx|fx); the padded
+// slices are indexed by grid row and column directly
+template <typename T>
+__device__ __forceinline__ double2 field_bilinear(const KeyDev& kd, int step, int r0, int r1, int c0, int c1, double fy,
+                                                  double fx, int Nx, int Ny) {
+    const size_t W = (size_t)Nx;
+    const int rows = kd.rows < 0 ? Ny : kd.rows;
+    const T* gx = (const T*)kd.vx + (size_t)step * W * rows;
+    const T* gy = (const T*)kd.vy + (size_t)step * W * rows;
+    const size_t a = (size_t)(r0 - kd.row0) * W, b = (size_t)(r1 - kd.row0) * W;
+    const double w00 = (1.0 - fy) * (1.0 - fx), w01 = (1.0 - fy) * fx, w10 = fy * (1.0 - fx), w11 = fy * fx;
+    return make_double2(
+        w00 * (double)gx[a + c0] + w01 * (double)gx[a + c1] + w10 * (double)gx[b + c0] + w11 * (double)gx[b + c1],
+        w00 * (double)gy[a + c0] + w01 * (double)gy[a + c1] + w10 * (double)gy[b + c0] + w11 * (double)gy[b + c1]);
+}
+
+__device__ __forceinline__ double2 lookup_bilinear(const GcfmParams& P, const KeyDev& kd, double x, double y,
+                                                   double vdes, int step) {
+    const int Nx = P.Nx, Ny = P.Ny;
+    if (step >= kd.nslice_alloc) return make_double2(0.0, 0.0);
+    // node j sits at X0[j] = j * L / (Nx - 1); the field lives on the interior nodes 1 .. Nx-2 (clamped outside)
+    auto split = [](double g, int n, int& i0, int& i1, double& f) {
+        double fl = floor(g);
+        if (!(fl >= 1.0)) fl = 1.0, g = 1.0;                 // (also NaN)
+        if (fl >= (double)(n - 2)) fl = (double)(n - 2), g = fl;
+        i0 = (int)fl;
+        i1 = i0 + 1 > n - 2 ? n - 2 : i0 + 1;
+        f = g - fl;
+    };
+    int c0, c1, r0, r1;
+    double fx, fy;
+    split(x / (P.L / (Nx - 1)), Nx, c0, c1, fx);
+    split(y / (P.H / (Ny - 1)), Ny, r0, r1, fy);
+    if (r0 < kd.own_lo || r0 >= kd.own_hi) return make_double2(0.0, 0.0);       // another rank's rows
+    if (kd.rows >= 0 && (r1 < kd.row0 || r1 >= kd.row0 + kd.rows)) r1 = r0;
+    const double2 d = (kd.dtype == OC_F32) ? field_bilinear<float>(kd, step, r0, r1, c0, c1, fy, fx, Nx, Ny)
+                                           : field_bilinear<double>(kd, step, r0, r1, c0, c1, fy, fx, Nx, Ny);
+    return make_double2(vdes * d.x, vdes * d.y);
+}
+
 // des = v_des * choose_optimal_velocity(pos, step)  (optimals.py:212-250, simulations.py:281)
 __device__ __forceinline__ double2 lookup(const GcfmParams& P, const KeyDev& kd, double x, double y, double vdes,
                                           int step, int agent, int32_t* err) {
     if (step >= kd.nt_opt - 1) return make_double2(0.0, 0.0);
+    if (P.fix & OC_FIX_LOOKUP) return lookup_bilinear(P, kd, x, y, vdes, step);
     const int Nx = P.Nx, Ny = P.Ny;
     int j0, j1, i0, i1;
     if (x < P.L - P.dx) {
@@ -1040,11 +1091,13 @@ struct TileShare {              // which tiles this launch works on (the whole s
 // the tiles' i records are in LDS; every wavefront does its share of its tile's pair forces (pair_share); barrier 2,
 // the tiles' force sums are complete and go to f_pair.  128 registers and < 40 KB of LDS per block keep 4 blocks per
 // CU resident.
-template <int NS>
+// FIX = false: the OC_FIX_* corrections are compiled out (the default, bug-compatible kernel pays nothing for them)
+template <int NS, bool FIX>
 __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, int step,
                                                 const Axis X0, const Axis Y0, int nprep, TileShare sh,
                                                 int32_t* __restrict__ cnt_out) {
     __shared__ PairLds<NS> L;
+    if (!FIX) __builtin_assume(P.fix == 0u);        // (launch_step picks FIX = true whenever a bit is set)
     const Snap& C = S.snap;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if ((int)blockIdx.x < nprep) {
@@ -1279,6 +1332,7 @@ GcfmParams make_params(const oc_handle* h) {
         P.ncx = (int)(c.room_length / P.cell) + 1;
         P.ncy = (int)(c.room_height / P.cell) + 1;
     }
+    P.fix = h->fix_flags;
     P.horder = 1;
     while ((1 << P.horder) < std::max(P.ncx, P.ncy)) ++P.horder;
     P.drift = 1.5 * c.v_max * c.dt * h->resort_every + 0.1;
@@ -1444,7 +1498,7 @@ extern "C" int oc_wallmap_build(oc_handle* h, int key, const float* V, float vmi
                        (int32_t*)w.gap8);
     // cap: no per-agent search radius exceeds a(v_max)^2 + eta_w (1 + v_max) * 33 (wall_radius_of)
     double amax = c.a_min + c.tau_a * c.v_max;
-    w.edt_cap = amax * amax + c.eta_walls * (1.0 + c.v_max) * 33.0 + 1.0;
+    w.edt_cap = std::max(amax * amax, amax) + c.eta_walls * (1.0 + c.v_max) * 33.0 + 1.0;
     if (c.wall_search_radius > 0) w.edt_cap = std::max(w.edt_cap, c.wall_search_radius + 1.0);
     hipLaunchKernelGGL(k_edt_nodes, dim3((unsigned)(((size_t)c.Nx * c.Ny + 63) / 64)), dim3(64), 0, s, make_params(h),
                        (const int2*)w.left, (const int32_t*)w.gap8, axis_x(h), axis_y(h), w.edt_cap, (float*)w.right);
@@ -1552,7 +1606,8 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
     const KeyDev* kd = (const KeyDev*)h->key_tables_dev;
     const int ns = h->pair_split, tpb = 4 / ns, ntl = share.hi - share.lo;
     const int npair = (ntl + tpb - 1) / tpb, nprep = std::min(std::max(S.ntiles / 4, 1), h->prep_blocks);
-    auto kf = ns == 4 ? k_forces<4> : (ns == 2 ? k_forces<2> : k_forces<1>);
+    auto kf = P.fix ? (ns == 4 ? k_forces<4, true> : (ns == 2 ? k_forces<2, true> : k_forces<1, true>))
+                    : (ns == 4 ? k_forces<4, false> : (ns == 2 ? k_forces<2, false> : k_forces<1, false>));
     oc_timer_begin(h, "gcfm_forces", s);
     hipLaunchKernelGGL(kf, dim3(nprep + npair), dim3(256), 0, s, P, S, kd, simu_step, axis_x(h), axis_y(h), nprep, share,
                        A.cnt_out);

@@ -80,6 +80,7 @@ extern "C" int oc_destroy(oc_handle* h) {
     (void)hipFree(h->rect_tab_dev);
     (void)hipFree(h->gcfm_buf);
     (void)hipFree(h->sort_tmp);
+    (void)hipFree(h->dens_buf);
     for (auto& kv : h->timers)
         for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
     delete h;
@@ -217,6 +218,14 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
         oc_set_error("oc_set_tuning: unknown knob '%s'", name);
         return OC_ERR_ARG;
     }
+    return OC_OK;
+}
+
+extern "C" int oc_set_fix_flags(oc_handle* h, uint32_t flags) {
+    OC_REQUIRE(h, "null handle");
+    OC_REQUIRE((flags & ~(uint32_t)OC_FIX_ALL) == 0, "unknown OC_FIX_* bit");
+    h->fix_flags = flags;
+    h->packed_valid = false;        // (the per-agent wall search radius depends on OC_FIX_WALL_FORCE)
     return OC_OK;
 }
 

@@ -99,6 +99,9 @@ struct oc_handle {
     size_t gcfm_bytes = 0;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    void* dens_buf = nullptr;   // scratch of oc_density (density.hip)
+    size_t dens_bytes = 0;
+    uint32_t fix_flags = 0;     // OC_FIX_* (oc_set_fix_flags): 0 = bug-compatible with the reference
     // ---- profiling
     bool profiling = false;
     int prof_mode = 0;

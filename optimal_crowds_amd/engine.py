@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import OC_F32, OC_F64, OcAgents, OcConfig, OcHjbStats, check
+from ._lib import FIX_BITS, OC_F32, OC_F64, OcAgents, OcConfig, OcHjbStats, check
 
 LIM = 10e-3          # reference optimals.py:95
 
@@ -105,6 +105,17 @@ class Engine:
     def set_tuning(self, name, value):
         """Launch-shape knobs of the step kernels (oc_hip.h: oc_set_tuning)."""
         check(self.lib.oc_set_tuning(self.h, name.encode(), int(value)))
+
+    def set_fix_flags(self, names):
+        """Opt-in corrections of reference quirks: an iterable of 'lookup', 'wall_force', 'pair_force',
+        'density_norm' (oc_hip.h: OC_FIX_*).  Empty = the reference's behaviour (default)."""
+        mask = 0
+        for n in names:
+            if n not in FIX_BITS:
+                raise ValueError("unknown fix %r (known: %s)" % (n, ", ".join(sorted(FIX_BITS))))
+            mask |= FIX_BITS[n]
+        check(self.lib.oc_set_fix_flags(self.h, mask))
+        self.fix_flags = mask
 
     # ------------------------------------------------------------------ per-key data
     def set_potential(self, key, V_host, rects):

@@ -59,6 +59,7 @@ class optimals:
         self.t = 0.
         self.stats = None
         self._k = _key_index
+        self._fix_horizon = _sim is not None and "horizon" in getattr(_sim, "fixes", ())
         if _sim is not None:
             self._engine = _sim._engine
         else:
@@ -90,6 +91,8 @@ class optimals:
         """reference optimals.py:124-206.  m: (Ny,Nx) density (NumPy array or device tensor) or None/0."""
         self.t = t
         self.nt_opt = round((self.T - self.t) / self.dt)
+        if self._fix_horizon:       # Q9 corrected: always the full horizon, slice s = time s*dt (simulation(fixes=...))
+            self.nt_opt = round(self.T / self.dt)
         mt = None
         if m is not None and not np.isscalar(m):
             mt = m if torch.is_tensor(m) else torch.as_tensor(np.ascontiguousarray(m, dtype=np.float64))

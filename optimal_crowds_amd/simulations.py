@@ -59,8 +59,14 @@ class _History(dict):
 
 class simulation:
     def __init__(self, room, T, recompute=False, *, config=None, device="cuda:0", dtype="float32",
-                 noise=None, seed=20240807, history=None, record=None, wall_search_radius=None, sharding=None):
-        """sharding: None (one GPU) or a callable engine -> (halo_comm, step_comm), e.g. parallel.dist_sharding():
+                 noise=None, seed=20240807, history=None, record=None, wall_search_radius=None, sharding=None,
+                 fixes=()):
+        """fixes: opt-in corrections of reference quirks, default none = bug-compatible (SURVEY quirk register):
+        'lookup' (Q7/Q8: bilinear interpolation over the four nodes, no IndexError band), 'wall_force' and 'pair_force'
+        (Q12: unit vectors, q_i with its square root, no factor 3), 'density_norm' (Q11: 2 pi sigma^2), 'horizon' (Q9: a
+        recompute solves the full horizon again, so slice s keeps meaning time s*dt and the field does not go
+        stale from t = T/2 on); 'all' = every one of them.
+        sharding: None (one GPU) or a callable engine -> (halo_comm, step_comm), e.g. parallel.dist_sharding():
         this process is then one rank of a multi-GPU simulation with replicated agents (Engine.enable_sharding);
         every rank constructs the same simulation (same room, config, seed) and makes the same calls."""
         self.recompute = recompute
@@ -130,6 +136,11 @@ class simulation:
                               len(key_names), self.N, device=device, dtype=dtype,
                               wall_search_radius=wall_search_radius)
         eng = self._engine
+        fixes = {fixes} if isinstance(fixes, str) else set(fixes)
+        if "all" in fixes:
+            fixes = {"lookup", "wall_force", "pair_force", "density_norm", "horizon"}
+        self.fixes = frozenset(fixes)
+        eng.set_fix_flags(self.fixes - {"horizon"})
         if sharding is not None:
             eng.enable_sharding(*sharding(eng))
         self.targets = {}

@@ -303,11 +303,14 @@ class Optimals:
 
         _, self.stats = rk45_solve(lambda tt, yy: self.rhs(yy, m), self.T, 0.0, y0, t_eval, on_slice=on_slice)
 
-    def choose_optimal_velocity(self, pos, t):
-        """optimals.py:212-250 (Q7 diagonal pair, Q8 IndexError band, Q9 time guard)."""
+    def choose_optimal_velocity(self, pos, t, fixed=False):
+        """optimals.py:212-250 (Q7 diagonal pair, Q8 IndexError band, Q9 time guard).  fixed=True: the corrected
+        lookup (fix flag 'lookup'), lookup_bilinear below."""
         x, y = pos
         if t >= self.nt_opt - 1:
             return np.array((0., 0.))
+        if fixed:
+            return lookup_bilinear(self.vx_opt[t], self.vy_opt[t], x, y, self.room_length, self.room_height)
         if x < self.room_length - self.dx:
             j = int(x // self.dx)
             if x > self.dx:
@@ -321,6 +324,33 @@ class Optimals:
         else:
             i = self.Ny - 3
         return np.array((np.mean(self.vx_opt[t][i, j]), np.mean(self.vy_opt[t][i, j])))
+
+
+def lookup_bilinear(vx_int, vy_int, x, y, room_length, room_height):
+    """Fix flag 'lookup' (Q7/Q8 corrected; no reference lines -- this is what optimals.py:234-248 intends): bilinear
+    interpolation of the direction field over the four grid NODES around (x, y).  vx_int, vy_int: one slice, the
+    reference's interior arrays (Ny-2, Nx-2), whose element [i, j] belongs to node (i+1, j+1) at
+    (X0[j+1], Y0[i+1]) = ((j+1) L/(Nx-1), (i+1) H/(Ny-1)).  Positions outside the interior nodes are clamped."""
+    Ny, Nx = vx_int.shape[0] + 2, vx_int.shape[1] + 2
+
+    def split(g, n):
+        fl = np.floor(g)
+        if not fl >= 1.0:
+            fl, g = 1.0, 1.0
+        if fl >= n - 2:
+            fl = float(n - 2)
+            g = fl
+        i0 = int(fl)
+        return i0, min(i0 + 1, n - 2), g - fl
+
+    c0, c1, fx = split(x / (room_length / (Nx - 1)), Nx)
+    r0, r1, fy = split(y / (room_height / (Ny - 1)), Ny)
+    w00, w01, w10, w11 = (1 - fy) * (1 - fx), (1 - fy) * fx, fy * (1 - fx), fy * fx
+    out = []
+    for f in (vx_int, vy_int):
+        out.append(w00 * float(f[r0 - 1, c0 - 1]) + w01 * float(f[r0 - 1, c1 - 1]) + w10 * float(f[r1 - 1, c0 - 1])
+                   + w11 * float(f[r1 - 1, c1 - 1]))
+    return np.array(out)
 
 
 def lookup_indices(x, y, room_length, room_height, dx, dy, Nx, Ny):
@@ -352,8 +382,9 @@ def lookup_indices(x, y, room_length, room_height, dx, dy, Nx, Ny):
 # ------------------------------------------------------------------------------------------
 # GCFM forces (pedestrians.py:216-334), vectorised over pairs / agents, same formulas
 # ------------------------------------------------------------------------------------------
-def pair_force(pi, vi, vdes_i, pj, vj, cfg):
-    """Repulsion of j on i (pedestrians.py:216-280).  All inputs (..., 2) / (...,) broadcastable."""
+def pair_force(pi, vi, vdes_i, pj, vj, cfg, unit=False):
+    """Repulsion of j on i (pedestrians.py:216-280).  All inputs (..., 2) / (...,) broadcastable.
+    unit=True: fix flag 'pair_force' (Q12 corrected): -rep * e along the unit vector instead of -rep * R."""
     a_min = cfg["b_min"]            # Q5: a_min is b_min (simulations.py:88, pedestrians.py:74)
     tau, b_min, b_max, eta = cfg["tau_a"], cfg["b_min"], cfg["b_max"], cfg["eta"]
     pi, vi, pj, vj = (np.asarray(a, dtype=float) for a in (pi, vi, pj, vj))
@@ -380,7 +411,7 @@ def pair_force(pi, vi, vdes_i, pj, vj, cfg):
         q_j = np.sqrt(1 / ((np.cos(al_j - be_j) / a_j) ** 2 + (np.sin(al_j - be_j) / b_j) ** 2))
         dist = r - q_i - q_j
         rep = np.minimum(k * np.exp(-dist / (eta * (1 + v_rel))), 1)
-        return -rep[..., None] * R
+        return -rep[..., None] * (e if unit else R)
 
 
 def nearest_wall_index_bruteforce(px, py, X, Y, V):
@@ -438,8 +469,9 @@ class WallMap:
         return bi
 
 
-def wall_force(p, v, vdes, X, Y, V, cfg, index=None):
-    """pedestrians.py:282-334 for one agent; `index` may carry a precomputed nearest-cell index."""
+def wall_force(p, v, vdes, X, Y, V, cfg, index=None, fixed=False):
+    """pedestrians.py:282-334 for one agent; `index` may carry a precomputed nearest-cell index.
+    fixed=True: fix flag 'wall_force' (Q12 corrected): q_i with its square root, -rep * e, no factor 3."""
     a_min = cfg["b_min"]
     tau, b_min, b_max, eta_w = cfg["tau_a"], cfg["b_min"], cfg["b_max"], cfg["eta_walls"]
     if index is None:
@@ -457,15 +489,20 @@ def wall_force(p, v, vdes, X, Y, V, cfg, index=None):
         a_i = a_min + tau * s
         b_i = b_max - (b_max - b_min) * np.minimum(s / vdes, 1)
         q_i = 1 / ((np.cos(al - be) / a_i) ** 2 + (np.sin(al - be) / b_i) ** 2)    # Q12: no sqrt
+        if fixed:
+            q_i = np.sqrt(q_i)
         dist = r - q_i
         rep = np.minimum(np.exp(-dist / (eta_w * (1 + v_rel))), 1)
+        if fixed:
+            return -rep * e
         return -3 * rep * R
 
 
-def gaussian_density(x, y, status, X, Y, V_all, sigma):
-    """simulations.py:453-487 (Q11 normaliser 2*pi*sigma; mask where every key has a wall)."""
+def gaussian_density(x, y, status, X, Y, V_all, sigma, fixed_norm=False):
+    """simulations.py:453-487 (Q11 normaliser 2*pi*sigma; mask where every key has a wall).
+    fixed_norm=True: fix flag 'density_norm', C = 2*pi*sigma^2."""
     d = np.zeros(X.shape)
-    C = np.sqrt(4 * np.pi ** 2 * sigma ** 2)
+    C = 2 * np.pi * sigma ** 2 if fixed_norm else np.sqrt(4 * np.pi ** 2 * sigma ** 2)
     for k in range(len(x)):
         if status[k]:
             d += np.exp(-((X - x[k]) ** 2 + (Y - y[k]) ** 2) / (2 * sigma ** 2)) / C
@@ -515,7 +552,10 @@ class Simulation:
     permutation, consuming np.random exactly like it); mode='synchronous' is the frozen-snapshot
     (Jacobi) update the GPU implements, with the SAME permutation-ordered noise assignment."""
 
-    def __init__(self, room, T, recompute=False, cfg=None, mode="sequential", fast_wall=True):
+    def __init__(self, room, T, recompute=False, cfg=None, mode="sequential", fast_wall=True, fixes=()):
+        """fixes: subset of {'lookup', 'wall_force', 'pair_force', 'density_norm', 'horizon'} -- the opt-in
+        corrections of the product (oc_hip.h OC_FIX_*), restated here so that they too have a checker."""
+        self.fixes = frozenset(fixes)
         self.cfg = cfg = dict(DEFAULT_CONFIG if cfg is None else cfg)
         self.room = room if isinstance(room, dict) else json.load(open(room))
         room = self.room
@@ -561,7 +601,8 @@ class Simulation:
     def _forces(self, i, x, y, vx, vy, status):
         key = self.key_names[self.key[i]]
         pos = np.array((x[i], y[i]))
-        des = self.v_des[i] * self.targets[key].choose_optimal_velocity(pos, self.simu_step)
+        des = self.v_des[i] * self.targets[key].choose_optimal_velocity(pos, self.simu_step,
+                                                                        fixed="lookup" in self.fixes)
         dist = np.sqrt((x - x[i]) ** 2 + (y - y[i]) ** 2)
         sel = status & (dist < self.cfg["repulsion_cutoff"])
         sel[i] = False
@@ -569,11 +610,13 @@ class Simulation:
         rep = np.array((0., 0.))
         if len(js):
             f = pair_force(pos, np.array((vx[i], vy[i])), self.v_des[i],
-                           np.column_stack([x[js], y[js]]), np.column_stack([vx[js], vy[js]]), self.cfg)
+                           np.column_stack([x[js], y[js]]), np.column_stack([vx[js], vy[js]]), self.cfg,
+                           unit="pair_force" in self.fixes)
             for row in f:                      # ascending j, sequential fp64 sum (Q20)
                 rep = rep + row
         idx = self.wallmaps[key].query(x[i], y[i]) if self.fast_wall else None
-        wall = wall_force(pos, np.array((vx[i], vy[i])), self.v_des[i], self.X, self.Y, self.Vs[key], self.cfg, idx)
+        wall = wall_force(pos, np.array((vx[i], vy[i])), self.v_des[i], self.X, self.Y, self.Vs[key], self.cfg, idx,
+                          fixed="wall_force" in self.fixes)
         return des, rep, wall
 
     def _advance(self, i, des, rep, wall, noise, x, y, vx, vy):
@@ -632,12 +675,14 @@ class Simulation:
 
     def density(self, sigma=None):
         sigma = self.cfg["sigma_convolution"] if sigma is None else sigma
-        return gaussian_density(self.x, self.y, self.status, self.X, self.Y, self.V, sigma)
+        return gaussian_density(self.x, self.y, self.status, self.X, self.Y, self.V, sigma,
+                                fixed_norm="density_norm" in self.fixes)
 
     def solve_all(self):
         m = self.density() * (self.simu_step > 0)
         for k in self.key_names:
-            self.targets[k].compute_optimal_velocity(self.time, m)
+            # 'horizon' (Q9 corrected): every solve covers the full horizon, slice s = time s*dt
+            self.targets[k].compute_optimal_velocity(0.0 if "horizon" in self.fixes else self.time, m)
 
     def run(self, on_step=None):
         """simulations.py:401-451 (without history/plots; on_step(sim) is called where write_history is)."""
