@@ -141,6 +141,15 @@ int oc_set_field_rows(oc_handle* h, int key, int dtype, const void* vx, const vo
                       int32_t nt_opt, int32_t row0, int32_t rows, int32_t own_lo, int32_t own_hi);
 /* Exit rectangles (cx,cy,w,h) of a key's possible targets: pedestrians.py:132-136. rects: HOST (n,4) float64. */
 int oc_set_key_targets(oc_handle* h, int key, const double* rects, int32_t n);
+/* Room description -> potential on the grid: replaces simulation.create_potential (simulations.py:516-576) and, with
+ * finalise != 0, the in-place finalisation of optimals.__init__ (optimals.py:89-91).  Shapes are HOST float64 arrays in
+ * the room file's own form: walls / holes / targets (n,4) = (cx, cy, width, height), cylinders (n,3) = (cx, cy, radius);
+ * targets = the rectangles of THIS key's targets.  V_out: float32 device (Ny,Nx), bit-identical to the reference's
+ * array (values -k, 0, 1; or wall_potential, 0, target_potential when finalised). */
+int oc_rasterise_potential(oc_handle* h, const double* walls, int32_t n_walls, const double* holes, int32_t n_holes,
+                           const double* cylinders, int32_t n_cyl, const double* targets, int32_t n_targets,
+                           double wall_potential, double target_potential, int32_t finalise, float* V_out,
+                           void* stream);
 /* Nearest-"wall"-cell structure of Vs[key] for pedestrians.py:311-315.  V: float32 device (Ny,Nx);
  * vmin = min(V) (host value): cells with V == vmin are the candidate set of the reference's argmin. */
 int oc_wallmap_build(oc_handle* h, int key, const float* V, float vmin, void* stream);

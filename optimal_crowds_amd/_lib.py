@@ -108,6 +108,9 @@ SIGNATURES = {
     "oc_set_hjb_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "oc_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "oc_set_fix_flags": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "oc_rasterise_potential": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_void_p,
+                                         C.c_void_p]),
 }
 
 _lib = None

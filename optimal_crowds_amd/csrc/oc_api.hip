@@ -81,6 +81,7 @@ extern "C" int oc_destroy(oc_handle* h) {
     (void)hipFree(h->gcfm_buf);
     (void)hipFree(h->sort_tmp);
     (void)hipFree(h->dens_buf);
+    (void)hipFree(h->shape_buf);
     for (auto& kv : h->timers)
         for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
     delete h;

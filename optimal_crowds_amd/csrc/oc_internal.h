@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include <map>
@@ -99,6 +100,8 @@ struct oc_handle {
     size_t gcfm_bytes = 0;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    void* shape_buf = nullptr;  // room shapes of oc_rasterise_potential (raster.hip)
+    size_t shape_bytes = 0;
     void* dens_buf = nullptr;   // scratch of oc_density (density.hip)
     size_t dens_bytes = 0;
     uint32_t fix_flags = 0;     // OC_FIX_* (oc_set_fix_flags): 0 = bug-compatible with the reference

@@ -118,11 +118,33 @@ class Engine:
         self.fix_flags = mask
 
     # ------------------------------------------------------------------ per-key data
+    def rasterise_potential(self, room, targets, wall_potential, target_potential, finalise=True):
+        """Room dict -> potential of the key whose targets are `targets`, rasterised on the device
+        (oc_rasterise_potential: reference simulations.py:516-576 + optimals.py:89-91).  float32 (Ny,Nx) tensor."""
+        def arr(items, w):
+            a = np.ascontiguousarray(np.array(list(items), dtype=np.float64).reshape(-1, w))
+            return a, (a.ctypes.data_as(C.c_void_p) if len(a) else None), len(a)
+        walls = arr(room["walls"].values(), 4)
+        holes = arr(room["holes"].values(), 4)
+        cyls = arr(room["cylinders"].values(), 3)
+        tg = arr([room["targets"][t] for t in targets], 4)
+        out = torch.empty((self.Ny, self.Nx), dtype=torch.float32, device=self.device)
+        check(self.lib.oc_rasterise_potential(self.h, walls[1], walls[2], holes[1], holes[2], cyls[1], cyls[2], tg[1], tg[2],
+                                              float(wall_potential), float(target_potential), int(bool(finalise)),
+                                              _ptr(out), self.stream()))
+        return out
+
     def set_potential(self, key, V_host, rects):
-        """V_host: finalised potential (Ny,Nx) float64 of key; rects: (n,4) exit rectangles of its targets."""
-        Vt = torch.as_tensor(np.ascontiguousarray(V_host, dtype=np.float32)).to(self.device)
+        """V_host: finalised potential (Ny,Nx) of key -- a NumPy array, or a float32 device tensor (rasterise_potential);
+        rects: (n,4) exit rectangles of its targets."""
+        if torch.is_tensor(V_host):
+            Vt = V_host.to(device=self.device, dtype=torch.float32).contiguous()
+            vmin = float(Vt.min().item())
+        else:
+            Vt = torch.as_tensor(np.ascontiguousarray(V_host, dtype=np.float32)).to(self.device)
+            vmin = float(V_host.min())
         self.V[key] = Vt
-        check(self.lib.oc_wallmap_build(self.h, key, _ptr(Vt), C.c_float(float(V_host.min())), self.stream()))
+        check(self.lib.oc_wallmap_build(self.h, key, _ptr(Vt), C.c_float(vmin), self.stream()))
         r = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
         check(self.lib.oc_set_key_targets(self.h, key, r.ctypes.data_as(C.c_void_p), len(r)))
 

@@ -54,11 +54,14 @@ class optimals:
         self.T = T
         self.nt_opt = round(self.T / self.dt)
         self.target = target
-        self.V = host.finalize_potential(V, var_config)      # in place, like the reference (optimals.py:89-91)
+        # in place, like the reference (optimals.py:89-91); V is None when the simulation rasterised the room on the
+        # device (already finalised there): the attribute is then the simulation's lazily downloaded array
+        self._V = host.finalize_potential(V, var_config) if V is not None else None
         self.lim = 10e-3
         self.t = 0.
         self.stats = None
         self._k = _key_index
+        self._sim = _sim
         self._fix_horizon = _sim is not None and "horizon" in getattr(_sim, "fixes", ())
         if _sim is not None:
             self._engine = _sim._engine
@@ -70,6 +73,10 @@ class optimals:
                              dtype=np.float64).reshape(-1, 4)
             self._engine.set_potential(0, self.V, rects)
             self._engine.alloc_field(0, self.nt_opt - 1)
+
+    @property
+    def V(self):
+        return self._V if self._V is not None else self._sim.Vs[self.target]
 
     @property
     def X_opt(self):

@@ -57,11 +57,42 @@ class _History(dict):
         return [(k, self[k]) for k in self.keys()]
 
 
+class _LazyPotentials(dict):
+    """Vs[key] -> (Ny,Nx) float64 array like the reference's; with device rasterisation the array is downloaded from
+    the GPU the first time somebody asks for it."""
+
+    def __init__(self):
+        super().__init__()
+        self._dev = {}
+
+    def _set_dev(self, key, tensor):
+        self._dev[key] = tensor
+        dict.__setitem__(self, key, None)
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if v is None:
+            v = self._dev[key].double().cpu().numpy()
+            dict.__setitem__(self, key, v)
+        return v
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
+RASTER_DEVICE_MIN_CELLS = 1 << 22      # 2048 x 2048 and larger: rasterise the room on the device
+
+
 class simulation:
     def __init__(self, room, T, recompute=False, *, config=None, device="cuda:0", dtype="float32",
                  noise=None, seed=20240807, history=None, record=None, wall_search_radius=None, sharding=None,
-                 fixes=()):
-        """fixes: opt-in corrections of reference quirks, default none = bug-compatible (SURVEY quirk register):
+                 fixes=(), rasterise=None):
+        """rasterise: 'host' (NumPy, like the reference), 'device' (oc_rasterise_potential, bit-identical; Vs[key] and
+        V become lazily downloaded arrays) or None = 'device' from 2048 x 2048 grid nodes on.
+        fixes: opt-in corrections of reference quirks, default none = bug-compatible (SURVEY quirk register):
         'lookup' (Q7/Q8: bilinear interpolation over the four nodes, no IndexError band), 'wall_force' and 'pair_force'
         (Q12: unit vectors, q_i with its square root, no factor 3), 'density_norm' (Q11: 2 pi sigma^2), 'horizon' (Q9: a
         recompute solves the full horizon again, so slice s keeps meaning time s*dt and the field does not go
@@ -98,26 +129,20 @@ class simulation:
         self.v_max = var_config["v_max"]
         self.recompute_step = var_config["recompute_frequency"]
 
-        # ---- potentials, keys and the crowd (reference simulations.py:104-160)
-        self.Vs = {}
-        self.V = np.zeros((self.Ny, self.Nx)) + 1
+        # ---- keys and the crowd (reference simulations.py:104-160; the sampler never looks at the potentials, Q16)
         self.place_ped = np.zeros((self.Ny, self.Nx))
-        key_names, xs, ys, vd, kk = [], [], [], [], []
+        key_names, xs, ys, vd, kk, box_keys = [], [], [], [], [], []
         self._possible = {}
         for box in var_room["initial_boxes"].values():
             targets = box[5:]
             key = " or ".join(targets)
-            V = host.create_potential(var_room, targets, self._X0, self._Y0)
-            host.finalize_potential(V, var_config)       # what optimals.__init__ does to the caller's array
-            self.Vs[key] = V
             if key not in key_names:
                 key_names.append(key)
             self._possible[key] = targets
-            self.V += V
+            box_keys.append(key)
             bx, by, bv = host.sample_box(box, self._X0, self._Y0, self.place_ped)
             xs.append(bx), ys.append(by), vd.append(bv)
             kk.append(np.full(len(bx), key_names.index(key), dtype=np.int32))
-        self.V[self.V > np.min(self.V)] = 0
         cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
         x0, y0 = cat(xs, float), cat(ys, float)
         self._v_des = cat(vd, float)
@@ -136,6 +161,32 @@ class simulation:
                               len(key_names), self.N, device=device, dtype=dtype,
                               wall_search_radius=wall_search_radius)
         eng = self._engine
+        # ---- potentials (reference simulations.py:104-121, 516-576; finalised like optimals.__init__ does, Q3)
+        if rasterise is None:
+            rasterise = "device" if self.Nx * self.Ny >= RASTER_DEVICE_MIN_CELLS else "host"
+        if rasterise not in ("host", "device"):
+            raise ValueError("rasterise must be 'host', 'device' or None")
+        self._raster_dev = rasterise == "device"
+        self.Vs = _LazyPotentials()
+        hp = var_config["hjb_params"]
+        if self._raster_dev:
+            for key in key_names:
+                self.Vs._set_dev(key, eng.rasterise_potential(var_room, self._possible[key], hp["wall_potential"],
+                                                              hp["target_potential"]))
+            V_all = torch.ones((self.Ny, self.Nx), dtype=torch.float32, device=eng.device)
+            for key in box_keys:                        # one term per BOX, like the reference's loop
+                V_all += self.Vs._dev[key]
+            V_all[V_all > V_all.min()] = 0
+            self._V_all_dev, self._V_host = V_all, None
+        else:
+            self._V_host = np.zeros((self.Ny, self.Nx)) + 1
+            for key in box_keys:
+                if key not in self.Vs:
+                    V = host.create_potential(var_room, self._possible[key], self._X0, self._Y0)
+                    self.Vs[key] = host.finalize_potential(V, var_config)
+                self._V_host += self.Vs[key]
+            self._V_host[self._V_host > np.min(self._V_host)] = 0
+            self._V_all_dev = torch.as_tensor(self._V_host.astype(np.float32)).to(eng.device)
         fixes = {fixes} if isinstance(fixes, str) else set(fixes)
         if "all" in fixes:
             fixes = {"lookup", "wall_force", "pair_force", "density_norm", "horizon"}
@@ -146,11 +197,11 @@ class simulation:
         self.targets = {}
         for k, key in enumerate(key_names):
             rects = np.array([var_room["targets"][t] for t in self._possible[key]], dtype=np.float64)
-            eng.set_potential(k, self.Vs[key], rects)
+            eng.set_potential(k, self.Vs._dev[key] if self._raster_dev else self.Vs[key], rects)
             eng.alloc_field(k, nt0 - 1)
-            self.targets[key] = optimals_mod.optimals(room, self.Vs[key], T, key, _sim=self, _key_index=k)
+            self.targets[key] = optimals_mod.optimals(room, None if self._raster_dev else self.Vs[key], T, key,
+                                                      _sim=self, _key_index=k)
         eng.set_agents(x0, y0, np.zeros(self.N), np.zeros(self.N), self._v_des, self._key_of)
-        self._V_all_dev = torch.as_tensor(self.V.astype(np.float32)).to(eng.device)
         self._noise_mode = noise or ("host" if self.N <= HOST_NOISE_MAX_AGENTS else "device")
         self._seed = seed
         self._status_host = np.ones(self.N, dtype=bool)
@@ -168,6 +219,18 @@ class simulation:
         print('ABM simulation room created!')
 
     # ------------------------------------------------------------------ reference attributes
+    @property
+    def V(self):
+        """1 + sum of the boxes' potentials, everything above the minimum set to 0 (reference simulations.py:119-121)"""
+        if self._V_host is None:
+            self._V_host = self._V_all_dev.double().cpu().numpy()
+        return self._V_host
+
+    @V.setter
+    def V(self, value):
+        self._V_host = np.asarray(value, dtype=float)
+        self._V_all_dev = torch.as_tensor(self._V_host.astype(np.float32)).to(self._engine.device)
+
     @property
     def X_opt(self):
         return np.meshgrid(self._X0, self._Y0)[0]
