@@ -188,8 +188,8 @@ def pmc_traffic(workload):
     return None
 
 
-def pmc_valu(workload):
-    """Wave-level VALU instructions per k_forces launch from the committed SQ-counter summary
+def pmc_valu(workload, counter="SQ_INSTS_VALU"):
+    """A per-launch SQ counter of k_forces (default: wave-level VALU instructions) from the committed summary
     (profiles/rNN_pmc_step_kernels.txt, tools/pmc_step.sh: rocprofv3 --pmc passes of this very command); None if
     absent or for another workload."""
     import glob
@@ -200,7 +200,8 @@ def pmc_valu(workload):
         try:
             txt = open(f).read()
             blk = txt[txt.index("k_forces"):]
-            m = re.search(r"SQ_INSTS_VALU\s+n=\d+\s+mean=([0-9.e+]+)", blk)
+            blk = blk[:blk.index("k_finish")] if "k_finish" in blk else blk
+            m = re.search(counter + r"\s+n=\d+\s+mean=([0-9.e+]+)", blk)
             if m:
                 return float(m.group(1))
         except Exception:
@@ -329,6 +330,16 @@ def main():
                                    "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
                                    "frac": ach / peak, "valu_instructions_per_launch": nv,
                                    "avg_launch_ms": kf["avg_ms"], "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/)"}
+        wc, bc, nw = (pmc_valu(args.workload, c) for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES"))
+        if wc and bc and nw:
+            # SQ_WAVE_CYCLES counts quad-cycles summed over the waves; SQ_BUSY_CYCLES is summed over the chip's 32
+            # shader engines (8 XCDs x 4), so busy/32 is the launch's length in shader cycles
+            resident = 4.0 * wc / (bc / 32.0)
+            result["roofline_valu"]["occupancy"] = {
+                "waves_per_simd_allowed_by_registers": 4, "waves_per_simd_hardware": 8,
+                "mean_resident_waves_per_simd": resident / 1024.0, "waves_per_launch": nw,
+                "mean_wave_lifetime_us": 4.0 * wc / nw / (bc / 32.0) * kf["avg_ms"] * 1e3,
+                "source": "SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAVES (profiles/)"}
     if rank == 0 and kf.get("avg_ms") and not args.no_work_count:
         result["breakdown"]["gcfm_work"] = gcfm_work(sim, cfg, kf["avg_ms"] * 1e-3,
                                                      result["breakdown"]["gcfm_ms_per_step"] * 1e-3)
