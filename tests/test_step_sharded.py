@@ -42,8 +42,12 @@ def _state(room, nkeys, n=6000, seed=5):
     return x, y, vx, vy, vdes, key, status
 
 
-def _new(room_name):
+FIXES = ("lookup", "wall_force", "pair_force")          # the opt-in corrections (oc_set_fix_flags) shard the same way
+
+
+def _new(room_name, fixes=()):
     eng, room, cfg, X0, Y0 = _engine(room_name, "float32", n_keys=2, max_agents=8192, cfg=_big(), wall_search_radius=0.0)
+    eng.set_fix_flags(fixes)
     names, Vs = _potentials(room, cfg, X0, Y0)
     for k, name in enumerate(names):
         eng.set_potential(k, Vs[k], _rects(room, name))
@@ -70,8 +74,8 @@ def _run_ranks(world, body):
     return out
 
 
-def _reference(room_name, state, noise, steps):
-    eng, room, cfg, names = _new(room_name)
+def _reference(room_name, state, noise, steps, fixes=()):
+    eng, room, cfg, names = _new(room_name, fixes)
     for k in range(len(names)):
         eng.alloc_field(k, NT - 1)
         eng.solve(k, T, NT)
@@ -84,18 +88,18 @@ def _reference(room_name, state, noise, steps):
     return st, outs
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_step_with_replicated_fields(world):
+@pytest.mark.parametrize("world,fixes", [(1, ()), (2, ()), (3, ()), (2, FIXES)])
+def test_sharded_step_with_replicated_fields(world, fixes):
     from optimal_crowds_amd import parallel
     room = room_library.ROOMS["exit_opposite"]()
     state = _state(room, 2)
     n = len(state[0])
     steps = 4
     noise = np.random.RandomState(1).normal(size=(steps, n, 2))
-    ref, ref_out = _reference("exit_opposite", state, noise, steps)
+    ref, ref_out = _reference("exit_opposite", state, noise, steps, fixes)
 
     def body(rank, tw):
-        eng, room_, cfg, names = _new("exit_opposite")
+        eng, room_, cfg, names = _new("exit_opposite", fixes)
         for k in range(len(names)):
             eng.alloc_field(k, NT - 1)
             eng.solve(k, T, NT)                      # every rank holds the whole field: the tile's owner looks up
@@ -119,7 +123,8 @@ def test_sharded_step_with_replicated_fields(world):
             assert np.abs(st[f] - ref[f]).max() <= 1e-11, f
 
 
-def test_sharded_step_with_row_block_fields():
+@pytest.mark.parametrize("fixes", [(), FIXES])
+def test_sharded_step_with_row_block_fields(fixes):
     """The direction field domain-decomposed by rows (oc_hjb_solve_rows -> oc_set_field_rows): a lookup is answered by
     the rank that owns the first cell's row.  Against the single-GPU run: the two solves differ by float32 round-off in
     the step controller's error sums (test_hjb_rows), so the desired velocities agree to 1e-4 on all but a few cells at
@@ -132,10 +137,10 @@ def test_sharded_step_with_row_block_fields():
     n = len(state[0])
     steps = 3
     noise = np.random.RandomState(2).normal(size=(steps, n, 2))
-    ref, ref_out = _reference("exit_opposite", state, noise, steps)
+    ref, ref_out = _reference("exit_opposite", state, noise, steps, fixes)
 
     def body(rank, tw):
-        eng, room_, cfg, names = _new("exit_opposite")
+        eng, room_, cfg, names = _new("exit_opposite", fixes)
         sh = parallel.RowShard(eng.Ny, rank, world, halo)
         hcomm = parallel.ThreadHaloComm(sh, eng.Nx, eng.tdtype, eng.device, tw)
         tw.barrier.wait(timeout=120)
