@@ -80,6 +80,7 @@ struct Snap {               // the packed snapshot
     float2* phead;
     int32_t* pidx;
     double4* tile_box;
+    double4* qbox;          // [4 * ntiles]: boxes of the tile's four quarters (records 16q .. 16q + 15)
 };
 
 struct PDK {                // per slot, fixed between re-sorts
@@ -124,6 +125,28 @@ __device__ __forceinline__ double wmax(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     return v;
+}
+// box of a tile's agents and of its four quarters (16 consecutive records: compact pieces of the Hilbert order).
+// px/py = +-inf pairs of the lane (an absent agent passes +inf, +inf, -inf, -inf).  Lanes 0, 16, 32, 48 store the
+// quarter boxes, lane 0 the tile box.
+__device__ __forceinline__ double4 tile_boxes(double lox, double loy, double hix, double hiy, int lane, int it,
+                                              double4* __restrict__ qbox) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        lox = fmin(lox, __shfl_xor(lox, o, 64));
+        loy = fmin(loy, __shfl_xor(loy, o, 64));
+        hix = fmax(hix, __shfl_xor(hix, o, 64));
+        hiy = fmax(hiy, __shfl_xor(hiy, o, 64));
+    }
+    if ((lane & 15) == 0) qbox[it * 4 + (lane >> 4)] = make_double4(lox, loy, hix, hiy);
+#pragma unroll
+    for (int o = 32; o > 8; o >>= 1) {
+        lox = fmin(lox, __shfl_xor(lox, o, 64));
+        loy = fmin(loy, __shfl_xor(loy, o, 64));
+        hix = fmax(hix, __shfl_xor(hix, o, 64));
+        hiy = fmax(hiy, __shfl_xor(hiy, o, 64));
+    }
+    return make_double4(lox, loy, hix, hiy);
 }
 
 // ---------------------------------------------------------------------------------- ordering
@@ -298,11 +321,11 @@ __global__ void __launch_bounds__(64) k_pack(const double* __restrict__ x, const
     }
     S.pvd[k] = make_double2(vxd, vyd);
     S.pdk[k] = dk;
-    double mnx = wmin(act ? px : INFINITY), mny = wmin(act ? py : INFINITY);
-    double mxx = wmax(act ? px : -INFINITY), mxy = wmax(act ? py : -INFINITY);
+    const double4 tb = tile_boxes(act ? px : INFINITY, act ? py : INFINITY, act ? px : -INFINITY, act ? py : -INFINITY,
+                                  threadIdx.x, blockIdx.x, C.qbox);
     if (threadIdx.x == 0) {
-        C.tile_box[blockIdx.x] = make_double4(mnx, mny, mxx, mxy);
-        S.tile_box0[blockIdx.x] = make_double4(mnx, mny, mxx, mxy);
+        C.tile_box[blockIdx.x] = tb;
+        S.tile_box0[blockIdx.x] = tb;
     }
 }
 
@@ -487,7 +510,14 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
         int t;
         if (use_list) t = (lane < nb_cnt) ? nb[1 + lane] : -1;
         else t = (ch * 64 + lane < S.ntiles) ? ch * 64 + lane : -1;
-        const bool hit = (t >= 0) && box_hit(bi, C.tile_box[t], c);
+        // this share only ever reads quarter(s) `sub` of a candidate tile: test that piece's own box (on a crowd at
+        // 2.4 agents/m^2 the quarters of the ~12.5 tiles within reach add up to ~9 tiles' worth of records)
+        bool hit = false;
+        if (t >= 0) {
+            if (NS == 4) hit = box_hit(bi, C.qbox[t * 4 + sub], c);
+            else if (NS == 2) hit = box_hit(bi, C.qbox[t * 4 + 2 * sub], c) || box_hit(bi, C.qbox[t * 4 + 2 * sub + 1], c);
+            else hit = box_hit(bi, C.tile_box[t], c);
+        }
         unsigned long long tmask = __ballot(hit);
         if (!tmask) continue;
         // next virtual tile: the NS lowest remaining hits; lane l fetches record j0 + l % NJ of hit l / NJ
@@ -1213,8 +1243,9 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     // would cost more than the rest of this kernel)
     const unsigned long long m_out = __ballot(out);
     // tile box of the new positions + validity of the neighbour lists
-    const double mnx = wmin(stay ? nx : INFINITY), mny = wmin(stay ? ny : INFINITY);
-    const double mxx = wmax(stay ? nx : -INFINITY), mxy = wmax(stay ? ny : -INFINITY);
+    const double4 tb = tile_boxes(stay ? nx : INFINITY, stay ? ny : INFINITY, stay ? nx : -INFINITY,
+                                  stay ? ny : -INFINITY, lane, it, C.qbox);
+    const double mnx = tb.x, mny = tb.y, mxx = tb.z, mxy = tb.w;
     if (lane == 0) {
         if (it == 0) {                              // IndexError-band flag raised by the lookups of k_forces
             const int e = err0;
@@ -1352,7 +1383,7 @@ int carve(oc_handle* h, int N, Scratch* S) {
     const size_t per_snap = sizeof(double2) + sizeof(float4) + sizeof(float2) + sizeof(int32_t);
     const size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + per_snap + sizeof(double2) + sizeof(PDK) +
                        3 * sizeof(double2) + sizeof(long long);
-    size_t need = per * (size_t)Np + (2 * sizeof(double4) + (NB_MAX + 3) * sizeof(int32_t)) * (size_t)nt + 64 + 16384;
+    size_t need = per * (size_t)Np + (6 * sizeof(double4) + (NB_MAX + 3) * sizeof(int32_t)) * (size_t)nt + 64 + 16384;
     if (need > h->gcfm_bytes) {
         if (h->gcfm_buf) OC_HIP_CHECK(hipFree(h->gcfm_buf));
         h->gcfm_buf = nullptr;
@@ -1373,6 +1404,7 @@ int carve(oc_handle* h, int N, Scratch* S) {
     S->snap.phead = (float2*)take(sizeof(float2) * Np);
     S->snap.pidx = (int32_t*)take(sizeof(int32_t) * Np);
     S->snap.tile_box = (double4*)take(sizeof(double4) * nt);
+    S->snap.qbox = (double4*)take(sizeof(double4) * 4 * nt);
     S->pvd = (double2*)take(sizeof(double2) * Np);
     S->pdk = (PDK*)take(sizeof(PDK) * Np);
     S->f_pair = (double2*)take(sizeof(double2) * Np);
