@@ -561,8 +561,12 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
             const float c2f = (float)c2 * 1.00001f + 1e-6f * ext * (ext + (float)c);
             const f2v nc2 = {-c2f, -c2f};
             int bself = -1;                                 // position of the i-tile itself in this virtual tile
+            int nfill = 0;                                  // real tiles in it (the last one of a chunk is partly padding)
 #pragma unroll
-            for (int b = 0; b < NS; ++b) bself = (jts[b] == it) ? b : bself;
+            for (int b = 0; b < NS; ++b) {
+                bself = (jts[b] == it) ? b : bself;
+                nfill += (jts[b] >= 0) ? 1 : 0;
+            }
             // ---- start loading the next virtual tile while this one is processed
             const bool more = tmask != 0ull;
             if (more) fetch();
@@ -574,18 +578,30 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
 #pragma unroll
             for (int h = 0; h < NW; ++h) {
                 uint32_t acc = 0u;
+                // the records of real tile b are 16*(4/NS)*b ..: pieces of the word that hold only padding are skipped
+                constexpr int PW = (NJ < WB) ? WB / NJ : 1;         // tile pieces per mask word
+                constexpr int GP = WB / 4 / PW;                     // groups of 4 records per piece
 #pragma unroll
-                for (int g = 0; g < WB / 4; ++g) {
-                    const float4 xs = *reinterpret_cast<const float4*>(&L.l_rx[w][32 * h + 4 * g]);
-                    const float4 ys = *reinterpret_cast<const float4*>(&L.l_ry[w][32 * h + 4 * g]);
-                    const f2v xa = {xs.x, xs.y}, xb = {xs.z, xs.w}, ya = {ys.x, ys.y}, yb = {ys.z, ys.w};
-                    const f2v dxa = xa - xi2, dxb = xb - xi2, dya = ya - yi2, dyb = yb - yi2;
-                    const f2v ta = __builtin_elementwise_fma(dxa, dxa, __builtin_elementwise_fma(dya, dya, nc2));
-                    const f2v tb = __builtin_elementwise_fma(dxb, dxb, __builtin_elementwise_fma(dyb, dyb, nc2));
-                    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(ta.x), 31);
-                    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(ta.y), 31);
-                    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(tb.x), 31);
-                    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(tb.y), 31);
+                for (int pc = 0; pc < PW; ++pc) {
+                    if ((32 * h + 4 * GP * pc) / NJ < nfill) {
+#pragma unroll
+                        for (int gg = 0; gg < GP; ++gg) {
+                            const int g = pc * GP + gg;
+                            const float4 xs = *reinterpret_cast<const float4*>(&L.l_rx[w][32 * h + 4 * g]);
+                            const float4 ys = *reinterpret_cast<const float4*>(&L.l_ry[w][32 * h + 4 * g]);
+                            const f2v xa = {xs.x, xs.y}, xb = {xs.z, xs.w}, ya = {ys.x, ys.y}, yb = {ys.z, ys.w};
+                            const f2v dxa = xa - xi2, dxb = xb - xi2, dya = ya - yi2, dyb = yb - yi2;
+                            const f2v ta = __builtin_elementwise_fma(dxa, dxa, __builtin_elementwise_fma(dya, dya, nc2));
+                            const f2v tb = __builtin_elementwise_fma(dxb, dxb, __builtin_elementwise_fma(dyb, dyb, nc2));
+                            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(ta.x), 31);
+                            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(ta.y), 31);
+                            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(tb.x), 31);
+                            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(tb.y), 31);
+                        }
+                    } else {
+                        acc <<= (4 * GP) & 31;                      // (PW == 1: the whole word, left as zero)
+                        if (PW == 1) acc = 0u;
+                    }
                 }
                 mw[h] = acc << (32 - WB);
             }
