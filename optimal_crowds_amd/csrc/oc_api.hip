@@ -215,6 +215,9 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     } else if (!strcmp(name, "prep_blocks")) {
         OC_REQUIRE(value >= 1 && value <= 65536, "prep_blocks out of range");
         h->prep_blocks = value;
+    } else if (!strcmp(name, "resort_every")) {
+        OC_REQUIRE(value >= 1 && value <= 4096, "resort_every out of range");
+        h->resort_every = value;
     } else {
         oc_set_error("oc_set_tuning: unknown knob '%s'", name);
         return OC_ERR_ARG;
@@ -232,6 +235,6 @@ extern "C" int oc_set_fix_flags(oc_handle* h, uint32_t flags) {
 
 extern "C" int oc_set_resort_every(oc_handle* h, int32_t steps) {
     OC_REQUIRE(h, "null handle");
-    h->resort_every = steps > 0 ? steps : 16;
+    h->resort_every = steps > 0 ? steps : 32;
     return OC_OK;
 }
