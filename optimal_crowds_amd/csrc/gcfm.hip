@@ -731,14 +731,23 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
 // the tie band.  An agent 12 m from a pillar marks 2-3 blocks in 2 rounds instead of walking ~240 rows.
 #define GAP_NONE (1 << 28)
 // lower bound on the squared distance to any candidate of 8-row block `blk`
+// (a BOUND, evaluated 16 times per round and agent: the rows' coordinates are taken as 8 blk h and 8 blk h + 7 h --
+// within an ulp of the axis values, and past the last row for the room's last block -- and 1 nm is given away instead
+// of selecting among exact axis values; the candidates themselves are measured on the exact axis)
 __device__ __forceinline__ double wall_block_bound(double py, int blk, int gap, bool prune_ok, int Ny, double hx,
                                                    const Axis Y0, double& dyb2) {
-    const int rlo = 8 * blk, rhi = min(rlo + 7, Ny - 1);
-    const double ylo = Y0[rlo], yhi = Y0[rhi];
-    const double dyb = (py < ylo) ? ylo - py : (py > yhi ? py - yhi : 0.0);
+    double ylo, yhi;
+    if (Y0.lin) {
+        ylo = (double)(8 * blk) * Y0.h;
+        yhi = ylo + 7.0 * Y0.h;
+    } else {                                    // a caller's own axis: its values
+        ylo = Y0.a[8 * blk];
+        yhi = Y0.a[min(8 * blk + 7, Ny - 1)];
+    }
+    const double dyb = fmax(fmax(ylo - py, py - yhi) - 1e-9, 0.0);
     // every candidate of the block: |dy| >= dyb, |dx| >= (gap - 1) hx (the agent sits within one cell of column jx)
-    const double lbh = prune_ok ? (double)max(gap - 1, 0) * hx * (1.0 - 1e-9) : 0.0;
-    dyb2 = dyb * dyb * (1.0 - 1e-12);
+    const double lbh = prune_ok ? (double)max(gap - 1, 0) * (hx * (1.0 - 1e-9)) : 0.0;
+    dyb2 = dyb * dyb;
     return dyb2 + lbh * lbh;
 }
 
