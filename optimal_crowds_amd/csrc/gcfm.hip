@@ -6,13 +6,15 @@
 // The library keeps a packed snapshot in SLOT order (agents sorted along a Hilbert curve over 2 m coarse cells; a
 // tile = 64 slots = one wavefront):
 //   ppos  double2 (x,y)      pvel  float4 (vx,vy,|v|,1/a^2)     phead float2 (unit heading, (1,0) if v=0)
-//   tile_box double4 (minx,miny,maxx,maxy) of a tile's active agents;  nb_list: tiles that can come within the
-//   cutoff before the next re-sort (boxes at sort time, cutoff + 2D margin; validity is re-checked every step)
+//   tile_box double4 (minx,miny,maxx,maxy) of a tile's active agents, qbox: the same for its four quarters (16
+//   consecutive records);  nb_list: tiles that can come within the cutoff before the next re-sort (boxes at sort
+//   time, cutoff + 2D margin; validity is re-checked every step)
 //   pvd double2 (float64 velocity), pdk (v_des, key): slot-ordered copies, so a step gathers nothing by agent index
 // One step = 2 launches:
 //   k_forces  blocks of 4 wavefronts.  PAIR blocks carry 4/NS tiles, NS wavefronts per tile sharing the tile's i
 //             records and float64 force sums in LDS; a wavefront takes its j-range of the candidate j-tiles (equal work
-//             per share), NS tiles at a time as one 64-record virtual j-tile: phase 1 builds per-lane candidate masks
+//             per share; candidates culled against the box of that j-range), NS tiles at a time as one 64-record
+//             virtual j-tile: phase 1 builds per-lane candidate masks
 //             with a conservative float32 test, the candidates are compacted into an LDS list (two per entry), phase 2
 //             walks the list: exact float64 cutoff decision (the reference's sqrt(dx^2+dy^2) < cutoff), packed float32
 //             force.  PREP blocks do what does not need the pair sums, one lane per agent: exact nearest-wall-cell
