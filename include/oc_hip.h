@@ -225,7 +225,8 @@ int oc_reset_kernel_stats(oc_handle* h);
 int oc_set_hjb_variant(oc_handle* h, int variant);
 /* Launch-shape knobs of the step kernels (results do not depend on them beyond float64 summation order):
  *   "pair_split"  1, 2 or 4 pair wavefronts per tile of 64 agents (default 4)
- *   "prep_blocks" blocks of the force kernel that do the wall search / field lookup of the tiles (default 256)
+ *   "prep_blocks" upper limit of the blocks of the force kernel that do the wall search / field lookup of the tiles
+ *                 (default 256; the launch uses the fewest blocks that give every prep wavefront the same tile count)
  *   "resort_every" same as oc_set_resort_every */
 int oc_set_tuning(oc_handle* h, const char* name, int value);
 
