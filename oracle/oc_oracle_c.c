@@ -260,3 +260,178 @@ void occ_step_sync(const occ_params* P, int N, int i0, int i1, const double* x, 
         }
     }
 }
+
+/* ---- the whole HJB solve: solve_ivp(hjb, (T, 0), ones, 'RK45', t_eval = linspace(T, 0, nt)), optimals.py:193-196, with
+ * SciPy 1.15.3's Dormand-Prince arithmetic restated: rk_step scipy rk.py:14-72, controller :111-176, tables :377-404,
+ * dense output :552-575, RMS norm common.py:63-66, initial step :68-134, reversed t_eval slicing ivp.py:598-616,706-723.
+ * Same algorithm as oracle/oc_oracle.py rk45_solve (which is pinned against SciPy itself and fixture G3); this copy exists
+ * so that a BASELINE-size grid (2048 x 2048) can be solved on the GPU box's host cores in about a minute.
+ *   keep_idx[n_keep] : t_eval indices k whose phi(t_eval[k]) goes to phi_keep (n_keep, Ny*Nx).
+ *   forced[n_forced] : optional.  forced[0] = T, then the end times of the steps to take: the controller is bypassed and
+ *                      every step is taken as given; err_out[s] receives the error norm the controller would have seen
+ *                      for step s (< 1 means "this solver would have accepted that step too").  Used to compare two
+ *                      adaptive solves on ONE step sequence, so that float32 error is separated from controller noise.
+ *   stats_out[4]     : nfev, attempts, accepted, (unused); t_steps[t_cap] accepted step end times (t_steps[0] = T). */
+static const double RKA[6][5] = {
+    {0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+static const double RKB[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+static const double RKE[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+static const double RKP[7][4] = {
+    {1, -8048581381.0 / 2820520608, 8663915743.0 / 2820520608, -12715105075.0 / 11282082432},
+    {0, 0, 0, 0},
+    {0, 131558114200.0 / 32700410799, -68118460800.0 / 10900136933, 87487479700.0 / 32700410799},
+    {0, -1754552775.0 / 470086768, 14199869525.0 / 1410260304, -10690763975.0 / 1880347072},
+    {0, 127303824393.0 / 49829197408, -318862633887.0 / 49829197408, 701980252875.0 / 199316789632},
+    {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
+    {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
+
+static double sumsq_scaled(const double* a, const double* b, const double* y, double atol, double rtol, size_t n) {
+    double s = 0.0;                                  /* sum ((a - b) / (atol + |y| rtol))^2, b may be NULL */
+#pragma omp parallel for schedule(static) reduction(+ : s)
+    for (size_t q = 0; q < n; ++q) {
+        const double v = (b ? a[q] - b[q] : a[q]) / (atol + fabs(y[q]) * rtol);
+        s += v * v;
+    }
+    return s;
+}
+
+int occ_rk45_solve(const occ_params* P, const double* V, const double* m, double T, int nt, double rtol, double atol,
+                   const int32_t* keep_idx, int n_keep, double* phi_keep, const double* forced, int n_forced,
+                   double* err_out, double* t_steps, int t_cap, int64_t* stats_out) {
+    const size_t n = (size_t)P->Ny * P->Nx;
+    double* buf = (double*)malloc(sizeof(double) * n * 10);
+    if (!buf) return -1;
+    double *y = buf, *ynew = buf + n, *ytmp = buf + 2 * n, *K[7];
+    for (int k = 0; k < 7; ++k) K[k] = buf + (3 + k) * n;
+    int64_t nfev = 0, n_att = 0, n_acc = 0;
+    for (size_t q = 0; q < n; ++q) y[q] = 1.0;
+    const double t0 = T, tf = 0.0, direction = -1.0;
+    double t = t0;
+    occ_hjb_rhs(P, y, V, m, K[6]);                   /* f0 in the FSAL slot */
+    ++nfev;
+    double h_abs;
+    {   /* select_initial_step, order 4 */
+        const double interval = fabs(tf - t0);
+        const double d0 = sqrt(sumsq_scaled(y, NULL, y, atol, rtol, n)) / sqrt((double)n);
+        const double d1 = sqrt(sumsq_scaled(K[6], NULL, y, atol, rtol, n)) / sqrt((double)n);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        if (h0 > interval) h0 = interval;
+#pragma omp parallel for schedule(static)
+        for (size_t q = 0; q < n; ++q) ytmp[q] = y[q] + h0 * direction * K[6][q];
+        occ_hjb_rhs(P, ytmp, V, m, K[0]);
+        ++nfev;
+        const double d2 = sqrt(sumsq_scaled(K[0], K[6], y, atol, rtol, n)) / sqrt((double)n) / h0;
+        double h1;
+        if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
+        else h1 = pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+        h_abs = fmin(fmin(100 * h0, h1), interval);
+    }
+    int n_rec = 0, k_next = 0, fstep = 0;
+    if (t_steps && t_cap > 0) t_steps[n_rec++] = t;
+    int* slot = (int*)malloc(sizeof(int) * (size_t)(nt > 0 ? nt : 1));
+    for (int k = 0; k < nt; ++k) slot[k] = -1;
+    for (int q = 0; q < n_keep; ++q)
+        if (keep_idx[q] >= 0 && keep_idx[q] < nt) slot[keep_idx[q]] = q;
+    const double tstep = (nt > 1) ? (0.0 - T) / (double)(nt - 1) : 0.0;     /* np.linspace(T, 0, nt) */
+    int rc = 0;
+    while (t != tf && nt > 0) {
+        double min_step = 10 * fabs(nextafter(t, direction * INFINITY) - t);
+        if (h_abs < min_step) h_abs = min_step;
+        int accepted = 0, rejected = 0;
+        double t_new = t, hh = 0;
+        double* sw = K[0]; K[0] = K[6]; K[6] = sw;  /* FSAL */
+        while (!accepted) {
+            if (forced) {
+                if (fstep + 1 >= n_forced) { rc = -2; goto done; }
+                t_new = forced[fstep + 1];
+                hh = t_new - t;
+                h_abs = fabs(hh);
+            } else {
+                if (h_abs < min_step) { rc = -3; goto done; }
+                hh = h_abs * direction;
+                t_new = t + hh;
+                if (direction * (t_new - tf) > 0) t_new = tf;
+                hh = t_new - t;
+                h_abs = fabs(hh);
+            }
+            ++n_att;
+            for (int s = 1; s < 6; ++s) {
+#pragma omp parallel for schedule(static)
+                for (size_t q = 0; q < n; ++q) {
+                    double acc = 0.0;
+                    for (int j = 0; j < s; ++j) acc += K[j][q] * RKA[s][j];
+                    ytmp[q] = y[q] + acc * hh;       /* dy = np.dot(K[:s].T, a[:s]) * h  (rk.py:64-66) */
+                }
+                occ_hjb_rhs(P, ytmp, V, m, K[s]);
+                ++nfev;
+            }
+#pragma omp parallel for schedule(static)
+            for (size_t q = 0; q < n; ++q) {
+                double acc = 0.0;
+                for (int j = 0; j < 6; ++j) acc += K[j][q] * RKB[j];
+                ynew[q] = y[q] + hh * acc;           /* rk.py:68 */
+            }
+            occ_hjb_rhs(P, ynew, V, m, K[6]);
+            ++nfev;
+            double es = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : es)
+            for (size_t q = 0; q < n; ++q) {
+                double acc = 0.0;
+                for (int j = 0; j < 7; ++j) acc += K[j][q] * RKE[j];
+                const double v = acc * hh / (atol + fmax(fabs(y[q]), fabs(ynew[q])) * rtol);
+                es += v * v;
+            }
+            const double err = sqrt(es) / sqrt((double)n);
+            if (forced) {
+                if (err_out) err_out[fstep] = err;
+                ++fstep;
+                accepted = 1;
+            } else if (err < 1) {
+                double factor = (err == 0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+                if (rejected) factor = fmin(1.0, factor);
+                h_abs *= factor;
+                accepted = 1;
+            } else {
+                h_abs *= fmax(0.2, 0.9 * pow(err, -0.2));
+                rejected = 1;
+            }
+        }
+        /* dense output for the t_eval points in (t_new, t]  (ivp.py:706-723, rk.py:560-575) */
+        while (k_next < nt) {
+            double tek = (double)k_next * tstep + T;
+            if (k_next == nt - 1) tek = 0.0;
+            if (!(tek >= t_new)) break;
+            const int k = k_next++;
+            if (slot[k] < 0) continue;
+            const double x = (tek - t) / hh;
+            double w[7];
+            for (int j = 0; j < 7; ++j) {
+                double xp = x, acc = 0.0;
+                for (int p = 0; p < 4; ++p) { acc += RKP[j][p] * xp; xp *= x; }
+                w[j] = acc;
+            }
+            double* out = phi_keep + (size_t)slot[k] * n;
+#pragma omp parallel for schedule(static)
+            for (size_t q = 0; q < n; ++q) {
+                double acc = 0.0;
+                for (int j = 0; j < 7; ++j) acc += K[j][q] * w[j];
+                out[q] = hh * acc + y[q];
+            }
+        }
+        sw = y; y = ynew; ynew = sw;
+        t = t_new;
+        ++n_acc;
+        if (t_steps && n_rec < t_cap) t_steps[n_rec++] = t;
+        if (direction * (t - tf) >= 0) break;
+    }
+done:
+    if (stats_out) { stats_out[0] = nfev; stats_out[1] = n_att; stats_out[2] = n_acc; stats_out[3] = n_rec; }
+    free(slot);
+    free(buf);
+    return rc;
+}

@@ -128,3 +128,29 @@ def step_sync(P, x, y, vx, vy, vdes, status, key, fields, X0, Y0, wallmaps, rect
                          _p(f64(X0)), _p(f64(Y0)), lefts, rights, _p(offs), _p(rr), _p(nrect), max_rect, _p(noise),
                          _p(nx), _p(ny), _p(nvx), _p(nvy), _p(nst))
     return nx, ny, nvx, nvy, nst
+
+
+def rk45_solve(P, V, m, T, nt, keep=(), forced=None, rtol=1e-3, atol=1e-6):
+    """The whole HJB solve of optimals.py:193-196 in C (occ_rk45_solve).  Returns (phi_keep (len(keep), Ny*Nx), stats);
+    forced: step end times to take instead of the controller's (stats['err'] = the error norm of each forced step)."""
+    n = P.Ny * P.Nx
+    keep = np.ascontiguousarray(keep, dtype=np.int32)
+    phi = np.empty((max(len(keep), 1), n))
+    t_steps = np.zeros(100000)
+    st = np.zeros(4, dtype=np.int64)
+    fz = err = None
+    if forced is not None:
+        fz = f64(forced)
+        err = np.zeros(len(fz))
+    lib = load()
+    lib.occ_rk45_solve.restype = C.c_int
+    rc = lib.occ_rk45_solve(C.byref(P), _p(f64(V)), _p(f64(m)), C.c_double(T), C.c_int(nt), C.c_double(rtol),
+                            C.c_double(atol), _p(keep), C.c_int(len(keep)), _p(phi), _p(fz) if fz is not None else None,
+                            C.c_int(len(fz) if fz is not None else 0), _p(err) if err is not None else None,
+                            _p(t_steps), C.c_int(len(t_steps)), _p(st))
+    if rc != 0:
+        raise RuntimeError("occ_rk45_solve failed (%d)" % rc)
+    stats = dict(nfev=int(st[0]), n_attempt=int(st[1]), n_accept=int(st[2]), t_steps=t_steps[:int(st[3])].copy())
+    if err is not None:
+        stats["err"] = err[:int(st[2])].copy()
+    return phi[:len(keep)], stats

@@ -1,0 +1,166 @@
+"""BASELINE configs[4]: the synthetic open room, 4096 x 4096 grid (409.55 m at grid_step 0.1), 500 000 agents,
+recompute=True, on ONE MI355X (its 134 GB direction field fits the 288 GB of a single GPU; the row-sharded form of
+the same run is covered by tests/test_hjb_rows.py and tests/test_step_sharded.py at small sizes).
+
+What run() does with recompute=True (reference simulations.py:424-435): a solve at step 0 with m = 0, then every 50
+steps the Gaussian density of the current crowd (simulations.py:453-487) becomes `m` and every key is solved again on
+the shrunken horizon nt = round((T - t)/dt) (quirk Q9).  This module walks that loop for 120 steps -- two recomputes --
+and checks, at full size:
+  * the horizon sequence (1000, 950, 900) and the Q9 lookup guard that follows from it;
+  * the direction field: unit-or-zero, padded ring zero;
+  * the device density on windows against the oracle's definition, and that it is what the re-solve is fed with;
+  * the re-solve at step 50 (m = density, nt = 950) against the C oracle's float64 solve of the SAME problem driven along
+    the GPU's accepted step sequence: phi and direction field at two slices (tolerances of SURVEY 8d);
+  * sampled pair forces / nearest wall cells / floor-field lookups of the moving crowd against the oracle.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oc_oracle as oc                     # noqa: E402  (checker only)
+from oracle import oc_oracle_c as occ                  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def c5():
+    import torch
+    import bench
+    sim, cfg = bench.build_sim("open_room")
+    yield sim, cfg
+    sim._engine.close()
+    sim._engine.fields = []
+    del sim
+    torch.cuda.empty_cache()
+
+
+def _norm(a, b):
+    return (a.double() ** 2 + b.double() ** 2).sqrt()
+
+
+def test_open_room_recompute_loop(c5):
+    import torch
+    sim, cfg = c5
+    eng = sim._engine
+    hp = cfg["hjb_params"]
+    assert (sim.Nx, sim.Ny, sim.N, len(sim._key_names)) == (4096, 4096, 500000, 1) and sim.recompute
+    nt0 = sim._nt0
+    key = sim._key_names[0]
+    opt = sim.targets[key]
+    P = occ.params(cfg, sim.room_length, sim.room_height, sim.Nx, sim.Ny)
+    V = np.ascontiguousarray(sim.Vs[key])
+    horizons, checked_resolve = [], False
+    sim._solve_all()                                            # step 0: m = 0 (simulations.py:424-425)
+    horizons.append(opt.nt_opt)
+    assert opt.stats["n_slices_written"] == nt0 - 1
+    for s in range(120):
+        if s > 0 and s % sim.recompute_step == 0:               # simulations.py:432-435
+            m = sim._density_dev(sim.sigma_convolution)
+            nt = round((sim.T - sim.time) / sim.dt)
+            if not checked_resolve:
+                # ---- the re-solve itself against the C oracle on the GPU's step sequence (float32 error alone)
+                slices = [0, nt - 2]
+                keep = [nt - 1 - q for q in slices]
+                st, phi_keep = eng.solve(0, sim.T, nt, m=m, keep=keep, want_steps=True)
+                got = phi_keep.cpu().numpy().reshape(2, -1)
+                del phi_keep
+                m64 = m.double().cpu().numpy()
+                assert m64.max() > 1.0 and (m64[V < 0] == 0).all()          # a real crowd density, masked on walls
+                want, zst = occ.rk45_solve(P, V, m64, sim.T, nt, keep=keep, forced=st["t_steps"])
+                assert zst["n_accept"] == st["n_accept"] and (zst["err"] < 1.0).all()
+                vx, vy = eng.field_interior(0)
+                for q, sl in enumerate(slices):
+                    sel = (V.ravel() >= 0) & (want[q] > oc.LIM)
+                    assert (np.abs(got[q] - want[q])[sel] / want[q][sel]).max() <= 2e-4
+                    gx, gy = occ.vels(P, want[q])
+                    hx, hy = vx[sl].double().cpu().numpy(), vy[sl].double().cpu().numpy()
+                    both = (np.hypot(gx, gy) > 0.5) & (np.hypot(hx, hy) > 0.5)
+                    ang = np.abs(np.arctan2(gx * hy - gy * hx, gx * hx + gy * hy))
+                    ph = want[q].reshape(sim.Ny, sim.Nx)
+                    p = ph * (ph > oc.LIM) + oc.LIM * (ph < oc.LIM)
+                    gs = cfg["grid_step"]
+                    nrm = np.hypot((p[1:-1, 2:] - p[1:-1, :-2]) / (2 * gs), (p[2:, 1:-1] - p[:-2, 1:-1]) / (2 * gs)) / \
+                        (hp["mu"] * p[1:-1, 1:-1])
+                    clear = np.abs(nrm - oc.LIM) > 0.1 * oc.LIM
+                    a = ang[both & clear]
+                    assert a.size > 1000 and a.max() <= 1e-2
+                    flip = (np.hypot(gx, gy) > 0.5) != (np.hypot(hx, hy) > 0.5)
+                    assert flip.mean() <= 1e-3
+                    del gx, gy, hx, hy, ang, both, clear, flip, nrm, p
+                del got, want, m64
+                checked_resolve = True
+            sim._solve_all()                                    # what run() does (same density, same horizon)
+            horizons.append(opt.nt_opt)
+            assert opt.nt_opt == nt and opt.stats["n_slices_written"] == nt - 1
+        sim.step(sim.dt)
+    assert horizons == [1000, 950, 900] and checked_resolve
+    assert sim.simu_step == 120 and sim.inside == sim.N         # nobody reaches the door 200 m away in 2.4 s
+
+    # ---- direction field after the last recompute: unit or zero, padded ring zero
+    vx, vy = eng.field_interior(0)
+    for s in (0, 450, horizons[-1] - 2):
+        n = _norm(vx[s], vy[s])
+        unit = n > 0.5
+        assert float((n[unit] - 1).abs().max()) < 1e-5 and float(n[~unit].abs().max()) == 0.0
+        assert 0.0 < float(unit.float().mean()) < 1.0
+        del n, unit
+    full = eng.fields[0][0]
+    assert float(full[:900, 0, :].abs().max()) == 0 and float(full[:900, :, -1].abs().max()) == 0
+
+    # ---- Q9: the lookup answers zero from simu_step >= nt_opt - 1 on (optimals.py:231-232)
+    des, err = eng.lookup(horizons[-1] - 1)
+    assert err == 0 and float(des.abs().max()) == 0.0
+    des, err = eng.lookup(120)
+    assert err == 0 and float(des.abs().max()) > 0.0
+
+    # ---- density of the moving crowd on windows against the oracle's definition (simulations.py:453-487, Q11)
+    st = eng.get_state()
+    x, y, vxa, vya = st["x"], st["y"], st["vx"], st["vy"]
+    status = st["status"].astype(bool)
+    sig = sim.sigma_convolution
+    d = sim.gaussian_density(sig)                               # float64 output, 6 sigma truncation
+    Vall = sim.V
+    for (r0, c0) in ((2000, 2000), (40, 3000), (4096 - 48, 4096 - 48), (0, 0)):
+        rr, cc = slice(r0, r0 + 32), slice(c0, c0 + 32)
+        Xw, Yw = np.meshgrid(sim._X0[cc], sim._Y0[rr])
+        near = (np.abs(x - sim._X0[cc].mean()) < 12 * sig + 2) & (np.abs(y - sim._Y0[rr].mean()) < 12 * sig + 2)
+        want = oc.gaussian_density(x[near], y[near], status[near], Xw, Yw, Vall[rr, cc], sig)
+        assert np.abs(d[rr, cc] - want).max() <= 2e-7 * max(want.max(), 1.0)
+    del d
+
+    # ---- sampled forces and lookups of the moving crowd against the oracle
+    rng = np.random.RandomState(5)
+    sample = rng.choice(np.nonzero(status)[0], 100, replace=False)
+    f = eng.pair_force().cpu().numpy()
+    for i in sample:
+        near = (np.abs(x - x[i]) < 4.5) & (np.abs(y - y[i]) < 4.5)
+        js = np.nonzero(near & status & (np.hypot(x - x[i], y - y[i]) < cfg["repulsion_cutoff"]))[0]
+        js = js[js != i]
+        want = oc.pair_force(np.array((x[i], y[i])), np.array((vxa[i], vya[i])), sim._v_des[i],
+                             np.column_stack([x[js], y[js]]), np.column_stack([vxa[js], vya[js]]), cfg).sum(axis=0)
+        assert np.abs(f[i] - want).max() <= 5e-5 * max(np.abs(want).max(), 1e-3)
+    idx, fw = eng.wall_force()
+    idx = idx.cpu().numpy()
+    wm = occ.WallMap(sim._X0, sim._Y0, V)
+    # agents next to the border walls (the only walls of this room) must have been searched, exactly
+    edge = np.nonzero(status & ((x < 6) | (y < 6) | (x > sim.room_length - 6) | (y > sim.room_height - 6)))[0][:40]
+    for i in list(sample[:30]) + list(edge):
+        want = int(wm.query(x[i], y[i])[0])
+        if idx[i] >= 0:
+            assert idx[i] == want
+        else:
+            r, c = divmod(want, sim.Nx)
+            dist = np.hypot(sim._X0[c] - x[i], sim._Y0[r] - y[i])
+            s_i = np.hypot(vxa[i], vya[i])
+            a = cfg["b_min"] + cfg["tau_a"] * s_i
+            assert dist > a * a + cfg["eta_walls"] * (1 + s_i) * 33.0
+    step = 120
+    des, err = eng.lookup(step)
+    des = des.cpu().numpy()
+    assert err == 0
+    fx, fy = (t[step].double().cpu().numpy() for t in eng.field_interior(0))
+    i0, i1, j0, j1, bad = oc.lookup_indices(x[sample], y[sample], sim.room_length, sim.room_height, sim.dx, sim.dy,
+                                            sim.Nx, sim.Ny)
+    assert not bad.any()
+    assert np.allclose(des[sample, 0], sim._v_des[sample] * 0.5 * (fx[i0, j0] + fx[i1, j1]), atol=1e-12)
+    assert np.allclose(des[sample, 1], sim._v_des[sample] * 0.5 * (fy[i0, j0] + fy[i1, j1]), atol=1e-12)

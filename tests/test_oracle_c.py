@@ -57,3 +57,20 @@ def test_c_step_sync_g7(golden):
     assert np.allclose(nx, g["syn_x"], atol=1e-10) and np.allclose(ny, g["syn_y"], atol=1e-10)
     assert np.allclose(nvx, g["syn_vx"], atol=1e-9) and np.allclose(nvy, g["syn_vy"], atol=1e-9)
     assert np.array_equal(nst.astype(bool), g["syn_status"])
+
+
+def test_c_rk45_solve_g3(golden):
+    """occ_rk45_solve against the reference's own solve_ivp run (fixture G3): same nfev, same accepted step times,
+    phi at the kept t_eval points; and the forced-step mode reproduces the free run from its own step list."""
+    g = golden("G3_solve_gold_a_T4.npz")
+    P, cfg, room = _P("gold_a")
+    nt = int(g["nt"])
+    keep = [int(k) for k in g["slices"]]
+    phi, st = occ.rk45_solve(P, g["V"], g["m"], float(g["T"]), nt, keep=keep)
+    assert st["nfev"] == int(g["nfev"])
+    assert len(st["t_steps"]) == len(g["t_steps"]) and np.allclose(st["t_steps"], g["t_steps"], rtol=0, atol=1e-10)
+    want = g["phi"].reshape(len(keep), -1)
+    assert np.abs(phi - want).max() <= 1e-10 * np.abs(want).max()
+    phi2, st2 = occ.rk45_solve(P, g["V"], g["m"], float(g["T"]), nt, keep=keep, forced=st["t_steps"])
+    assert st2["n_accept"] == st["n_accept"] and (st2["err"] < 1).all()
+    assert np.abs(phi2 - phi).max() <= 1e-12 * np.abs(phi).max()
