@@ -182,6 +182,18 @@ int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out, void* str
  * Rebuilds the spatial order every `resort_every` steps (0 = library default). */
 int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise, uint64_t seed,
                  int32_t* counters, void* stream);
+/* One SEQUENTIAL (Gauss-Seidel) step in the reference's own update order -- simulations.py:268-332 with
+ * pedestrians.py:140-162 returning the already advanced trajectory point: agents are visited one by one in the
+ * permutation `perm` (device int32 (N): perm[0] moves first; the host draws it like simulations.py:271 does), and
+ * agent i sees the NEW position / velocity / status of every agent visited before it.  The library level-schedules the
+ * permutation: an agent moves as soon as all earlier agents within cutoff + 2 M of it have moved (M = "seq_margin_mm",
+ * default 250 mm, a bound on one step's displacement that every round verifies; a violation is OC_ERR_STATE), one pair
+ * of launches per level, so the result equals the one-by-one loop up to float32 pair arithmetic and summation order.
+ * noise as in oc_gcfm_step (noise[i] = agent i's draw, whatever its place in the permutation).  rounds_out (host, may be
+ * NULL): number of levels.  Synchronises (the host watches the pending count).  For trajectory-level parity with the
+ * reference; oc_gcfm_step (synchronous) is the fast path. */
+int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t simu_step, const int32_t* perm, const double* noise,
+                            uint64_t seed, int32_t* counters, int32_t* rounds_out, void* stream);
 /* The step on `world` GPUs with REPLICATED agents: every rank holds the whole agent state and calls this
  * with the same arguments.  Rank r computes the pair forces and the wall forces of its contiguous share of the tiles
  * (against all agents) and the desired velocities of the agents whose floor-field rows it holds (oc_set_field_rows;
@@ -227,7 +239,8 @@ int oc_set_hjb_variant(oc_handle* h, int variant);
  *   "pair_split"  1, 2 or 4 pair wavefronts per tile of 64 agents (default 4)
  *   "prep_blocks" upper limit of the blocks of the force kernel that do the wall search / field lookup of the tiles
  *                 (default 256; the launch uses the fewest blocks that give every prep wavefront the same tile count)
- *   "resort_every" same as oc_set_resort_every */
+ *   "resort_every" same as oc_set_resort_every
+ *   "seq_margin_mm" displacement bound M of oc_gcfm_step_sequential in millimetres (default 250) */
 int oc_set_tuning(oc_handle* h, const char* name, int value);
 
 /* Opt-in corrections of reference quirks (SURVEY.md quirk register, section 8f-4).  Default 0: every entry point is

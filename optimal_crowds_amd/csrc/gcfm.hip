@@ -103,6 +103,9 @@ struct Scratch {
     double2 *f_pair, *f_wall, *des;     // single-shot diagnostic exports only
     long long* widx;
     int32_t* ctrl;
+    int32_t* seq_rank;      // sequential mode: position of the slot's agent in the step's permutation
+    int32_t* seq_state;     // 0 = not yet updated this step, 1 = being updated in this round, 2 = updated (or no agent)
+    int32_t* seq_ctl;       // [0..3]: agents still pending after round r (slot r & 3); [4]: displacement-bound violations
     int32_t Np, ntiles;
 };
 
@@ -1191,8 +1194,12 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
 
 // simulations.py:303-332 for the 64 agents of a tile, float64, then the next step's packed snapshot in place.
 // Everything is read by slot and was prepared by k_forces: one level of loads.
+// SEQ (sequential mode, k_seq_pairs below): only the agents marked for this round (seq_state == 1) are advanced; the
+// others keep their records.  `seq_round` selects the slot of the pending counter, `seq_margin` is the displacement
+// bound the round's independence rests on (a larger move raises seq_ctl[4]).
+template <bool SEQ>
 __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const double* __restrict__ rect_tab, int nkeys,
-                                               StepArgs A) {
+                                               StepArgs A, int seq_round, double seq_margin) {
     __shared__ double l_rect[RECT_KEYS_LDS * RECT_TAB];
     const Snap& C = S.snap;
     const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
@@ -1200,10 +1207,12 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     if (tab_lds)
         for (int q = lane; q < nkeys * RECT_TAB; q += 64) l_rect[q] = rect_tab[q];
     const int i = C.pidx[k];
-    const bool act = i >= 0;
+    const int sstate = SEQ ? S.seq_state[k] : 1;
+    const bool live = i >= 0;                       // an agent sits in this slot
+    const bool act = live && sstate == 1;           // ... and is advanced by this launch
     bool out = false;
-    double nx = 1e300, ny = 1e300;
     const double2 p = C.ppos[k], v = S.pvd[k], ds = S.des[k], fw = S.f_wall[k], fp = S.f_pair[k];
+    double nx = (SEQ && live) ? p.x : 1e300, ny = (SEQ && live) ? p.y : 1e300;
     const PDK dk = S.pdk[k];
     // (needed only at the very end, by lane 0: fetched with the rest so that the tail holds no memory round trip)
     const double4 b0 = S.tile_box0[it];
@@ -1244,6 +1253,10 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
         A.vx[i] = nvx;
         A.vy[i] = nvy;
         if (A.agent_time) A.agent_time[i] = at0 + dt;
+        if (SEQ) {
+            S.seq_state[k] = 2;
+            if (!(fabs(nx - p.x) <= seq_margin && fabs(ny - p.y) <= seq_margin)) S.seq_ctl[4] = 1;
+        }
         // exit test against the agent's own targets, strict (pedestrians.py:132-136)
         const double* rt = (tab_lds ? l_rect : rect_tab) + (size_t)dk.key * RECT_TAB;
         const int nrect = (int)rt[0];
@@ -1265,7 +1278,11 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
             S.pvd[k] = make_double2(nvx, nvy);
         }
     }
-    const bool stay = act && !out;
+    const bool stay = live && !out;
+    if (SEQ) {      // agents that still wait for an earlier neighbour: the host launches rounds until none is left
+        const unsigned long long m_pend = __ballot(live && sstate == 0);
+        if (lane == 0 && m_pend) atomicAdd(&S.seq_ctl[seq_round & 3], __popcll(m_pend));
+    }
     // counters: only exits touch them (one word takes ~88 atomics per us: 1563 tiles adding to one counter every step
     // would cost more than the rest of this kernel)
     const unsigned long long m_out = __ballot(out);
@@ -1274,7 +1291,7 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
                                   stay ? ny : -INFINITY, lane, it, C.qbox);
     const double mnx = tb.x, mny = tb.y, mxx = tb.z, mxy = tb.w;
     if (lane == 0) {
-        if (it == 0) {                              // IndexError-band flag raised by the lookups of k_forces
+        if (it == 0 && (!SEQ || seq_round == 0)) {  // IndexError-band flag raised by the lookups of k_forces
             const int e = err0;
             A.cnt_out[C_ERR] = e;
             S.ctrl[C_ERR + 8] = 0;
@@ -1292,6 +1309,121 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
         C.tile_box[it] = make_double4(mnx, mny, mxx, mxy);
         const double D = P.drift;
         if (mnx <= mxx && (mnx < b0.x - D || mny < b0.y - D || mxx > b0.z + D || mxy > b0.w + D)) S.ctrl[C_INVALID] = 1;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------- sequential (Gauss-Seidel) mode
+// The reference updates the agents ONE BY ONE in a fresh random permutation, and an agent sees the already advanced
+// positions / velocities / status of those visited before it (simulations.py:271, pedestrians.py:140-162).  That order
+// is reproduced exactly by level scheduling: agent i may be advanced as soon as every agent that comes EARLIER in the
+// permutation and lies within cutoff + 2 M of it has been advanced (M = bound on one step's displacement, checked by
+// k_finish<true>): two agents advanced in the same round are then farther apart than the cutoff before and after their
+// moves, so neither contributes to the other, and each reads exactly the state the one-by-one loop would have shown
+// it -- new records of the earlier neighbours, old records of the later ones.  A round = k_seq_pairs (who is free to
+// go + their pair sums from the LIVE records) + k_finish<true> (advance them in place); the rounds' number is the
+// depth of the permutation's dependency graph (tens at crowd densities), so this mode costs that many launches per
+// step: it exists for trajectory-level parity with the reference, the synchronous step is the fast path.
+__global__ void k_seq_invperm(const int32_t* __restrict__ perm, int N, int32_t* __restrict__ inv) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < N) {
+        const int i = perm[r];
+        if (i >= 0 && i < N) inv[i] = r;
+    }
+}
+
+__global__ void k_seq_init(Scratch S, const int32_t* __restrict__ inv) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) S.seq_ctl[0] = S.seq_ctl[1] = S.seq_ctl[2] = S.seq_ctl[3] = S.seq_ctl[4] = 0;
+    if (k >= S.Np) return;
+    const int i = S.snap.pidx[k];
+    S.seq_rank[k] = (i >= 0) ? inv[i] : 0x7FFFFFFF;
+    S.seq_state[k] = (i >= 0) ? 0 : 2;
+}
+
+struct SeqLds {
+    double2 pos[64];
+    float4 vel[64];
+    float2 head[64];
+    int32_t rank[64], state[64];
+};
+
+// one wavefront per tile, one lane per agent i; every pair of the candidate tiles is visited (float64 distances, the
+// packed float32 force of pair_term2, float64 sums in slot order of the j's)
+__global__ void __launch_bounds__(64) k_seq_pairs(GcfmParams P, Scratch S, int round, double margin) {
+    __shared__ SeqLds L;
+    const Snap& C = S.snap;
+    const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
+    if (it == 0 && lane == 0) S.seq_ctl[(round + 1) & 3] = 0;          // next round's pending counter
+    const int st_i = S.seq_state[k];
+    if (!__any(st_i == 0)) return;                                      // the whole tile has been advanced
+    const int i = C.pidx[k];
+    const int rank_i = S.seq_rank[k];
+    const double2 pi = C.ppos[k];
+    const float4 vi = C.pvel[k];
+    const float2 hi = C.phead[k];
+    float inv_vdes = 0.f, ib2_i = 0.f;
+    if (i >= 0) {
+        const double vd = S.pdk[k].v_des;
+        inv_vdes = (float)(1.0 / vd);
+        const double b = P.b_max - (P.b_max - P.b_min) * fmin((double)vi.z / vd, 1.0);
+        ib2_i = (float)(1.0 / (b * b));
+    }
+    const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
+    const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
+    const bool unit_dir = (P.fix & OC_FIX_PAIR_FORCE) != 0;
+    const double reach = P.cutoff + 2.0 * margin, reach2 = reach * reach;
+    const double4 bi = C.tile_box[it];
+    bool blocked = false;
+    double fx = 0.0, fy = 0.0;
+    const int32_t* nb = S.nb_list + (size_t)it * (NB_MAX + 1);
+    const int nb_cnt = nb[0];
+    const bool use_list = (nb_cnt >= 0) && (S.ctrl[C_INVALID] == 0);
+    const int nchunk = use_list ? 1 : (S.ntiles + 63) / 64;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        int t;
+        if (use_list) t = (lane < nb_cnt) ? nb[1 + lane] : -1;
+        else t = (ch * 64 + lane < S.ntiles) ? ch * 64 + lane : -1;
+        // (live boxes: read while other tiles may be advancing; a box only ever matters through agents that are within
+        // reach, and those are not being advanced in this round -- see the header)
+        const bool hit = (t >= 0) && box_hit(bi, C.tile_box[t], reach + margin);
+        unsigned long long tmask = __ballot(hit);
+        while (tmask) {
+            const int jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
+            tmask &= tmask - 1;
+            __syncthreads();
+            L.pos[lane] = C.ppos[jt * 64 + lane];
+            L.vel[lane] = C.pvel[jt * 64 + lane];
+            L.head[lane] = C.phead[jt * 64 + lane];
+            L.rank[lane] = S.seq_rank[jt * 64 + lane];
+            L.state[lane] = S.seq_state[jt * 64 + lane];
+            __syncthreads();
+            if (i >= 0 && st_i == 0)
+            for (int q = 0; q < 64; q += 2) {
+                const double2 pa = L.pos[q], pb = L.pos[q + 1];
+                const double dxA = pa.x - pi.x, dyA = pa.y - pi.y, dxB = pb.x - pi.x, dyB = pb.y - pi.y;
+                const double d2A = dxA * dxA + dyA * dyA, d2B = dxB * dxB + dyB * dyB;
+                // an earlier neighbour that has not moved yet: wait for it
+                blocked = blocked || (L.state[q] != 2 && L.rank[q] < rank_i && d2A < reach2) ||
+                          (L.state[q + 1] != 2 && L.rank[q + 1] < rank_i && d2B < reach2);
+                const bool okA = d2A <= P.cut_d2max && d2A > 0.0, okB = d2B <= P.cut_d2max && d2B > 0.0;
+                if (okA || okB) {
+                    const float4 va = L.vel[q], vb = L.vel[q + 1];
+                    const float2 ha = L.head[q], hb = L.head[q + 1];
+                    f2v gx, gy;
+                    pair_term2((f2v){(float)dxA, (float)dxB}, (f2v){(float)dyA, (float)dyB}, vi.x, vi.y, vi.z, hi.x, hi.y,
+                               vi.w, ib2_i, inv_vdes, (f2v){va.x, vb.x}, (f2v){va.y, vb.y}, (f2v){va.z, vb.z},
+                               (f2v){va.w, vb.w}, (f2v){ha.x, hb.x}, (f2v){ha.y, hb.y}, b_max, db, neg_inv_eta_log2e,
+                               unit_dir, gx, gy);
+                    if (okA) { fx += (double)gx.x; fy += (double)gy.x; }
+                    if (okB) { fx += (double)gx.y; fy += (double)gy.y; }
+                }
+            }
+        }
+    }
+    if (i >= 0 && st_i == 0 && !blocked) {
+        S.f_pair[k] = make_double2(fx, fy);
+        S.seq_state[k] = 1;
     }
 }
 
@@ -1403,14 +1535,15 @@ GcfmParams make_params(const oc_handle* h) {
     return P;
 }
 
-int carve(oc_handle* h, int N, Scratch* S) {
+int carve(oc_handle* h, int N, Scratch* S, bool diag = false) {
     int Np = ((N + 63) / 64) * 64;
     if (Np == 0) Np = 64;
     const int nt = Np / 64;
     const size_t per_snap = sizeof(double2) + sizeof(float4) + sizeof(float2) + sizeof(int32_t);
     const size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + per_snap + sizeof(double2) + sizeof(PDK) +
                        3 * sizeof(double2) + sizeof(long long);
-    size_t need = per * (size_t)Np + (6 * sizeof(double4) + (NB_MAX + 3) * sizeof(int32_t)) * (size_t)nt + 64 + 16384;
+    size_t need = (per + 2 * sizeof(int32_t)) * (size_t)Np + (6 * sizeof(double4) + (NB_MAX + 3) * sizeof(int32_t)) * (size_t)nt +
+                  1024 + 16384;
     if (need > h->gcfm_bytes) {
         if (h->gcfm_buf) OC_HIP_CHECK(hipFree(h->gcfm_buf));
         h->gcfm_buf = nullptr;
@@ -1426,6 +1559,12 @@ int carve(oc_handle* h, int N, Scratch* S) {
         p += (bytes + 255) & ~(size_t)255;
         return (void*)q;
     };
+    // the control words come FIRST: their address must not depend on the agent count (oc_run_status reads them whatever
+    // set of agents the last call packed); diagnostic exports use their own copy (prepare) and never touch the run's
+    S->ctrl = (int32_t*)take(64);
+    int32_t* ctrl_diag = (int32_t*)take(64);
+    S->seq_ctl = (int32_t*)take(64);
+    if (diag) S->ctrl = ctrl_diag;
     S->snap.ppos = (double2*)take(sizeof(double2) * Np);
     S->snap.pvel = (float4*)take(sizeof(float4) * Np);
     S->snap.phead = (float2*)take(sizeof(float2) * Np);
@@ -1446,7 +1585,8 @@ int carve(oc_handle* h, int N, Scratch* S) {
     S->nb_list = (int32_t*)take(sizeof(int32_t) * (NB_MAX + 1) * (size_t)nt);
     S->tile_work = (int32_t*)take(sizeof(int32_t) * nt);
     S->tile_order = (int32_t*)take(sizeof(int32_t) * nt);
-    S->ctrl = (int32_t*)take(64);
+    S->seq_rank = (int32_t*)take(sizeof(int32_t) * Np);
+    S->seq_state = (int32_t*)take(sizeof(int32_t) * Np);
     S->Np = Np;
     S->ntiles = nt;
     return OC_OK;
@@ -1528,11 +1668,12 @@ int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hi
     h->steps_since_sort = 0;
     h->packed_x = a->x;
     h->packed_N = N;
+    h->packed_seq = false;
     return OC_OK;
 }
 
 int prepare(oc_handle* h, const oc_agents* a, Scratch* S, GcfmParams* P, hipStream_t s) {
-    int rc = carve(h, a->N, S);
+    int rc = carve(h, a->N, S, true);      // single-shot diagnostic exports: own control words
     if (rc) return rc;
     *P = make_params(h);
     if ((rc = upload_keys(h, s))) return rc;
@@ -1687,11 +1828,12 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
         return OC_ERR_STATE;
     }
     oc_timer_begin(h, "gcfm_finish", s);
-    hipLaunchKernelGGL(k_finish, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
-                       (int)h->fields.size(), A);
+    hipLaunchKernelGGL(k_finish<false>, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
+                       (int)h->fields.size(), A, 0, 0.0);
     oc_timer_end(h, "gcfm_finish", s);
     OC_HIP_CHECK(hipGetLastError());
     h->packed_valid = true;
+    h->packed_seq = false;          // (held to the synchronous step's drift bound only)
     ++h->steps_since_sort;
     ++h->prof_tick;
     return OC_OK;
@@ -1714,6 +1856,89 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     }
     const TileShare all = {0, S.ntiles, 1, 0};
     return launch_step(h, a, S, P, simu_step, noise, seed, counters, all, nullptr, nullptr, nullptr, s);
+}
+
+
+// One SEQUENTIAL step (see k_seq_pairs): the caller's permutation and noise, rounds until every active agent has moved.
+extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t simu_step, const int32_t* perm,
+                                       const double* noise, uint64_t seed, int32_t* counters, int32_t* rounds_out,
+                                       void* stream) {
+    int rc = check_agents(h, a);
+    if (rc) return rc;
+    if ((rc = require_wallmaps(h))) return rc;
+    OC_REQUIRE(perm || a->N == 0, "the sequential step needs the permutation");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scratch S;
+    if ((rc = carve(h, a->N, &S))) return rc;
+    GcfmParams P = make_params(h);
+    if ((rc = upload_keys(h, s))) return rc;
+    const double margin = h->seq_margin;
+    OC_REQUIRE(margin > 0 && margin < P.drift, "seq_margin must stay below the neighbour lists' drift allowance");
+    // the neighbour lists must cover cutoff + 2 M around the LIVE boxes: they do while no box has drifted more than
+    // drift - M from its sort-time box (k_finish<true> checks exactly that); a snapshot left by synchronous steps was
+    // held to the weaker bound, so it is rebuilt
+    if (!h->packed_valid || h->packed_x != a->x || h->packed_N != a->N || h->steps_since_sort >= h->resort_every ||
+        !h->packed_seq) {
+        if ((rc = repack(h, a, &S, P, s))) return rc;
+    }
+    h->packed_seq = true;
+    StepArgs A;
+    A.x = a->x; A.y = a->y; A.vx = a->vx; A.vy = a->vy;
+    A.status = a->status;
+    A.agent_time = a->agent_time;
+    A.noise = noise;
+    A.seed = seed;
+    A.step = simu_step;
+    A.cnt_out = counters ? counters : S.ctrl;
+    const KeyDev* kd = (const KeyDev*)h->key_tables_dev;
+    const int N = a->N;
+    if (N > 0) {
+        hipLaunchKernelGGL(k_seq_invperm, dim3((N + 255) / 256), dim3(256), 0, s, perm, N, S.vals_a);
+    }
+    hipLaunchKernelGGL(k_seq_init, dim3((S.Np + 255) / 256), dim3(256), 0, s, S, (const int32_t*)S.vals_a);
+    // wall forces and desired velocities of ALL agents from the state at the start of the step: an agent's own record
+    // does not change before its turn (the prep blocks of k_forces alone; they also reset the step's counters)
+    {
+        const int nprep = std::max((S.ntiles + 3) / 4, 1);
+        const TileShare all = {0, S.ntiles, 0, 0};
+        auto kf = P.fix ? k_forces<4, true> : k_forces<4, false>;
+        hipLaunchKernelGGL(kf, dim3(nprep), dim3(256), 0, s, P, S, kd, simu_step, axis_x(h), axis_y(h), nprep, all,
+                           A.cnt_out);
+    }
+    GcfmParams Pf = P;
+    Pf.drift = P.drift - margin;            // validity bound of the neighbour lists in this mode (see above)
+    int rounds = 0, pending = N > 0 ? 1 : 0;
+    int32_t ctl[8];
+    while (pending > 0) {
+        const int burst = 4;                // rounds between two looks at the pending counter
+        for (int b = 0; b < burst; ++b, ++rounds) {
+            hipLaunchKernelGGL(k_seq_pairs, dim3(S.ntiles), dim3(64), 0, s, P, S, rounds, margin);
+            hipLaunchKernelGGL((k_finish<true>), dim3(S.ntiles), dim3(64), 0, s, Pf, S, (const double*)h->rect_tab_dev,
+                               (int)h->fields.size(), A, rounds, margin);
+        }
+        OC_HIP_CHECK(hipMemcpyAsync(ctl, S.seq_ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
+        OC_HIP_CHECK(hipStreamSynchronize(s));
+        pending = ctl[(rounds - 1) & 3];
+        if (ctl[4]) {
+            oc_set_error("sequential step %d: an agent moved farther than seq_margin = %g m in one step; the level "
+                         "schedule is not valid (raise it with oc_set_tuning(\"seq_margin_mm\"))", simu_step, margin);
+            h->packed_valid = false;
+            return OC_ERR_STATE;
+        }
+        if (rounds > N + burst) {
+            oc_set_error("sequential step %d did not drain (%d agents pending)", simu_step, pending);
+            h->packed_valid = false;
+            return OC_ERR_STATE;
+        }
+    }
+    OC_HIP_CHECK(hipGetLastError());
+    if (rounds_out) *rounds_out = rounds;
+    h->packed_valid = true;
+    h->work_valid = false;
+    ++h->steps_since_sort;
+    ++h->prof_tick;
+    return OC_OK;
 }
 
 extern "C" int oc_run_status(oc_handle* h, int32_t* out4, int reset, void* stream) {

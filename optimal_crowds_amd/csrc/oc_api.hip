@@ -218,6 +218,9 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     } else if (!strcmp(name, "resort_every")) {
         OC_REQUIRE(value >= 1 && value <= 4096, "resort_every out of range");
         h->resort_every = value;
+    } else if (!strcmp(name, "seq_margin_mm")) {
+        OC_REQUIRE(value >= 1 && value <= 1500, "seq_margin_mm out of range");
+        h->seq_margin = 1e-3 * value;
     } else {
         oc_set_error("oc_set_tuning: unknown knob '%s'", name);
         return OC_ERR_ARG;

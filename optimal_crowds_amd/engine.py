@@ -355,6 +355,24 @@ class Engine:
             return int(c[0]), int(c[1]), int(c[2])
         return None
 
+    def step_sequential(self, simu_step, perm, noise=None, seed=0):
+        """One SEQUENTIAL step in the reference's update order (oc_gcfm_step_sequential): agents move one by one in
+        the permutation `perm` and see the already advanced state of those before them (simulations.py:271,
+        pedestrians.py:140-162).  Returns (exited, bad, active, levels)."""
+        if self.sharded:
+            raise ValueError("the sequential step is a single-GPU mode")
+        if noise is not None and not torch.is_tensor(noise):
+            noise = torch.as_tensor(np.ascontiguousarray(noise, dtype=np.float64)).to(self.device)
+        perm = torch.as_tensor(np.ascontiguousarray(perm, dtype=np.int32)).to(self.device)
+        if perm.numel() != self.agents["N"]:
+            raise ValueError("the permutation must list every agent once")
+        rounds = C.c_int32(0)
+        check(self.lib.oc_gcfm_step_sequential(self.h, C.byref(self._astruct), int(simu_step), _ptr(perm), _ptr(noise),
+                                               C.c_uint64(int(seed)), _ptr(self.counters), C.byref(rounds),
+                                               self.stream()))
+        c = self.counters.cpu().numpy()
+        return int(c[0]), int(c[1]), int(c[2]), int(rounds.value)
+
     def step_sharded(self, simu_step, comm, noise=None, seed=0, sync=True):
         """One synchronous GCFM step on comm.world ranks with replicated agents (oc_gcfm_step_sharded): this rank does
         the pair / wall forces of its share of the tiles and the lookups its field rows cover, `comm` (parallel

@@ -7,9 +7,11 @@ solves and the density run in HIP kernels through liboc_hip.so.  Agent state liv
 `agents[i]` are light views (pedestrians.ped) onto it.
 
 Differences a user can observe (DESIGN.md "Deviations"):
-  * the agent update is synchronous (all agents see the positions of the step's start); the reference updates
-    agents one by one in a random order.  The random permutation is still drawn (noise='host') so that the
-    global np.random stream is consumed exactly like the reference's.
+  * the agent update is synchronous by default (all agents see the positions of the step's start); the reference
+    updates agents one by one in a random order.  The random permutation is still drawn (noise='host') so that the
+    global np.random stream is consumed exactly like the reference's.  update='sequential' reproduces the reference's
+    order itself (oc_gcfm_step_sequential: the permutation is level-scheduled on the device), at one pair of launches
+    per dependency level instead of one per step.
   * noise='device' (default above `host_noise_max_agents`) draws the step noise with Philox on the GPU.
 """
 import warnings
@@ -89,7 +91,7 @@ RASTER_DEVICE_MIN_CELLS = 1 << 22      # 2048 x 2048 and larger: rasterise the r
 class simulation:
     def __init__(self, room, T, recompute=False, *, config=None, device="cuda:0", dtype="float32",
                  noise=None, seed=20240807, history=None, record=None, wall_search_radius=None, sharding=None,
-                 fixes=(), rasterise=None):
+                 fixes=(), rasterise=None, update="synchronous"):
         """rasterise: 'host' (NumPy, like the reference), 'device' (oc_rasterise_potential, bit-identical; Vs[key] and
         V become lazily downloaded arrays) or None = 'device' from 2048 x 2048 grid nodes on.
         fixes: opt-in corrections of reference quirks, default none = bug-compatible (SURVEY quirk register):
@@ -101,6 +103,10 @@ class simulation:
         this process is then one rank of a multi-GPU simulation with replicated agents (Engine.enable_sharding);
         every rank constructs the same simulation (same room, config, seed) and makes the same calls."""
         self.recompute = recompute
+        if update not in ("synchronous", "sequential"):
+            raise ValueError("update must be 'synchronous' or 'sequential'")
+        self.update = update
+        self.levels = []            # update='sequential': dependency levels of each step's permutation
         var_config = host.load_config(config)
         var_room = host.load_room(room)
         self._cfg, self._room = var_config, var_room
@@ -202,7 +208,9 @@ class simulation:
             self.targets[key] = optimals_mod.optimals(room, None if self._raster_dev else self.Vs[key], T, key,
                                                       _sim=self, _key_index=k)
         eng.set_agents(x0, y0, np.zeros(self.N), np.zeros(self.N), self._v_des, self._key_of)
-        self._noise_mode = noise or ("host" if self.N <= HOST_NOISE_MAX_AGENTS else "device")
+        self._noise_mode = noise or ("host" if self.N <= HOST_NOISE_MAX_AGENTS or update == "sequential" else "device")
+        if update == "sequential" and sharding is not None:
+            raise ValueError("update='sequential' is a single-GPU mode")
         self._seed = seed
         self._status_host = np.ones(self.N, dtype=bool)
         # trajectory recorder (ped.traj / ped.vels / history): (steps+1, 4, N) float64 in HBM when it fits
@@ -275,14 +283,19 @@ class simulation:
         eng = self._engine
         if dt != self.dt:
             raise ValueError("the device step uses config dt (%g)" % self.dt)
-        noise = None
-        if self._noise_mode == "host":
+        noise = perm = None
+        if self._noise_mode == "host" or self.update == "sequential":
             # same draws, in the same order, as the reference: one permutation, then 2 normals per active agent
             perm = np.random.choice(np.arange(self.N), self.N, replace=False)
+        if self._noise_mode == "host":
             noise = np.zeros((self.N, 2))
             act = perm[self._status_host[perm]]
             noise[act] = np.random.normal(size=(len(act), 2))
-        exited, bad, active = eng.step(self.simu_step, noise=noise, seed=self._seed)
+        if self.update == "sequential":     # the reference's own order: reference simulations.py:271, pedestrians.py:140-162
+            exited, bad, active, levels = eng.step_sequential(self.simu_step, perm, noise=noise, seed=self._seed)
+            self.levels.append(levels)
+        else:
+            exited, bad, active = eng.step(self.simu_step, noise=noise, seed=self._seed)
         if bad:
             raise IndexError("agent %d left the region covered by the floor field (index %d is out of bounds)"
                              % (bad - 1, bad - 1))
@@ -352,7 +365,7 @@ class simulation:
     def run(self, verbose=False, draw=False, mode='scatter'):
         print(f"Computing trajectories at time {self.time}")
         self._solve_all()
-        if self._noise_mode == "device" and not verbose and not draw:
+        if self._noise_mode == "device" and self.update == "synchronous" and not verbose and not draw:
             self._time_first = self.time
             self._run_enqueued()
         while (self.inside > 0) & (self.time < self.T):

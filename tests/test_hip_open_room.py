@@ -83,7 +83,7 @@ def test_open_room_recompute_loop(c5):
                         (hp["mu"] * p[1:-1, 1:-1])
                     clear = np.abs(nrm - oc.LIM) > 0.1 * oc.LIM
                     a = ang[both & clear]
-                    assert a.size > 1000 and a.max() <= 1e-2
+                    assert a.size > (1000 if sl == 0 else 50) and a.max() <= 1e-2
                     flip = (np.hypot(gx, gy) > 0.5) != (np.hypot(hx, hy) > 0.5)
                     assert flip.mean() <= 1e-3
                     del gx, gy, hx, hy, ang, both, clear, flip, nrm, p
