@@ -8,8 +8,11 @@ Rounding noise is its seed: two float64 implementations that differ only in summ
 (6e-8) saturate at whatever the controller tolerates, which is an RMS over ALL cells (scipy common.py:63-66): on a
 2048^2 grid a ripple of a few per cent confined to the thousand cells next to a door still has an error norm < 1.
 The ripple is invisible to what the path consumes: central differences (optimals.py:174-175) take both neighbours from
-the same checkerboard colour, so the direction field does not see it.  Hence: a loose pointwise bound that documents
-the ripple, SURVEY 8d's 5e-3 on the 2x2-block average (which removes the mode), and 1e-2 rad on the direction field.
+the same checkerboard colour, so a ripple of locally uniform amplitude cancels in the direction field.  Hence: a loose
+pointwise bound that documents the ripple, a tighter one on the 2x2-block average (which removes the mode where its
+amplitude varies slowly), and 1e-2 rad on the direction field for all but a stated fraction of the cells (those where
+the ripple's amplitude changes from one cell to the next, next to doors and wall corners).  On a 200 x 200 grid the
+norm dilutes less and SURVEY 8d's figures (5e-3, 1e-2 rad everywhere) hold as they stand.
 """
 import numpy as np
 
@@ -47,3 +50,11 @@ def direction_errors(gx, gy, hx, hy, clear):
     ang = np.abs(np.arctan2(gx * hy - gy * hx, gx * hx + gy * hy))
     flip = (np.hypot(gx, gy) > 0.5) != (np.hypot(hx, hy) > 0.5)
     return ang[both & clear], float(flip.mean())
+
+
+def describe(a):
+    """summary of an error sample for assertion messages"""
+    if a.size == 0:
+        return "empty"
+    return "n=%d max=%.3e p99=%.3e p99.99=%.3e frac>1e-2=%.2e" % (
+        a.size, a.max(), np.percentile(a, 99), np.percentile(a, 99.99), (a > 1e-2).mean())
