@@ -33,6 +33,87 @@ const double RK_P[7][4] = {
     {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
     {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
 
+
+// ---- device copies of the tables: the step controller runs on the device (k_control)
+__constant__ double dRK_A[6][5] = {
+    {0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+__constant__ double dRK_B[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+__constant__ double dRK_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+// ---- device-resident step controller (hjb variant 0) -------------------------------------------------------------
+// SciPy's _step_impl (rk.py:111-176) and the t_eval bookkeeping of solve_ivp (ivp.py:706-723) restated as ONE thread of
+// k_control: after the stage launches of an attempt it turns the error sums into accept / reject, the next step size,
+// the list of t_eval points the accepted step covers and the coefficient tables of the NEXT attempt, all in this
+// struct in device memory.  The stage, output and rescale kernels take their pointers' roles, coefficients and slice
+// ranges from here, so an attempt is a fixed sequence of launches that the host enqueues without waiting for any of
+// them: no host round trip per attempt (it cost 2-3 ms of a 16 ms solve), and in the row-block solve no host
+// synchronisation around the collectives.  The host only watches `ticks` / `done` in a pinned mailbox to know when to
+// stop enqueuing; attempts enqueued past the end find `done` set and return at once.
+template <typename T>
+struct HjbCtl {
+    double t, tf, Tfinal, h_abs, rtol, atol0, n_rms, te_step, lim;
+    double hh, t_new;                   // the attempt about to run: step and its end time
+    double out_t, out_hh, out_unscale;  // the step just accepted (k_out): its start, length and 2^expo
+    double h_min, h_max;
+    int32_t nt, k_next;                 // t_eval = linspace(T, 0, nt); next index to emit
+    int32_t parity;                     // y = Y[parity], y_new = Y[1 - parity], K0 = KX[parity], K6 = KX[1 - parity]
+    int32_t expo;                       // state = phi * 2^-expo
+    int32_t rejected, done, status;
+    int32_t accepted, out_parity, k_lo, k_hi, do_scale;     // decision of the last attempt
+    int32_t n_attempt, n_accept, n_rescale, n_tsteps, ticks, is_f32;
+    T cA[3][6], cB[3][6], he[7];        // h * a_sj of launch A (stages 1-3) and B (stages 4, 5, y_new); h * E_j
+    T atol_s, out_lim_s, scale;
+};
+
+// first part of an attempt (rk.py:121-137): clamp the step, end time, coefficient tables
+template <typename T>
+__host__ __device__ inline void ctl_prepare_attempt(HjbCtl<T>& c, bool new_step) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TAB_A dRK_A
+#define TAB_B dRK_B
+#define TAB_E dRK_E
+#else
+#define TAB_A RK_A
+#define TAB_B RK_B
+#define TAB_E RK_E
+#endif
+    const double direction = -1.0;
+    const double min_step = 10 * fabs(nextafter(c.t, direction * INFINITY) - c.t);
+    if (new_step) {
+        if (c.h_abs < min_step) c.h_abs = min_step;
+    } else if (c.h_abs < min_step) {
+        c.status = OC_ERR_SOLVER;       // "step size too small"
+        c.done = 1;
+        return;
+    }
+    double hh = c.h_abs * direction;
+    double t_new = c.t + hh;
+    if (direction * (t_new - c.tf) > 0) t_new = c.tf;
+    hh = t_new - c.t;
+    c.h_abs = fabs(hh);
+    c.hh = hh;
+    c.t_new = t_new;
+    for (int q = 0; q < 3; ++q)
+        for (int j = 0; j < 6; ++j) {
+            c.cA[q][j] = j < 1 + q ? (T)(TAB_A[1 + q][j] * hh) : (T)0;
+            c.cB[q][j] = q < 2 ? (j < 4 + q ? (T)(TAB_A[4 + q][j] * hh) : (T)0) : (T)(TAB_B[j] * hh);
+        }
+    for (int j = 0; j < 7; ++j) c.he[j] = (T)(TAB_E[j] * hh);
+    c.atol_s = (T)(c.atol0 * ldexp(1.0, -c.expo));
+#undef TAB_A
+#undef TAB_B
+#undef TAB_E
+}
+
+template <typename T>
+__host__ __device__ inline double ctl_te(const HjbCtl<T>& c, int k) {      // np.linspace(T, 0, nt)[k]
+    return (k == c.nt - 1) ? 0.0 : (double)k * c.te_step + c.Tfinal;
+}
+
 template <typename T>
 struct Lin8 {   // out = base + sum_j c[j] * K[j]
     const T* k[8];
@@ -212,6 +293,119 @@ __global__ void __launch_bounds__(1024) k_reduce_final(const double* __restrict_
             __threadfence_system();
         }
     }
+}
+
+// The step controller: error norm of the attempt that just ran -> accept / reject, next step size, the t_eval points
+// of an accepted step, range management, the next attempt's coefficients (scipy rk.py:139-176, ivp.py:706-723).
+// parts: nparts pairs (sum of squared scaled errors, max |y_new|) -- the stage kernel's per-block partials, or the
+// ranks' pairs after the all-gather of a row-block solve (summed in rank order on every rank: identical decisions).
+// att_log[attempt]: bit 0 = a real attempt, bit 1 = accepted, bits 8.. = direction-field slices its k_out writes.
+// mailbox (pinned host memory): [0] ticks (control launches so far, written last), [1] done, [2] status, [3] attempts.
+template <typename T>
+__global__ void __launch_bounds__(1024) k_control(HjbCtl<T>* __restrict__ ctl, const double* __restrict__ parts,
+                                                  int nparts, double* __restrict__ t_steps, int t_cap,
+                                                  int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox) {
+    __shared__ double ls[16], lm[16];
+    __shared__ int s_done;
+    if (threadIdx.x == 0) s_done = ctl->done;
+    __syncthreads();
+    if (s_done) {                               // an attempt enqueued past the end of the solve
+        if (threadIdx.x == 0) {
+            ctl->accepted = 0;
+            ctl->do_scale = 0;
+            const int tk = ++ctl->ticks;
+            if (tk - 1 < log_cap) att_log[tk - 1] = 0;
+            mailbox[1] = 1.0;
+            __threadfence_system();
+            mailbox[0] = (double)tk;
+            __threadfence_system();
+        }
+        return;
+    }
+    const double2* __restrict__ p2 = reinterpret_cast<const double2*>(parts);
+    double s = 0.0, m = 0.0;
+    const int nth = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * nth) {
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i0 + u * nth < nparts) ? p2[i0 + u * nth] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s += v[u].x;
+            m = fmax(m, v[u].y);
+        }
+    }
+    s = wave_sum(s);
+    m = wave_max(m);
+    const int w = threadIdx.x >> 6, nw = (nth + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        ls[w] = s;
+        lm[w] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double esum = 0.0, ymax = 0.0;
+    for (int q = 0; q < nw; ++q) {
+        esum += ls[q];
+        ymax = fmax(ymax, lm[q]);
+    }
+    HjbCtl<T>& c = *ctl;
+    const double err = sqrt(esum) / sqrt(c.n_rms);
+    ++c.n_attempt;
+    c.accepted = 0;
+    c.do_scale = 0;
+    int logw = 1;
+    if (!(err == err)) {
+        c.status = OC_ERR_SOLVER - 100;         // NaN error norm (state overflow)
+        c.done = 1;
+    } else if (err < 1) {
+        double factor = (err == 0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+        if (c.rejected) factor = fmin(1.0, factor);
+        const double hstep = fabs(c.hh);
+        c.h_abs *= factor;
+        c.h_min = fmin(c.h_min, hstep);
+        c.h_max = fmax(c.h_max, hstep);
+        c.accepted = 1;
+        c.out_parity = c.parity;
+        c.parity ^= 1;
+        c.out_t = c.t;
+        c.out_hh = c.hh;
+        c.out_unscale = ldexp(1.0, c.expo);
+        c.out_lim_s = (T)(c.lim * ldexp(1.0, -c.expo));
+        c.k_lo = c.k_next;
+        int nv = 0;
+        while (c.k_next < c.nt && ctl_te(c, c.k_next) >= c.t_new) {
+            nv += c.k_next >= 1 ? 1 : 0;
+            ++c.k_next;
+        }
+        c.k_hi = c.k_next;
+        c.t = c.t_new;
+        ++c.n_accept;
+        if (c.n_tsteps < t_cap) t_steps[c.n_tsteps++] = c.t;
+        if (c.is_f32 && ymax > 0x1p64) {        // range management: keep max |y| near 2^32
+            const int e = (int)floor(log2(ymax)) - 32;
+            c.scale = (T)ldexp(1.0, -e);
+            c.do_scale = 1;
+            c.expo += e;
+            ++c.n_rescale;
+        }
+        c.rejected = 0;
+        logw |= 2 | (nv << 8);
+        if (-(c.t - c.tf) >= 0) c.done = 1;     // direction = -1
+        else ctl_prepare_attempt(c, true);
+    } else {
+        c.h_abs *= fmax(0.2, 0.9 * pow(err, -0.2));
+        c.rejected = 1;
+        ctl_prepare_attempt(c, false);
+    }
+    const int tk = ++c.ticks;
+    if (tk - 1 < log_cap) att_log[tk - 1] = logw;
+    mailbox[1] = (double)c.done;
+    mailbox[2] = (double)c.status;
+    mailbox[3] = (double)c.n_attempt;
+    __threadfence_system();
+    mailbox[0] = (double)tk;
+    __threadfence_system();
 }
 
 // dense output (scipy rk.py:560-575): phi = y_old + h * sum_p (sum_j K_j P_jp) x^(p+1)
@@ -484,14 +678,12 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
 
 template <typename T>
 struct Stage3Args {
-    const T* y;
-    const T* kin[4];        // K0 .. K_{S0-1}
+    const HjbCtl<T>* ctl;   // roles of the buffers (parity), coefficients, atol: written by k_control
+    T* Y[2];                // y / y_new
+    T* KX[2];               // K0 / K6 (FSAL: they swap on every accepted step)
+    T* KM[5];               // K1 .. K5
     const T* coef;
-    T* kout[3];             // the three new stage derivatives
-    T* ynew;                // FINAL only
-    T c[3][6];              // stage q of the launch: h * a_{s,j} for slot j (inputs first, then the new K's; 0 = unused)
-    T he[7];                // FINAL: h * E_j for K0..K6
-    T atol, rtol, a_lap;
+    T rtol, a_lap;
     double* partial;
     int Ny, Nx;
     int row_lo, row_hi;     // rows whose error / max|y| this launch accounts for
@@ -500,6 +692,22 @@ struct Stage3Args {
 template <typename T, int S0, bool FINAL>
 __global__ void __launch_bounds__(F3_NT) k_stage3(Stage3Args<T> A) {
     __shared__ T buf[2][F3_RH][F3_LS];
+    const HjbCtl<T>* __restrict__ ctl = A.ctl;
+    if (ctl->done) return;                          // an attempt enqueued past the end of the solve
+    // launch A: K1, K2, K3 from y, K0;  launch B (FINAL): K4, K5, y_new, K6 from y, K0 .. K3
+    const int par = ctl->parity;
+    T cc[3][6], he[7];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) cc[q][j] = FINAL ? ctl->cB[q][j] : ctl->cA[q][j];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) he[j] = FINAL ? ctl->he[j] : (T)0;
+    const T atol_s = ctl->atol_s;
+    const T* __restrict__ y = A.Y[par];
+    const T* kin[4] = {A.KX[par], A.KM[0], A.KM[1], A.KM[2]};
+    T* kout[3] = {FINAL ? A.KM[3] : A.KM[0], FINAL ? A.KM[4] : A.KM[1], FINAL ? A.KX[par ^ 1] : A.KM[2]};
+    T* ynew = A.Y[par ^ 1];
     const int Ny = A.Ny, Nx = A.Nx;
     const int nbx = (Nx + F3_X - 1) / F3_X, nby = (Ny + F3_Y - 1) / F3_Y, nb = nbx * nby;
     const int per = (nb + 7) / 8;
@@ -521,9 +729,9 @@ __global__ void __launch_bounds__(F3_NT) k_stage3(Stage3Args<T> A) {
         for (int j = 0; j < S0 + 3; ++j) kv[j][m] = (T)0;
         if (in) {
             const int64_t idx = (int64_t)gi * Nx + gj;
-            yv[m] = A.y[idx];
+            yv[m] = y[idx];
 #pragma unroll
-            for (int j = 0; j < S0; ++j) kv[j][m] = A.kin[j][idx];
+            for (int j = 0; j < S0; ++j) kv[j][m] = kin[j][idx];
             if (ring[m] >= 1) cf[m] = A.coef[idx];
         }
     }
@@ -535,7 +743,7 @@ __global__ void __launch_bounds__(F3_NT) k_stage3(Stage3Args<T> A) {
             if (ring[m] >= q) {
                 T t = (T)0;
 #pragma unroll
-                for (int j = 0; j < S0 + q; ++j) t += A.c[q][j] * kv[j][m];
+                for (int j = 0; j < S0 + q; ++j) t += cc[q][j] * kv[j][m];
                 t = yv[m] + t;
                 tq[m] = t;
                 buf[q & 1][row[m]][col[m]] = t;
@@ -563,14 +771,14 @@ __global__ void __launch_bounds__(F3_NT) k_stage3(Stage3Args<T> A) {
             const int gi = i0 + row[m], gj = j0 + col[m];
             const int64_t idx = (int64_t)gi * Nx + gj;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) A.kout[q][idx] = kv[S0 + q][m];
+            for (int q = 0; q < 3; ++q) kout[q][idx] = kv[S0 + q][m];
             if (FINAL) {
-                A.ynew[idx] = tq[m];
+                ynew[idx] = tq[m];
                 if (gi >= A.row_lo && gi < A.row_hi) {
-                    T e = A.he[6] * kv[S0 + 2][m];
+                    T e = he[6] * kv[S0 + 2][m];
 #pragma unroll
-                    for (int j = 0; j < S0 + 2; ++j) e += A.he[j] * kv[j][m];
-                    const T sc = A.atol + fmax(fabs(yv[m]), fabs(tq[m])) * A.rtol;
+                    for (int j = 0; j < S0 + 2; ++j) e += he[j] * kv[j][m];
+                    const T sc = atol_s + fmax(fabs(yv[m]), fabs(tq[m])) * A.rtol;
                     const T qq = e / sc;
                     esum += (double)qq * (double)qq;
                     ymax = fmax(ymax, (double)fabs(tq[m]));
@@ -602,28 +810,30 @@ __global__ void __launch_bounds__(F3_NT) k_stage3(Stage3Args<T> A) {
 // Dense output + direction field for every t_eval point of one accepted step, in one pass: the quartic
 // interpolant's coefficients Q = K^T P (scipy rk.py:178-180) stay in registers, each slice's phi goes through a
 // double-buffered LDS tile, and vels (optimals.py:168-186) writes the slice of the (padded) direction field.
-#define OUT_MAXS 16
 template <typename T>
 struct OutArgs {
-    const T* y;
-    const T* k[6];          // K0, K2, K3, K4, K5, K6 (row 1 of P is zero)
-    T p[6][4];              // the matching rows of P
-    T hx[OUT_MAXS][4];      // h*x, h*x^2, h*x^3, h*x^4 per slice
-    T* vx[OUT_MAXS];
-    T* vy[OUT_MAXS];
-    double* keep[OUT_MAXS];
-    double unscale;
-    T lim_s, lim, mu, inv2dx, inv2dy;
-    int ns, Ny, Nx;
+    const HjbCtl<T>* ctl;   // the accepted step: buffer roles, t, h, its t_eval range [k_lo, k_hi), 2^expo
+    T* Y[2];
+    T* KX[2];
+    T* KM[5];
+    T p[6][4];              // rows 0, 2, 3, 4, 5, 6 of P (row 1 is zero)
+    T* vx_base;             // direction field (nslice, Ny, Nx): slice nt - 1 - k  <->  t_eval[k]
+    T* vy_base;
+    size_t slice_elems;
+    double* keep_base;      // audit: phi(t_eval[k]) unscaled, float64, slot keep_slot[k] (or NULL)
+    const int32_t* keep_slot;
+    T lim, mu, inv2dx, inv2dy;
+    int Ny, Nx;
 };
 
 template <typename T>
-__device__ __forceinline__ void interp_coeffs(const OutArgs<T>& A, int64_t idx, int n, T* yq, T (*Q)[4]) {
+__device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* const (&k)[6], const T (&P)[6][4],
+                                              int64_t idx, int n, T* yq, T (*Q)[4]) {
     // n = 4: one vector of cells, n = 1: a single cell
     if (n == 4) {
-        V4<T> yv = ld4(A.y + idx), kk[6];
+        V4<T> yv = ld4(y + idx), kk[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) kk[j] = ld4(A.k[j] + idx);
+        for (int j = 0; j < 6; ++j) kk[j] = ld4(k[j] + idx);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             yq[q] = yv.v[q];
@@ -631,20 +841,20 @@ __device__ __forceinline__ void interp_coeffs(const OutArgs<T>& A, int64_t idx, 
             for (int pp = 0; pp < 4; ++pp) {
                 T acc = (T)0;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc += kk[j].v[q] * A.p[j][pp];
+                for (int j = 0; j < 6; ++j) acc += kk[j].v[q] * P[j][pp];
                 Q[q][pp] = acc;
             }
         }
     } else {
-        yq[0] = A.y[idx];
+        yq[0] = y[idx];
         T kk[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) kk[j] = A.k[j][idx];
+        for (int j = 0; j < 6; ++j) kk[j] = k[j][idx];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             T acc = (T)0;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc += kk[j] * A.p[j][pp];
+            for (int j = 0; j < 6; ++j) acc += kk[j] * P[j][pp];
             Q[0][pp] = acc;
         }
     }
@@ -653,6 +863,14 @@ __device__ __forceinline__ void interp_coeffs(const OutArgs<T>& A, int64_t idx, 
 template <typename T>
 __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
     __shared__ alignas(16) T tile[2][HT_LH][HT_LS];
+    const HjbCtl<T>* __restrict__ ctl = A.ctl;
+    if (!ctl->accepted) return;                     // a rejected attempt (or one past the end) has nothing to emit
+    const int par = ctl->out_parity;
+    const int k_lo = ctl->k_lo, k_hi = ctl->k_hi, nt = ctl->nt;
+    const double t0 = ctl->out_t, hh = ctl->out_hh, unscale = ctl->out_unscale, te_step = ctl->te_step, Tf = ctl->Tfinal;
+    const T lim_s = ctl->out_lim_s;
+    const T* __restrict__ y = A.Y[par];
+    const T* const kk[6] = {A.KX[par], A.KM[1], A.KM[2], A.KM[3], A.KM[4], A.KX[par ^ 1]};     // K0, K2 .. K5, K6
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int Ny = A.Ny, Nx = A.Nx;
     int i0, j0, logical;
@@ -660,24 +878,35 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
     const int gi = i0 + ry, gj = j0 + 4 * cx;
     const bool valid = gi < Ny && gj < Nx;
     const int64_t idx = (int64_t)gi * Nx + gj;
+    const int64_t ncell = (int64_t)Ny * Nx;
     T yq[4], Q[4][4], hy[4], hQ[4][4];
-    if (valid) interp_coeffs(A, idx, 4, yq, Q);
+    if (valid) interp_coeffs<T>(y, kk, A.p, idx, 4, yq, Q);
     const HaloRole hr = halo_role(i0, j0, Ny, Nx);
     const int hn = (hr.kind == 1 || hr.kind == 2) ? 4 : (hr.kind >= 3 ? 1 : 0);
-    if (hn) interp_coeffs(A, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
-    auto clip = [&](T v) { return (v > A.lim_s) ? v : ((v < A.lim_s) ? A.lim_s : (T)0); };
-    for (int s = 0; s < A.ns; ++s) {
-        const int buf = s & 1;
-        const T h1 = A.hx[s][0], h2 = A.hx[s][1], h3 = A.hx[s][2], h4 = A.hx[s][3];
+    if (hn) interp_coeffs<T>(y, kk, A.p, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
+    auto clip = [&](T v) { return (v > lim_s) ? v : ((v < lim_s) ? lim_s : (T)0); };
+    int it = 0;
+    for (int k = k_lo; k < k_hi; ++k) {
+        // t_eval[k] <-> slice nt - 1 - k of the field; k = 0 (phi = 1 at t = T) is never used (optimals.py:200-204)
+        const bool want_v = k >= 1;
+        double* keep = (A.keep_slot && A.keep_slot[k] >= 0) ? A.keep_base + (size_t)A.keep_slot[k] * ncell : nullptr;
+        if (!want_v && !keep) continue;
+        const double te = (k == nt - 1) ? 0.0 : (double)k * te_step + Tf;
+        const double x = (te - t0) / hh;
+        const T h1 = (T)(hh * x), h2 = (T)(hh * (x * x)), h3 = (T)(hh * (x * x * x)), h4 = (T)(hh * (x * x * x * x));
+        T* vxs = want_v ? A.vx_base + (size_t)(nt - 1 - k) * A.slice_elems : nullptr;
+        T* vys = want_v ? A.vy_base + (size_t)(nt - 1 - k) * A.slice_elems : nullptr;
+        const int buf = it & 1;
+        ++it;
         V4<T> ph;
         if (valid) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 ph.v[q] = yq[q] + (((Q[q][0] * h1 + Q[q][1] * h2) + Q[q][2] * h3) + Q[q][3] * h4);
             st4(&tile[buf][ry + 1][4 + 4 * cx], ph);
-            if (A.keep[s]) {
+            if (keep) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) A.keep[s][idx + q] = (double)ph.v[q] * A.unscale;
+                for (int q = 0; q < 4; ++q) keep[idx + q] = (double)ph.v[q] * unscale;
             }
         }
         if (hn == 4) {
@@ -690,7 +919,7 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
             tile[buf][hr.li][hr.lj] = hy[0] + (((hQ[0][0] * h1 + hQ[0][1] * h2) + hQ[0][2] * h3) + hQ[0][3] * h4);
         }
         __syncthreads();
-        if (A.vx[s] && valid) {
+        if (vxs && valid) {
             const V4<T> up = ld4(&tile[buf][ry][4 + 4 * cx]), dn = ld4(&tile[buf][ry + 2][4 + 4 * cx]);
             const T lft = tile[buf][ry + 1][3 + 4 * cx], rgt = tile[buf][ry + 1][8 + 4 * cx];
             V4<T> ox, oy;
@@ -707,9 +936,49 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
                 ox.v[q] = border ? (T)0 : vxo;
                 oy.v[q] = border ? (T)0 : vyo;
             }
-            st4_nt(A.vx[s] + idx, ox);
-            st4_nt(A.vy[s] + idx, oy);
+            st4_nt(vxs + idx, ox);
+            st4_nt(vys + idx, oy);
         }
+    }
+}
+
+// range management and halo staging of the device-controlled solve: which buffers hold y / K6 is decided by k_control
+template <typename T>
+__global__ void k_scale_ctl(const HjbCtl<T>* __restrict__ ctl, T* Y0, T* Y1, T* K0, T* K1, int64_t n) {
+    if (!ctl->do_scale) return;
+    const int par = ctl->parity;                    // the roles AFTER the accepted step: y = Y[par], FSAL slot = KX[par]
+    const T sc = ctl->scale;
+    T* a = par ? Y1 : Y0;
+    T* b = par ? K1 : K0;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        a[i] *= sc;
+        b[i] *= sc;
+    }
+}
+
+// After an attempt of a row-block solve: the `halo` owned rows next to each neighbour of (y, K0-to-be) go to the staging
+// buffers (dtype (2, halo, Nx) each) and, after the caller's exchange, the neighbours' rows come back into the halo rows.
+// After a rejected attempt the exchange moves rows that are already in place (every rank must still take part).
+template <typename T, bool PACK>
+__global__ void k_halo_stage(const HjbCtl<T>* __restrict__ ctl, T* Y0, T* Y1, T* K0, T* K1, T* up, T* dn, size_t lo,
+                             size_t hi, size_t hn, int has_up, int has_dn) {
+    const int par = ctl->parity;
+    T* y = par ? Y1 : Y0;
+    T* k = par ? K1 : K0;
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 4 * hn) return;
+    const int which = (int)(g / hn);
+    const size_t e = g % hn;
+    T* arr = (which & 1) ? k : y;
+    if (which < 2) {
+        if (!has_up) return;
+        if (PACK) up[(which & 1) * hn + e] = arr[lo + e];
+        else arr[lo - hn + e] = up[(which & 1) * hn + e];
+    } else {
+        if (!has_dn) return;
+        if (PACK) dn[(which & 1) * hn + e] = arr[hi - hn + e];
+        else arr[hi + e] = dn[(which & 1) * hn + e];
     }
 }
 
@@ -878,96 +1147,289 @@ void launch_stages_fused(Solver<T>& S, double hh, T atol_s, T rtol) {
     hipLaunchKernelGGL((k_stage<T, 5, true>), dim3(S.fused_grid()), dim3(256), 0, S.s, A);
 }
 
-// the six RHS evaluations of one RK attempt as two launches of three stages each (k_stage3)
+// ---- the solve with the device-resident controller (hjb variant 0; single GPU and row blocks) ---------------------
+// Host part: SciPy's select_initial_step (three reductions, read back once each), then attempts are ENQUEUED -- stage
+// launch A, stage launch B, [row blocks: local reduction, the caller's all-gather], k_control, [row blocks: pack, the
+// caller's halo exchange, unpack], k_out, k_scale_ctl -- a few ahead of the device, never waiting for one: the host
+// watches the controller's tick count in a pinned mailbox only to stop when `done` is posted.  In a row-block solve the
+// ranks must enqueue the same number of attempts (every attempt holds collectives), so there the host synchronises
+// the stream once per burst of attempts and all ranks read the same `done` (their controllers are bit-identical).
 template <typename T>
-int launch_stages_fused3(Solver<T>& S, double hh, T atol_s, T rtol) {
-    Stage3Args<T> A;
-    memset(&A, 0, sizeof(A));
-    A.y = S.y;
-    A.coef = S.coef;
-    A.Ny = S.Ny;
-    A.Nx = S.Nx;
-    A.a_lap = S.a_lap;
-    A.atol = atol_s;
-    A.rtol = rtol;
-    A.partial = S.h->red_partial;
-    A.row_lo = S.sh ? S.sh->own_lo : 0;
-    A.row_hi = S.sh ? S.sh->own_hi : S.Ny;
-    const int nb = ((S.Nx + F3_X - 1) / F3_X) * ((S.Ny + F3_Y - 1) / F3_Y);
-    const dim3 grid(8 * ((nb + 7) / 8));
-    // launch A: stages 1..3 from K0
-    A.kin[0] = S.K[0];
-    for (int q = 0; q < 3; ++q) {
-        for (int j = 0; j < 6; ++j) A.c[q][j] = j < 1 + q ? (T)(RK_A[1 + q][j] * hh) : (T)0;
-        A.kout[q] = S.K[1 + q];
-    }
-    hipLaunchKernelGGL((k_stage3<T, 1, false>), grid, dim3(F3_NT), 0, S.s, A);
-    // launch B: stages 4, 5 and y_new / K6 / error from K0..K3
-    for (int j = 0; j < 4; ++j) A.kin[j] = S.K[j];
-    for (int q = 0; q < 2; ++q) {
-        for (int j = 0; j < 6; ++j) A.c[q][j] = j < 4 + q ? (T)(RK_A[4 + q][j] * hh) : (T)0;
-        A.kout[q] = S.K[4 + q];
-    }
-    for (int j = 0; j < 6; ++j) A.c[2][j] = (T)(RK_B[j] * hh);
-    A.kout[2] = S.K[6];
-    A.ynew = S.ynew;
-    for (int j = 0; j < 7; ++j) A.he[j] = (T)(RK_E[j] * hh);
-    hipLaunchKernelGGL((k_stage3<T, 4, true>), grid, dim3(F3_NT), 0, S.s, A);
-    return nb;
-}
-
-// dense output of every t_eval point in (t_new, t] + direction field slices, <= OUT_MAXS slices per launch
-template <typename T>
-int emit_slices_fused(Solver<T>& S, const std::vector<double>& te, int nt, int& k_next, double t, double t_new,
-                      double hh, const std::vector<int>& keep_slot, double* phi_keep, void* vx_out, void* vy_out,
-                      size_t slice_elems, int expo, oc_hjb_stats& stats) {
-    const oc_config& c = S.h->cfg;
+int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, void* vx_out, void* vy_out,
+                  const int32_t* keep_idx, int32_t n_keep, double* phi_keep, double* t_steps, int32_t t_steps_cap,
+                  oc_hjb_stats* st, hipStream_t s, const oc_hjb_shard* sh) {
+    const oc_config& c = h->cfg;
+    Solver<T> S;
+    S.h = h;
+    S.s = s;
+    S.sh = sh;
+    S.Ny = sh ? sh->Ny_local : c.Ny;
+    S.Nx = c.Nx;
+    S.n = (int64_t)S.Ny * S.Nx;
+    const int own_lo = sh ? sh->own_lo : 0, own_hi = sh ? sh->own_hi : S.Ny;
+    const int64_t own_off = (int64_t)own_lo * S.Nx, n_own = (int64_t)(own_hi - own_lo) * S.Nx;
+    const double n_rms = sh ? (double)sh->Ny_global * S.Nx : (double)S.n;
+    S.coef = (const T*)coef_v;
+    S.a_lap = (T)(-0.5 * c.sigma * c.sigma / (c.dx * c.dy));
+    int rc = S.alloc();
+    if (rc) return rc;
     const int64_t n = S.n;
-    while (k_next < nt && te[k_next] >= t_new) {
-        OutArgs<T> A;
-        memset(&A, 0, sizeof(A));
-        A.y = S.y;
-        const int rows[6] = {0, 2, 3, 4, 5, 6};
-        for (int q = 0; q < 6; ++q) {
-            A.k[q] = S.K[rows[q]];
-            for (int p = 0; p < 4; ++p) A.p[q][p] = (T)RK_P[rows[q]][p];
-        }
-        A.unscale = std::ldexp(1.0, expo);
-        A.lim_s = (T)(c.lim * std::ldexp(1.0, -expo));
-        A.lim = (T)c.lim;
-        A.mu = (T)c.mu;
-        A.inv2dx = (T)(1.0 / (2 * c.dx));
-        A.inv2dy = (T)(1.0 / (2 * c.dy));
-        A.Ny = S.Ny;
-        A.Nx = S.Nx;
-        int ns = 0, nv = 0;
-        while (ns < OUT_MAXS && k_next < nt && te[k_next] >= t_new) {
-            int k = k_next++;
-            bool want_v = (k >= 1), want_keep = keep_slot[k] >= 0;
-            if (!want_v && !want_keep) continue;
-            double x = (te[k] - t) / hh;
-            double xp = x;
-            for (int p = 0; p < 4; ++p) {
-                A.hx[ns][p] = (T)(hh * xp);
-                xp *= x;
-            }
-            A.keep[ns] = want_keep ? phi_keep + (size_t)keep_slot[k] * n : nullptr;
-            if (want_v) {
-                int sidx = nt - 1 - k;
-                A.vx[ns] = (T*)vx_out + (size_t)sidx * slice_elems;
-                A.vy[ns] = (T*)vy_out + (size_t)sidx * slice_elems;
-                ++nv;
-            }
-            ++ns;
-        }
-        if (ns == 0) continue;
-        A.ns = ns;
-        oc_timer_begin(S.h, "hjb_out", S.s);
-        hipLaunchKernelGGL(k_out<T>, dim3(S.fused_grid()), dim3(256), 0, S.s, A);
-        // algorithmic bytes: read y_old + 6 stage arrays once, write 2 field components per slice
-        oc_timer_end(S.h, "hjb_out", S.s, sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2)));
-        stats.n_slices_written += nv;
+    const double rtol = c.rtol, atol0 = c.atol;
+    const int RB = 1024;
+    oc_hjb_stats stats;
+    memset(&stats, 0, sizeof(stats));
+    stats.h_min = 1e300;
+    if (nt <= 1) {   // linspace(T,0,nt) has no slice that the fill loop would use (optimals.py:200)
+        if (st) *st = stats;
+        return OC_OK;
     }
+    // ---- device-side bookkeeping (allocated once per handle)
+    const int T_CAP = 65536, LOG_CAP = 65536;
+    if (!h->hjb_ctl) {
+        OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 4096));
+        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_tsteps, sizeof(double) * T_CAP));
+        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_log, sizeof(int32_t) * LOG_CAP));
+    }
+    static_assert(sizeof(HjbCtl<T>) <= 4096, "controller block too large");
+    HjbCtl<T>* ctl = (HjbCtl<T>*)h->hjb_ctl;
+    int32_t* keep_slot_dev = nullptr;
+    if (n_keep > 0) {
+        std::vector<int32_t> slot(nt, -1);
+        for (int q = 0; q < n_keep; ++q) {
+            OC_REQUIRE(keep_idx[q] >= 0 && keep_idx[q] < nt, "keep index out of range");
+            slot[keep_idx[q]] = q;
+        }
+        OC_HIP_CHECK(hipMalloc((void**)&keep_slot_dev, sizeof(int32_t) * nt));
+        OC_HIP_CHECK(hipMemcpy(keep_slot_dev, slot.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice));
+    }
+    struct Guard {                      // the keep table lives for this call only
+        int32_t* p;
+        ~Guard() { if (p) (void)hipFree(p); }
+    } guard{keep_slot_dev};
+
+    // buffers: Y[0] = y, Y[1] = y_new; KX[0] = K[0], KX[1] = K[6] (FSAL pair); KM = K1 .. K5
+    T* Y[2] = {S.y, S.ynew};
+    T* KX[2] = {S.K[0], S.K[6]};
+    hipLaunchKernelGGL(k_fill<T>, S.g1(), dim3(256), 0, s, S.y, (T)1, n);
+    const double t0 = Tfinal, tf = 0.0, direction = -1.0;
+    S.rhs(S.y, KX[0]);                  // f0 = K0 of the first step
+    // ---- select_initial_step (scipy common.py:68-134), order = 4
+    double h_abs;
+    {
+        double interval = std::fabs(tf - t0);
+        double s0, s1, s2;
+        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, S.y + own_off, (const T*)nullptr,
+                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
+        if ((rc = S.reduce(&s0, nullptr))) return rc;
+        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, KX[0] + own_off, (const T*)nullptr,
+                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
+        if ((rc = S.reduce(&s1, nullptr))) return rc;
+        double d0 = std::sqrt(s0) / std::sqrt(n_rms), d1 = std::sqrt(s1) / std::sqrt(n_rms);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = std::min(h0, interval);
+        Lin8<T> L;
+        L.n = 1;
+        L.k[0] = KX[0];
+        L.c[0] = (T)(h0 * direction);
+        hipLaunchKernelGGL(k_lincomb<T>, S.g1(), dim3(256), 0, s, S.y, L, S.ytmp, n);
+        S.rhs(S.ytmp, S.K[1]);
+        hipLaunchKernelGGL((k_norm_scaled<T, 1>), dim3(RB), dim3(256), 0, s, S.K[1] + own_off, KX[0] + own_off,
+                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
+        if ((rc = S.reduce(&s2, nullptr))) return rc;
+        double d2 = std::sqrt(s2) / std::sqrt(n_rms) / h0;
+        double h1;
+        if (d1 <= 1e-15 && d2 <= 1e-15)
+            h1 = std::max(1e-6, h0 * 1e-3);
+        else
+            h1 = std::pow(0.01 / std::max(d1, d2), 1.0 / 5.0);
+        h_abs = std::min(std::min(100 * h0, h1), interval);
+    }
+    stats.h_abs0 = h_abs;
+    // ---- the controller's initial state
+    HjbCtl<T> hc;
+    memset(&hc, 0, sizeof(hc));
+    hc.t = t0; hc.tf = tf; hc.Tfinal = Tfinal; hc.h_abs = h_abs; hc.rtol = rtol; hc.atol0 = atol0; hc.n_rms = n_rms;
+    hc.te_step = (0.0 - Tfinal) / (double)(nt - 1);
+    hc.lim = c.lim;
+    hc.h_min = 1e300;
+    hc.nt = nt;
+    hc.is_f32 = sizeof(T) == 4 ? 1 : 0;
+    ctl_prepare_attempt(hc, true);
+    OC_HIP_CHECK(hipMemcpyAsync(ctl, &hc, sizeof(hc), hipMemcpyHostToDevice, s));
+    OC_HIP_CHECK(hipStreamSynchronize(s));          // (hc lives on this stack frame)
+    volatile double* mb = h->red_host + 2 * OC_MAX_WORLD + 4;
+    mb[0] = mb[1] = mb[2] = mb[3] = 0.0;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    double* mb_dev = (double*)h->red_mailbox_dev + 4;
+
+    // ---- kernel arguments (fixed for the whole solve)
+    Stage3Args<T> SA;
+    memset(&SA, 0, sizeof(SA));
+    SA.ctl = ctl;
+    SA.Y[0] = Y[0]; SA.Y[1] = Y[1];
+    SA.KX[0] = KX[0]; SA.KX[1] = KX[1];
+    for (int j = 0; j < 5; ++j) SA.KM[j] = S.K[1 + j];
+    SA.coef = S.coef;
+    SA.rtol = (T)rtol;
+    SA.a_lap = S.a_lap;
+    SA.partial = h->red_partial;
+    SA.Ny = S.Ny;
+    SA.Nx = S.Nx;
+    SA.row_lo = own_lo;
+    SA.row_hi = own_hi;
+    const int nb3 = ((S.Nx + F3_X - 1) / F3_X) * ((S.Ny + F3_Y - 1) / F3_Y);
+    const dim3 grid3(8 * ((nb3 + 7) / 8));
+    OutArgs<T> OA;
+    memset(&OA, 0, sizeof(OA));
+    OA.ctl = ctl;
+    OA.Y[0] = Y[0]; OA.Y[1] = Y[1];
+    OA.KX[0] = KX[0]; OA.KX[1] = KX[1];
+    for (int j = 0; j < 5; ++j) OA.KM[j] = S.K[1 + j];
+    {
+        const int rows[6] = {0, 2, 3, 4, 5, 6};
+        for (int q = 0; q < 6; ++q)
+            for (int pp = 0; pp < 4; ++pp) OA.p[q][pp] = (T)RK_P[rows[q]][pp];
+    }
+    OA.vx_base = (T*)vx_out;
+    OA.vy_base = (T*)vy_out;
+    OA.slice_elems = (size_t)S.Ny * S.Nx;
+    OA.keep_base = phi_keep;
+    OA.keep_slot = keep_slot_dev;
+    OA.lim = (T)c.lim;
+    OA.mu = (T)c.mu;
+    OA.inv2dx = (T)(1.0 / (2 * c.dx));
+    OA.inv2dy = (T)(1.0 / (2 * c.dy));
+    OA.Ny = S.Ny;
+    OA.Nx = S.Nx;
+    const size_t lo = (size_t)own_lo * S.Nx, hi = (size_t)own_hi * S.Nx, hn = sh ? (size_t)sh->halo * S.Nx : 0;
+    const bool halos = sh && (sh->has_up || sh->has_dn);
+
+    // profiling: events around the stage pair and around k_out of every attempt; which of them were real / accepted is
+    // known only afterwards (att_log), so the sums are formed after the solve
+    const bool prof = h->profiling && (h->prof_mode & 1);
+    std::vector<hipEvent_t>& ev = h->hjb_events;
+    size_t ev_used = 0;
+    auto event = [&]() -> hipEvent_t {
+        if (ev_used == ev.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            ev.push_back(e);
+        }
+        hipEvent_t e = ev[ev_used++];
+        (void)hipEventRecord(e, s);
+        return e;
+    };
+    int enq = 0;
+    auto enqueue_attempt = [&]() -> int {
+        if (prof) event();
+        hipLaunchKernelGGL((k_stage3<T, 1, false>), grid3, dim3(F3_NT), 0, s, SA);
+        hipLaunchKernelGGL((k_stage3<T, 4, true>), grid3, dim3(F3_NT), 0, s, SA);
+        if (prof) event();
+        if (sh) {
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, nb3, sh->red_local);
+            if (sh->allgather_red(sh->user) != 0) {
+                oc_set_error("hjb_solve_rows: the allgather_red callback failed");
+                return OC_ERR_STATE;
+            }
+            hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(1024), 0, s, ctl, (const double*)sh->red_all, sh->world,
+                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev);
+        } else {
+            hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(1024), 0, s, ctl, (const double*)h->red_partial, nb3,
+                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev);
+        }
+        if (halos) {
+            const dim3 gh((unsigned)((4 * hn + 255) / 256));
+            hipLaunchKernelGGL((k_halo_stage<T, true>), gh, dim3(256), 0, s, ctl, Y[0], Y[1], KX[0], KX[1],
+                               (T*)sh->send_up, (T*)sh->send_dn, lo, hi, hn, sh->has_up, sh->has_dn);
+            if (sh->exchange_halo(sh->user) != 0) {
+                oc_set_error("hjb_solve_rows: the exchange_halo callback failed");
+                return OC_ERR_STATE;
+            }
+            hipLaunchKernelGGL((k_halo_stage<T, false>), gh, dim3(256), 0, s, ctl, Y[0], Y[1], KX[0], KX[1],
+                               (T*)sh->recv_up, (T*)sh->recv_dn, lo, hi, hn, sh->has_up, sh->has_dn);
+        }
+        if (prof) event();
+        hipLaunchKernelGGL(k_out<T>, dim3(S.fused_grid()), dim3(256), 0, s, OA);
+        if (prof) event();
+        if (sizeof(T) == 4)
+            hipLaunchKernelGGL(k_scale_ctl<T>, S.g1(), dim3(256), 0, s, ctl, Y[0], Y[1], KX[0], KX[1], n);
+        ++enq;
+        return OC_OK;
+    };
+    const int BURST = sh ? 8 : 4, LAG = 6;
+    bool done = false;
+    while (!done) {
+        for (int b = 0; b < BURST; ++b)
+            if ((rc = enqueue_attempt())) return rc;
+        if (enq > LOG_CAP - 2 * BURST) {
+            oc_set_error("RK45: more than %d attempts", LOG_CAP);
+            (void)hipStreamSynchronize(s);
+            return OC_ERR_SOLVER;
+        }
+        if (sh) {
+            OC_HIP_CHECK(hipStreamSynchronize(s));
+        } else {
+            // let the device catch up to within LAG attempts of what is enqueued (or finish)
+            for (long spin = 0;; ++spin) {
+                if (mb[1] != 0.0 || mb[0] >= (double)(enq - LAG)) break;
+                if ((spin & 4095) == 4095 && hipStreamQuery(s) == hipSuccess) break;
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        done = mb[1] != 0.0;
+        if (!done && !sh && hipStreamQuery(s) == hipSuccess && mb[0] < (double)enq) {
+            // the stream drained but the mailbox did not move: mapped memory is not visible -> read the device copy
+            OC_HIP_CHECK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
+            done = hc.done != 0;
+        }
+    }
+    OC_HIP_CHECK(hipStreamSynchronize(s));
+    OC_HIP_CHECK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
+    if (hc.status != 0) {
+        if (hc.status == OC_ERR_SOLVER) oc_set_error("RK45: step size too small at t=%g", hc.t);
+        else oc_set_error("RK45: NaN error norm at t=%g (state overflow?)", hc.t);
+        return OC_ERR_SOLVER;
+    }
+    const int n_real = hc.n_attempt;
+    std::vector<int32_t> log((size_t)std::min(enq, LOG_CAP));
+    if (!log.empty()) OC_HIP_CHECK(hipMemcpy(log.data(), h->hjb_log, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost));
+    if (prof) {
+        oc_timer& ts = h->timers["hjb_stage"];
+        oc_timer& to = h->timers["hjb_out"];
+        for (int a = 0; a < enq && (size_t)(4 * a + 3) < ev_used && (size_t)a < log.size(); ++a) {
+            float e1 = 0.f, e2 = 0.f;
+            (void)hipEventElapsedTime(&e1, ev[4 * a], ev[4 * a + 1]);
+            (void)hipEventElapsedTime(&e2, ev[4 * a + 2], ev[4 * a + 3]);
+            if (log[a] & 1) {           // a real attempt: 16 array passes (launch A 6, launch B 10)
+                ts.add_ms += e1;
+                ts.add_n += 1;
+                ts.bytes += 16.0 * sizeof(T) * (double)n;
+            }
+            if (log[a] & 2) {           // accepted: k_out read y + 6 stage arrays once, wrote 2 components per slice
+                const int nv = log[a] >> 8;
+                to.add_ms += e2;
+                to.add_n += 1;
+                to.bytes += sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2));
+                stats.n_slices_written += nv;
+            }
+        }
+    } else {
+        for (size_t a = 0; a < log.size(); ++a)
+            if (log[a] & 2) stats.n_slices_written += log[a] >> 8;
+    }
+    if (t_steps && t_steps_cap > 0) {
+        t_steps[0] = t0;
+        const int m = std::min(hc.n_tsteps, t_steps_cap - 1);
+        if (m > 0) OC_HIP_CHECK(hipMemcpy(t_steps + 1, h->hjb_tsteps, sizeof(double) * m, hipMemcpyDeviceToHost));
+    }
+    stats.nfev = S.nfev + 6 * n_real;
+    stats.n_attempt = n_real;
+    stats.n_accept = hc.n_accept;
+    stats.n_rescale = hc.n_rescale;
+    stats.h_min = hc.h_min;
+    stats.h_max = hc.h_max;
+    stats.final_exponent = hc.expo;
+    if (st) *st = stats;
     return OC_OK;
 }
 
@@ -997,7 +1459,10 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
     const double rtol = c.rtol, atol0 = c.atol;
     const int RB = 1024;
     const bool use_fused = (h->hjb_variant != 1) && (c.Nx % 4 == 0);   // vector kernels need 16-byte rows
-    if (sh && !use_fused) {
+    if (h->hjb_variant == 0 && use_fused)        // the default: three stages per launch, controller on the device
+        return hjb_solve_dev<T>(h, coef_v, Tfinal, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, t_steps, t_steps_cap,
+                                st, s, sh);
+    if (sh) {
         oc_set_error("hjb_solve_rows needs the fused kernels (Nx %% 4 == 0, hjb variant 0)");
         return OC_ERR_ARG;
     }
@@ -1089,10 +1554,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
             int nred = RB;
             double atol_s = atol0 * scale_of();
             oc_timer_begin(h, "hjb_stage", s);
-            if (use_fused && h->hjb_variant == 0) {
-                nred = launch_stages_fused3(S, hh, (T)atol_s, (T)rtol);
-                S.nfev += 6;
-            } else if (use_fused) {
+            if (use_fused) {
                 launch_stages_fused(S, hh, (T)atol_s, (T)rtol);
                 S.nfev += 6;
                 nred = S.fused_blocks();
@@ -1127,7 +1589,8 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                                    h->red_partial);
                 nred = RB;
             }
-            // algorithmic bytes of one attempt: 39 array passes
+            // bytes this variant is designed to move per attempt: one launch per stage = 39 array passes (the
+            // one-array-per-pass kernels move more; both are cross-check paths, the default is hjb_solve_dev)
             oc_timer_end(h, "hjb_stage", s, 39.0 * sizeof(T) * (double)n);
             double esum, ymax;
             if ((rc = S.reduce(&esum, &ymax, nred))) return rc;
@@ -1146,11 +1609,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                 // ---- row-block solve: refresh the halo rows of y_new and K6 (valid again `halo` rows deep)
                 if ((rc = S.exchange_halo())) return rc;
                 // ---- dense output for t_eval points in (t_new, t]  (scipy ivp.py:706-723)
-                if (use_fused) {
-                    if ((rc = emit_slices_fused(S, te, nt, k_next, t, t_new, hh, keep_slot, phi_keep, vx_out, vy_out,
-                                                slice_elems, expo, stats)))
-                        return rc;
-                } else {
+                {
                     while (k_next < nt && te[k_next] >= t_new) {
                         int k = k_next++;
                         bool want_v = (k >= 1);

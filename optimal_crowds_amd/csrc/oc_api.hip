@@ -71,6 +71,10 @@ extern "C" int oc_destroy(oc_handle* h) {
     (void)hipFree(h->red_partial);
     (void)hipFree(h->red_out);
     (void)hipHostFree(h->red_host);
+    (void)hipFree(h->hjb_ctl);
+    (void)hipFree(h->hjb_tsteps);
+    (void)hipFree(h->hjb_log);
+    for (hipEvent_t e : h->hjb_events) (void)hipEventDestroy(e);
     for (auto& w : h->wallmaps) {
         (void)hipFree(w.left);
         (void)hipFree(w.right);
@@ -142,6 +146,8 @@ extern "C" int oc_kernel_stats(oc_handle* h, const char* name, int64_t* launches
             ++n;
         }
         bytes = t.bytes;
+        ms += t.add_ms;
+        n += t.add_n;
     }
     if (launches) *launches = n;
     if (total_ms) *total_ms = ms;
@@ -154,6 +160,8 @@ extern "C" int oc_reset_kernel_stats(oc_handle* h) {
     for (auto& kv : h->timers) {
         kv.second.used = 0;
         kv.second.bytes = 0.0;
+        kv.second.add_ms = 0.0;
+        kv.second.add_n = 0;
     }
     return OC_OK;
 }

@@ -60,6 +60,8 @@ struct oc_timer {
     std::vector<hipEvent_t> ev;   // pairs (begin, end), reused after a reset
     size_t used = 0;
     double bytes = 0.0;
+    double add_ms = 0.0;          // launches whose event times the caller resolved itself (hjb_solve_dev)
+    int64_t add_n = 0;
 };
 
 struct oc_handle {
@@ -78,6 +80,10 @@ struct oc_handle {
     void* red_mailbox_dev = nullptr; // device address of the mailbox
     long long red_seq = 0;
     int32_t red_blocks = 0;
+    void* hjb_ctl = nullptr;         // device-resident step controller (hjb.hip: HjbCtl), accepted step times, attempt log
+    double* hjb_tsteps = nullptr;
+    int32_t* hjb_log = nullptr;
+    std::vector<hipEvent_t> hjb_events;
     // ---- per-key data
     std::vector<oc_field_desc> fields;
     std::vector<oc_wallmap> wallmaps;
