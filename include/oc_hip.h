@@ -198,12 +198,15 @@ int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t simu_step,
  * with the same arguments.  Rank r computes the pair forces and the wall forces of its contiguous share of the tiles
  * (against all agents) and the desired velocities of the agents whose floor-field rows it holds (oc_set_field_rows;
  * with oc_set_field every rank holds everything and rank 0 answers), writes them -- zeros elsewhere -- into `xchg`
- * (float64, 6 * oc_padded_agents(N) values, caller-owned), calls `allreduce_sum(user, xchg, count)`, which must SUM
+ * (float64, oc_xchg_doubles(N) = 6 * oc_padded_agents(N) + OC_MAX_WORLD values, caller-owned: three double2 per slot,
+ * then one IndexError-band word per rank), calls `allreduce_sum(user, xchg, count)`, which must SUM
  * the buffer over the ranks in place on `stream` (RCCL all-reduce; every element has one non-zero contribution, so the
  * result does not depend on the reduction order), and then every rank finishes ALL agents from the reduced buffer:
- * the replicated states stay bit-identical without another exchange.  counters[1] (IndexError band) is the local
- * rank's view. */
+ * the replicated states stay bit-identical without another exchange, and counters[1] (IndexError band) is the same on
+ * every rank.  A key whose field this rank does not hold (no oc_set_field / oc_set_field_rows for it: keys dealt to
+ * different ranks, SURVEY 8e "partition by key first") is answered by the rank(s) that do. */
 int64_t oc_padded_agents(int32_t N);
+int64_t oc_xchg_doubles(int32_t N);
 int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise, uint64_t seed,
                          int32_t* counters, int32_t rank, int32_t world, double* xchg,
                          int (*allreduce_sum)(void* user, double* buf, int64_t count), void* user, void* stream);

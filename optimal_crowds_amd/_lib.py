@@ -96,6 +96,7 @@ SIGNATURES = {
     "oc_gcfm_step_sequential": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64,
                                           C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "oc_padded_agents": (C.c_int64, [C.c_int32]),
+    "oc_xchg_doubles": (C.c_int64, [C.c_int32]),
     "oc_gcfm_step_sharded": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.c_int32, C.c_int32, C.c_void_p, ALLREDUCE_CB, C.c_void_p, C.c_void_p]),
     "oc_run_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),

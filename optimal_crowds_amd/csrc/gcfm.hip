@@ -1199,7 +1199,8 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
 // bound the round's independence rests on (a larger move raises seq_ctl[4]).
 template <bool SEQ>
 __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const double* __restrict__ rect_tab, int nkeys,
-                                               StepArgs A, int seq_round, double seq_margin) {
+                                               StepArgs A, int seq_round, double seq_margin,
+                                               const double* __restrict__ err_slots, int n_err_slots) {
     __shared__ double l_rect[RECT_KEYS_LDS * RECT_TAB];
     const Snap& C = S.snap;
     const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
@@ -1216,7 +1217,13 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     const PDK dk = S.pdk[k];
     // (needed only at the very end, by lane 0: fetched with the rest so that the tail holds no memory round trip)
     const double4 b0 = S.tile_box0[it];
-    const int err0 = (it == 0) ? S.ctrl[C_ERR + 8] : 0;
+    // IndexError-band flag of this step's lookups: the local word, or -- sharded step -- the ranks' words, which travelled
+    // with the exchange buffer so that EVERY rank raises (a lookup is answered by the rank that holds the field rows)
+    int err0 = 0;
+    if (it == 0) {
+        err0 = S.ctrl[C_ERR + 8];
+        for (int r = 0; r < n_err_slots; ++r) err0 = max(err0, (int)err_slots[r]);
+    }
     const double at0 = (act && A.agent_time) ? A.agent_time[i] : 0.0;
     double n0 = 0.0, n1 = 0.0;
     if (act) {      // noise: caller's standard normals, or Philox4x32-10 + Box-Muller (float32)
@@ -1791,10 +1798,15 @@ extern "C" int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out
     return OC_OK;
 }
 
+__global__ void k_err_publish(const int32_t* __restrict__ ctrl, double* __restrict__ slots, int rank) {
+    slots[rank] = (double)ctrl[C_ERR + 8];          // (the other ranks' slots stay zero for the sum)
+}
+
 // one step, or one rank's part of it: k_forces on the tiles of `share`, [the caller's sum over the ranks], k_finish
 static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmParams& P, int32_t simu_step,
                        const double* noise, uint64_t seed, int32_t* counters, TileShare share,
-                       int (*allreduce_sum)(void*, double*, int64_t), void* user, double* xchg, hipStream_t s) {
+                       int (*allreduce_sum)(void*, double*, int64_t), void* user, double* xchg, int rank,
+                       hipStream_t s) {
     StepArgs A;
     A.x = a->x; A.y = a->y; A.vx = a->vx; A.vy = a->vy;
     A.status = a->status;
@@ -1823,13 +1835,20 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
     oc_timer_end(h, "gcfm_forces", s);
     h->work_valid = share.by_work != 0;     // (a rank's share measures only its own tiles)
     h->work_tiles = S.ntiles;
-    if (allreduce_sum && allreduce_sum(user, xchg, 6 * (int64_t)S.Np) != 0) {
-        oc_set_error("oc_gcfm_step_sharded: the allreduce_sum callback failed");
-        return OC_ERR_STATE;
+    const double* err_slots = nullptr;
+    int n_err_slots = 0;
+    if (allreduce_sum) {
+        err_slots = xchg + 6 * (size_t)S.Np;
+        n_err_slots = OC_MAX_WORLD;
+        hipLaunchKernelGGL(k_err_publish, dim3(1), dim3(1), 0, s, S.ctrl, xchg + 6 * (size_t)S.Np, rank);
+        if (allreduce_sum(user, xchg, 6 * (int64_t)S.Np + OC_MAX_WORLD) != 0) {
+            oc_set_error("oc_gcfm_step_sharded: the allreduce_sum callback failed");
+            return OC_ERR_STATE;
+        }
     }
     oc_timer_begin(h, "gcfm_finish", s);
     hipLaunchKernelGGL(k_finish<false>, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
-                       (int)h->fields.size(), A, 0, 0.0);
+                       (int)h->fields.size(), A, 0, 0.0, err_slots, n_err_slots);
     oc_timer_end(h, "gcfm_finish", s);
     OC_HIP_CHECK(hipGetLastError());
     h->packed_valid = true;
@@ -1855,7 +1874,7 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
         if ((rc = repack(h, a, &S, P, s))) return rc;
     }
     const TileShare all = {0, S.ntiles, 1, 0};
-    return launch_step(h, a, S, P, simu_step, noise, seed, counters, all, nullptr, nullptr, nullptr, s);
+    return launch_step(h, a, S, P, simu_step, noise, seed, counters, all, nullptr, nullptr, nullptr, 0, s);
 }
 
 
@@ -1915,7 +1934,7 @@ extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t
         for (int b = 0; b < burst; ++b, ++rounds) {
             hipLaunchKernelGGL(k_seq_pairs, dim3(S.ntiles), dim3(64), 0, s, P, S, rounds, margin);
             hipLaunchKernelGGL((k_finish<true>), dim3(S.ntiles), dim3(64), 0, s, Pf, S, (const double*)h->rect_tab_dev,
-                               (int)h->fields.size(), A, rounds, margin);
+                               (int)h->fields.size(), A, rounds, margin, (const double*)nullptr, 0);
         }
         OC_HIP_CHECK(hipMemcpyAsync(ctl, S.seq_ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
         OC_HIP_CHECK(hipStreamSynchronize(s));
@@ -1968,6 +1987,8 @@ extern "C" int64_t oc_padded_agents(int32_t N) {
     return Np == 0 ? 64 : Np;
 }
 
+extern "C" int64_t oc_xchg_doubles(int32_t N) { return 6 * oc_padded_agents(N) + OC_MAX_WORLD; }
+
 extern "C" int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise,
                                     uint64_t seed, int32_t* counters, int32_t rank, int32_t world, double* xchg,
                                     int (*allreduce_sum)(void* user, double* buf, int64_t count), void* user,
@@ -1990,10 +2011,13 @@ extern "C" int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t si
     S.f_pair = (double2*)xchg;
     S.f_wall = S.f_pair + S.Np;
     S.des = S.f_wall + S.Np;
-    OC_HIP_CHECK(hipMemsetAsync(xchg, 0, sizeof(double) * 6 * (size_t)S.Np, s));
+    OC_HIP_CHECK(hipMemsetAsync(xchg, 0, sizeof(double) * (6 * (size_t)S.Np + OC_MAX_WORLD), s));
+    // who answers a lookup: with row blocks -- or with keys dealt to different ranks, where this rank holds no field of
+    // some key -- every rank walks all tiles and the holder of the field rows answers; with every field whole on every
+    // rank the tile's owner does
     bool rows = false;
-    for (const auto& f : h->fields) rows = rows || f.rows >= 0;
+    for (const auto& f : h->fields) rows = rows || f.rows >= 0 || f.vx == nullptr;
     const TileShare mine = {(int32_t)((int64_t)S.ntiles * rank / world), (int32_t)((int64_t)S.ntiles * (rank + 1) / world), 0,
                             rows ? 1 : 0};
-    return launch_step(h, a, S, P, simu_step, noise, seed, counters, mine, allreduce_sum, user, xchg, s);
+    return launch_step(h, a, S, P, simu_step, noise, seed, counters, mine, allreduce_sum, user, xchg, rank, s);
 }

@@ -53,6 +53,7 @@ __constant__ double dRK_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17
 // them: no host round trip per attempt (it cost 2-3 ms of a 16 ms solve), and in the row-block solve no host
 // synchronisation around the collectives.  The host only watches `ticks` / `done` in a pinned mailbox to know when to
 // stop enqueuing; attempts enqueued past the end find `done` set and return at once.
+#define HJB_MAXS 24
 template <typename T>
 struct HjbCtl {
     double t, tf, Tfinal, h_abs, rtol, atol0, n_rms, te_step, lim;
@@ -66,7 +67,13 @@ struct HjbCtl {
     int32_t accepted, out_parity, k_lo, k_hi, do_scale;     // decision of the last attempt
     int32_t n_attempt, n_accept, n_rescale, n_tsteps, ticks, is_f32;
     T cA[3][6], cB[3][6], he[7];        // h * a_sj of launch A (stages 1-3) and B (stages 4, 5, y_new); h * E_j
-    T atol_s, out_lim_s, scale;
+    T atol_s, out_lim_s;
+    // Range management without a pass over the arrays: after a step whose max |y_new| passed 2^64, y_new and K6 stay
+    // in memory as they are and the NEXT step multiplies them by `in_scale` (an exact power of two) as it loads them
+    // -- as y and K0, in its stage launches and in its k_out -- so everything it writes is in the new scale.
+    T in_scale, out_in_scale;
+    int32_t n_hx;                       // k_out's per-slice factors h x, h x^2, h x^3, h x^4 (0: more than HJB_MAXS slices,
+    T hx[HJB_MAXS][4];                  // computed in the kernel)
 };
 
 // first part of an attempt (rk.py:121-137): clamp the step, end time, coefficient tables
@@ -379,12 +386,23 @@ __global__ void __launch_bounds__(1024) k_control(HjbCtl<T>* __restrict__ ctl, c
             ++c.k_next;
         }
         c.k_hi = c.k_next;
+        c.n_hx = (c.k_hi - c.k_lo <= HJB_MAXS) ? c.k_hi - c.k_lo : 0;
+        for (int q = 0; q < c.n_hx; ++q) {      // dense output (rk.py:560-575): x = (t_eval - t_old) / h, powers 1..4
+            const double x = (ctl_te(c, c.k_lo + q) - c.t) / c.hh;
+            double xp = x;
+            for (int pp = 0; pp < 4; ++pp) {
+                c.hx[q][pp] = (T)(c.hh * xp);
+                xp *= x;
+            }
+        }
+        c.out_in_scale = c.in_scale;
+        c.in_scale = (T)1;
         c.t = c.t_new;
         ++c.n_accept;
         if (c.n_tsteps < t_cap) t_steps[c.n_tsteps++] = c.t;
         if (c.is_f32 && ymax > 0x1p64) {        // range management: keep max |y| near 2^32
             const int e = (int)floor(log2(ymax)) - 32;
-            c.scale = (T)ldexp(1.0, -e);
+            c.in_scale = (T)ldexp(1.0, -e);
             c.do_scale = 1;
             c.expo += e;
             ++c.n_rescale;
@@ -703,7 +721,7 @@ __global__ void __launch_bounds__(F3_NT) k_stage3(Stage3Args<T> A) {
         for (int j = 0; j < 6; ++j) cc[q][j] = FINAL ? ctl->cB[q][j] : ctl->cA[q][j];
 #pragma unroll
     for (int j = 0; j < 7; ++j) he[j] = FINAL ? ctl->he[j] : (T)0;
-    const T atol_s = ctl->atol_s;
+    const T atol_s = ctl->atol_s, in_scale = ctl->in_scale;
     const T* __restrict__ y = A.Y[par];
     const T* kin[4] = {A.KX[par], A.KM[0], A.KM[1], A.KM[2]};
     T* kout[3] = {FINAL ? A.KM[3] : A.KM[0], FINAL ? A.KM[4] : A.KM[1], FINAL ? A.KX[par ^ 1] : A.KM[2]};
@@ -729,9 +747,10 @@ __global__ void __launch_bounds__(F3_NT) k_stage3(Stage3Args<T> A) {
         for (int j = 0; j < S0 + 3; ++j) kv[j][m] = (T)0;
         if (in) {
             const int64_t idx = (int64_t)gi * Nx + gj;
-            yv[m] = y[idx];
+            yv[m] = y[idx] * in_scale;              // (1 unless the previous step ordered a rescale: exact)
 #pragma unroll
             for (int j = 0; j < S0; ++j) kv[j][m] = kin[j][idx];
+            kv[0][m] *= in_scale;
             if (ring[m] >= 1) cf[m] = A.coef[idx];
         }
     }
@@ -828,12 +847,17 @@ struct OutArgs {
 
 template <typename T>
 __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* const (&k)[6], const T (&P)[6][4],
-                                              int64_t idx, int n, T* yq, T (*Q)[4]) {
-    // n = 4: one vector of cells, n = 1: a single cell
+                                              T in_scale, int64_t idx, int n, T* yq, T (*Q)[4]) {
+    // n = 4: one vector of cells, n = 1: a single cell.  y and K0 (k[0]) carry the step's pending rescale (HjbCtl).
     if (n == 4) {
         V4<T> yv = ld4(y + idx), kk[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) kk[j] = ld4(k[j] + idx);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            yv.v[q] *= in_scale;
+            kk[0].v[q] *= in_scale;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             yq[q] = yv.v[q];
@@ -846,10 +870,11 @@ __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* 
             }
         }
     } else {
-        yq[0] = y[idx];
+        yq[0] = y[idx] * in_scale;
         T kk[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) kk[j] = k[j][idx];
+        kk[0] *= in_scale;
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             T acc = (T)0;
@@ -868,7 +893,8 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
     const int par = ctl->out_parity;
     const int k_lo = ctl->k_lo, k_hi = ctl->k_hi, nt = ctl->nt;
     const double t0 = ctl->out_t, hh = ctl->out_hh, unscale = ctl->out_unscale, te_step = ctl->te_step, Tf = ctl->Tfinal;
-    const T lim_s = ctl->out_lim_s;
+    const T lim_s = ctl->out_lim_s, in_scale = ctl->out_in_scale;
+    const int n_hx = ctl->n_hx;
     const T* __restrict__ y = A.Y[par];
     const T* const kk[6] = {A.KX[par], A.KM[1], A.KM[2], A.KM[3], A.KM[4], A.KX[par ^ 1]};     // K0, K2 .. K5, K6
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
@@ -880,10 +906,10 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
     const int64_t idx = (int64_t)gi * Nx + gj;
     const int64_t ncell = (int64_t)Ny * Nx;
     T yq[4], Q[4][4], hy[4], hQ[4][4];
-    if (valid) interp_coeffs<T>(y, kk, A.p, idx, 4, yq, Q);
+    if (valid) interp_coeffs<T>(y, kk, A.p, in_scale, idx, 4, yq, Q);
     const HaloRole hr = halo_role(i0, j0, Ny, Nx);
     const int hn = (hr.kind == 1 || hr.kind == 2) ? 4 : (hr.kind >= 3 ? 1 : 0);
-    if (hn) interp_coeffs<T>(y, kk, A.p, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
+    if (hn) interp_coeffs<T>(y, kk, A.p, in_scale, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
     auto clip = [&](T v) { return (v > lim_s) ? v : ((v < lim_s) ? lim_s : (T)0); };
     int it = 0;
     for (int k = k_lo; k < k_hi; ++k) {
@@ -891,9 +917,24 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
         const bool want_v = k >= 1;
         double* keep = (A.keep_slot && A.keep_slot[k] >= 0) ? A.keep_base + (size_t)A.keep_slot[k] * ncell : nullptr;
         if (!want_v && !keep) continue;
-        const double te = (k == nt - 1) ? 0.0 : (double)k * te_step + Tf;
-        const double x = (te - t0) / hh;
-        const T h1 = (T)(hh * x), h2 = (T)(hh * (x * x)), h3 = (T)(hh * (x * x * x)), h4 = (T)(hh * (x * x * x * x));
+        T h1, h2, h3, h4;
+        if (n_hx) {                                 // the controller's table (uniform loads)
+            h1 = ctl->hx[k - k_lo][0];
+            h2 = ctl->hx[k - k_lo][1];
+            h3 = ctl->hx[k - k_lo][2];
+            h4 = ctl->hx[k - k_lo][3];
+        } else {
+            const double te = (k == nt - 1) ? 0.0 : (double)k * te_step + Tf;
+            const double x = (te - t0) / hh;
+            double xp = x;
+            h1 = (T)(hh * xp);
+            xp *= x;
+            h2 = (T)(hh * xp);
+            xp *= x;
+            h3 = (T)(hh * xp);
+            xp *= x;
+            h4 = (T)(hh * xp);
+        }
         T* vxs = want_v ? A.vx_base + (size_t)(nt - 1 - k) * A.slice_elems : nullptr;
         T* vys = want_v ? A.vy_base + (size_t)(nt - 1 - k) * A.slice_elems : nullptr;
         const int buf = it & 1;
@@ -939,21 +980,6 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
             st4_nt(vxs + idx, ox);
             st4_nt(vys + idx, oy);
         }
-    }
-}
-
-// range management and halo staging of the device-controlled solve: which buffers hold y / K6 is decided by k_control
-template <typename T>
-__global__ void k_scale_ctl(const HjbCtl<T>* __restrict__ ctl, T* Y0, T* Y1, T* K0, T* K1, int64_t n) {
-    if (!ctl->do_scale) return;
-    const int par = ctl->parity;                    // the roles AFTER the accepted step: y = Y[par], FSAL slot = KX[par]
-    const T sc = ctl->scale;
-    T* a = par ? Y1 : Y0;
-    T* b = par ? K1 : K0;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        a[i] *= sc;
-        b[i] *= sc;
     }
 }
 
@@ -1150,7 +1176,7 @@ void launch_stages_fused(Solver<T>& S, double hh, T atol_s, T rtol) {
 // ---- the solve with the device-resident controller (hjb variant 0; single GPU and row blocks) ---------------------
 // Host part: SciPy's select_initial_step (three reductions, read back once each), then attempts are ENQUEUED -- stage
 // launch A, stage launch B, [row blocks: local reduction, the caller's all-gather], k_control, [row blocks: pack, the
-// caller's halo exchange, unpack], k_out, k_scale_ctl -- a few ahead of the device, never waiting for one: the host
+// caller's halo exchange, unpack], k_out -- a few ahead of the device, never waiting for one: the host
 // watches the controller's tick count in a pinned mailbox only to stop when `done` is posted.  In a row-block solve the
 // ranks must enqueue the same number of attempts (every attempt holds collectives), so there the host synchronises
 // the stream once per burst of attempts and all ranks read the same `done` (their controllers are bit-identical).
@@ -1185,11 +1211,9 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     }
     // ---- device-side bookkeeping (allocated once per handle)
     const int T_CAP = 65536, LOG_CAP = 65536;
-    if (!h->hjb_ctl) {
-        OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 4096));
-        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_tsteps, sizeof(double) * T_CAP));
-        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_log, sizeof(int32_t) * LOG_CAP));
-    }
+    if (!h->hjb_ctl) OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 4096));
+    if (!h->hjb_tsteps) OC_HIP_CHECK(hipMalloc((void**)&h->hjb_tsteps, sizeof(double) * T_CAP));
+    if (!h->hjb_log) OC_HIP_CHECK(hipMalloc((void**)&h->hjb_log, sizeof(int32_t) * LOG_CAP));
     static_assert(sizeof(HjbCtl<T>) <= 4096, "controller block too large");
     HjbCtl<T>* ctl = (HjbCtl<T>*)h->hjb_ctl;
     int32_t* keep_slot_dev = nullptr;
@@ -1254,6 +1278,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     hc.h_min = 1e300;
     hc.nt = nt;
     hc.is_f32 = sizeof(T) == 4 ? 1 : 0;
+    hc.in_scale = hc.out_in_scale = (T)1;
     ctl_prepare_attempt(hc, true);
     OC_HIP_CHECK(hipMemcpyAsync(ctl, &hc, sizeof(hc), hipMemcpyHostToDevice, s));
     OC_HIP_CHECK(hipStreamSynchronize(s));          // (hc lives on this stack frame)
@@ -1351,8 +1376,6 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         if (prof) event();
         hipLaunchKernelGGL(k_out<T>, dim3(S.fused_grid()), dim3(256), 0, s, OA);
         if (prof) event();
-        if (sizeof(T) == 4)
-            hipLaunchKernelGGL(k_scale_ctl<T>, S.g1(), dim3(256), 0, s, ctl, Y[0], Y[1], KX[0], KX[1], n);
         ++enq;
         return OC_OK;
     };
@@ -1487,6 +1510,11 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
         keep_slot[keep_idx[q]] = q;
     }
 
+    int32_t* keep_slot_dev = nullptr;   // device copy of keep_slot for the fused writer (this call only)
+    struct Guard {
+        int32_t*& p;
+        ~Guard() { if (p) (void)hipFree(p); }
+    } guard{keep_slot_dev};
     int expo = 0;                       // state = phi * 2^-expo
     auto scale_of = [&]() { return std::ldexp(1.0, -expo); };
 
@@ -1609,7 +1637,63 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                 // ---- row-block solve: refresh the halo rows of y_new and K6 (valid again `halo` rows deep)
                 if ((rc = S.exchange_halo())) return rc;
                 // ---- dense output for t_eval points in (t_new, t]  (scipy ivp.py:706-723)
-                {
+                if (use_fused) {
+                    // the fused writer of the default path (k_out), its controller block filled in by the host: the
+                    // one-launch-per-stage variant stays bit-identical to the default one
+                    if (!h->hjb_ctl) OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 4096));
+                    if (!h->hjb_ctl_host) OC_HIP_CHECK(hipHostMalloc(&h->hjb_ctl_host, 4096, hipHostMallocDefault));
+                    HjbCtl<T>& oc = *(HjbCtl<T>*)h->hjb_ctl_host;
+                    memset(&oc, 0, sizeof(oc));
+                    oc.accepted = 1;
+                    oc.out_parity = 0;
+                    oc.nt = nt;
+                    oc.Tfinal = Tfinal;
+                    oc.te_step = (0.0 - Tfinal) / (double)(nt - 1);
+                    oc.out_t = t;
+                    oc.out_hh = hh;
+                    oc.out_unscale = std::ldexp(1.0, expo);
+                    oc.out_lim_s = (T)(c.lim * scale_of());
+                    oc.out_in_scale = (T)1;
+                    oc.k_lo = k_next;
+                    int nv = 0;
+                    while (k_next < nt && te[k_next] >= t_new) {
+                        nv += k_next >= 1 ? 1 : 0;
+                        ++k_next;
+                    }
+                    oc.k_hi = k_next;
+                    oc.n_hx = 0;                    // (the kernel computes the slice factors itself)
+                    if (n_keep > 0 && !keep_slot_dev) {
+                        OC_HIP_CHECK(hipMalloc((void**)&keep_slot_dev, sizeof(int32_t) * nt));
+                        OC_HIP_CHECK(hipMemcpy(keep_slot_dev, keep_slot.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice));
+                    }
+                    OC_HIP_CHECK(hipMemcpyAsync(h->hjb_ctl, &oc, sizeof(oc), hipMemcpyHostToDevice, s));
+                    OutArgs<T> OA;
+                    memset(&OA, 0, sizeof(OA));
+                    OA.ctl = (const HjbCtl<T>*)h->hjb_ctl;
+                    OA.Y[0] = OA.Y[1] = S.y;
+                    OA.KX[0] = S.K[0];
+                    OA.KX[1] = S.K[6];
+                    for (int j = 0; j < 5; ++j) OA.KM[j] = S.K[1 + j];
+                    const int prow[6] = {0, 2, 3, 4, 5, 6};
+                    for (int q = 0; q < 6; ++q)
+                        for (int pp = 0; pp < 4; ++pp) OA.p[q][pp] = (T)RK_P[prow[q]][pp];
+                    OA.vx_base = (T*)vx_out;
+                    OA.vy_base = (T*)vy_out;
+                    OA.slice_elems = slice_elems;
+                    OA.keep_base = phi_keep;
+                    OA.keep_slot = keep_slot_dev;
+                    OA.lim = (T)c.lim;
+                    OA.mu = (T)c.mu;
+                    OA.inv2dx = (T)(1.0 / (2 * c.dx));
+                    OA.inv2dy = (T)(1.0 / (2 * c.dy));
+                    OA.Ny = S.Ny;
+                    OA.Nx = S.Nx;
+                    oc_timer_begin(h, "hjb_out", s);
+                    hipLaunchKernelGGL(k_out<T>, dim3(S.fused_grid()), dim3(256), 0, s, OA);
+                    oc_timer_end(h, "hjb_out", s, sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2)));
+                    stats.n_slices_written += nv;
+                    // (the pinned block is rewritten only after the next attempt's reduction has been read: copy done)
+                } else {
                     while (k_next < nt && te[k_next] >= t_new) {
                         int k = k_next++;
                         bool want_v = (k >= 1);

@@ -72,6 +72,7 @@ extern "C" int oc_destroy(oc_handle* h) {
     (void)hipFree(h->red_out);
     (void)hipHostFree(h->red_host);
     (void)hipFree(h->hjb_ctl);
+    if (h->hjb_ctl_host) (void)hipHostFree(h->hjb_ctl_host);
     (void)hipFree(h->hjb_tsteps);
     (void)hipFree(h->hjb_log);
     for (hipEvent_t e : h->hjb_events) (void)hipEventDestroy(e);

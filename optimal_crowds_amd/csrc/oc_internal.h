@@ -80,6 +80,7 @@ struct oc_handle {
     void* red_mailbox_dev = nullptr; // device address of the mailbox
     long long red_seq = 0;
     int32_t red_blocks = 0;
+    void* hjb_ctl_host = nullptr;    // pinned staging copy of the controller block (host-controlled cross-check variants)
     void* hjb_ctl = nullptr;         // device-resident step controller (hjb.hip: HjbCtl), accepted step times, attempt log
     double* hjb_tsteps = nullptr;
     int32_t* hjb_log = nullptr;

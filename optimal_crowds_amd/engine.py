@@ -155,18 +155,34 @@ class Engine:
         ThreadHaloComm on a RowShard) and keeps only that block of the direction field, `step` does this rank's share
         of the forces and lookups and sums them over the ranks (oc_gcfm_step_sharded through step_comm).  Every rank
         must make the same calls with the same arguments; the agent states stay bit-identical across the ranks."""
-        if halo_comm.shard.world > 1 and halo_comm.shard.field_margin < 1:
-            raise ValueError("sharded lookups need halo >= 7")
-        self._halo_comm, self._step_comm = halo_comm, step_comm
+        comms = halo_comm if isinstance(halo_comm, dict) else {k: halo_comm for k in range(self.n_keys)}
+        for c in comms.values():
+            if c is not None and c.shard.world > 1 and c.shard.field_margin < 1:
+                raise ValueError("sharded lookups need halo >= 7")
+        # per key: the communicator of the rank group that solves it (keys first, then row blocks: parallel
+        # .key_row_plan), or None when this rank holds no part of that key's field
+        self._halo_comms, self._step_comm = comms, step_comm
 
     @property
     def sharded(self):
-        return getattr(self, "_halo_comm", None) is not None
+        return getattr(self, "_halo_comms", None) is not None
+
+    def holds_key(self, key):
+        return not self.sharded or self._halo_comms.get(key) is not None
+
+    def _key_rows(self, key):
+        """the communicator of a key solved in row blocks by several ranks, else None (whole grid here, or not held)"""
+        c = self._halo_comms.get(key) if self.sharded else None
+        return c if (c is not None and c.shard.world > 1) else None
 
     def alloc_field(self, key, nslice):
         # slices are stored padded as (Ny, Nx) so that every row is 16-byte aligned for the vector kernels;
         # the reference's (Ny-2, Nx-2) array is the interior block [1:-1, 1:-1] (see field_interior)
-        rows = self._halo_comm.shard.Ny_local if self.sharded else self.Ny       # sharded: this rank's row block
+        if not self.holds_key(key):             # another rank group solves and answers this key
+            self.fields[key] = [None, None, nslice, 0]
+            return None, None
+        rc = self._key_rows(key)
+        rows = rc.shard.Ny_local if rc is not None else self.Ny                  # row-sharded: this rank's block
         shape = (max(nslice, 0), rows, self.Nx)
         vx = torch.zeros(shape, dtype=self.tdtype, device=self.device)
         vy = torch.zeros(shape, dtype=self.tdtype, device=self.device)
@@ -176,6 +192,8 @@ class Engine:
     def field_interior(self, key):
         """(vx_opt, vy_opt) views of shape (nslice, Ny-2, Nx-2), the reference's arrays (optimals.py:80-81)."""
         vx, vy = self.fields[key][0], self.fields[key][1]
+        if vx is None:
+            raise ValueError("key %d is held by another rank group" % key)
         return vx[:, 1:-1, 1:-1], vy[:, 1:-1, 1:-1]
 
     def make_coef(self, key, m=None, out=None):
@@ -203,12 +221,16 @@ class Engine:
         vx, vy, nslice, _ = self.fields[key]
         if nt - 1 > nslice:
             raise ValueError("horizon exceeds allocated field slices")
-        if self.sharded:
-            if want_steps:
-                raise ValueError("want_steps is not available on a sharded engine")
-            st, _, phi_keep = self.solve_rows(key, T, nt, self._halo_comm, m=m, keep=keep, field=(vx, vy))
+        if not self.holds_key(key):
             self.fields[key][3] = nt
-            sh = self._halo_comm.shard
+            return None, None
+        rc = self._key_rows(key)
+        if rc is not None:
+            if want_steps:
+                raise ValueError("want_steps is not available on a row-sharded key")
+            st, _, phi_keep = self.solve_rows(key, T, nt, rc, m=m, keep=keep, field=(vx, vy))
+            self.fields[key][3] = nt
+            sh = rc.shard
             check(self.lib.oc_set_field_rows(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt),
                                              int(sh.row0), int(sh.Ny_local), int(sh.g0), int(sh.g1)))
             return st, phi_keep
@@ -276,8 +298,11 @@ class Engine:
     def set_field_horizon(self, key, nt):
         vx, vy, nslice, _ = self.fields[key]
         self.fields[key][3] = nt
-        if self.sharded:
-            sh = self._halo_comm.shard
+        if vx is None:
+            return
+        rc = self._key_rows(key)
+        if rc is not None:
+            sh = rc.shard
             check(self.lib.oc_set_field_rows(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt),
                                              int(sh.row0), int(sh.Ny_local), int(sh.g0), int(sh.g1)))
             return
@@ -379,7 +404,7 @@ class Engine:
         .DistStepComm or ThreadStepComm) sums the exchange buffer over the ranks, every rank finishes all agents."""
         if noise is not None and not torch.is_tensor(noise):
             noise = torch.as_tensor(np.ascontiguousarray(noise, dtype=np.float64)).to(self.device)
-        n = 6 * int(self.lib.oc_padded_agents(int(self.agents["N"])))
+        n = int(self.lib.oc_xchg_doubles(int(self.agents["N"])))
         if getattr(self, "_xchg", None) is None or self._xchg.numel() != n:
             self._xchg = torch.zeros(n, dtype=torch.float64, device=self.device)
         comm.bind(self._xchg)

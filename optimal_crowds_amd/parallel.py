@@ -1,9 +1,10 @@
 """Multi-GPU plumbing for the path (one process per GPU, torch.distributed; backend "nccl" = RCCL on ROCm).
 
-The bench's default for N > 1 is an ensemble of independent simulations.  This module carries the
-other mode, ONE simulation on N GPUs as SURVEY 8e lays it out:
-* the HJB grid in row blocks: `RowShard` is the geometry of one rank's block, `DistHaloComm` carries the two
-  collectives of `oc_hjb_solve_rows` (include/oc_hip.h) -- halo rows to the neighbours, all-gather of the error norm;
+ONE simulation on N GPUs as SURVEY 8e lays it out (what `bench.py --gpus N` measures for the multi-key / large-grid
+workloads):
+* keys first, then the HJB grid in row blocks: `key_row_plan` deals the keys to groups of ranks, `RowShard` is the
+  geometry of one rank's block, `DistHaloComm` carries the two collectives of `oc_hjb_solve_rows` (include/oc_hip.h) --
+  halo rows to the neighbours, all-gather of the error norm -- enqueued on the launch stream, no host synchronisation;
 * replicated agents: `DistStepComm` carries the one sum-all-reduce per step of `oc_gcfm_step_sharded`;
 * `dist_sharding()` is the `sharding=` argument that switches a whole `simulations.simulation` to this mode;
 * `ThreadHaloComm` / `ThreadStepComm` / `thread_sharding` run several virtual ranks inside one process on one GPU (tests).
@@ -48,9 +49,20 @@ def sum_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
-def key_partition(n_keys, world, rank):
-    """Independent HJB solves: key k goes to rank k % world (zero communication during the solve)."""
-    return [k for k in range(n_keys) if k % world == rank]
+def key_row_plan(n_keys, world):
+    """partition by key first (the solves of different keys are independent: zero communication), then split
+    each key's grid into row blocks over the ranks of its group.  Returns, per key, the tuple of world ranks that solve
+    it, in row-block order.  world >= n_keys: contiguous groups of world // n_keys ranks (the first world % n_keys
+    groups get one more): C4 on 4 GPUs = 2 keys x 2-way rows.  world < n_keys: key k goes whole to rank k % world."""
+    if world >= n_keys:
+        base, rem = divmod(world, n_keys)
+        plan, r0 = [], 0
+        for k in range(n_keys):
+            n = base + (1 if k < rem else 0)
+            plan.append(tuple(range(r0, r0 + n)))
+            r0 += n
+        return plan
+    return [(k % world,) for k in range(n_keys)]
 
 
 def row_blocks(Ny, world):
@@ -62,42 +74,6 @@ def row_blocks(Ny, world):
         out.append((r0, r1))
         r0 = r1
     return out
-
-
-def halo_exchange(block, rank, world, group=None):
-    """block: (rows, Nx) tensor of this rank's rows.  Returns (above, below): the neighbour rows adjacent to the
-    block (None at the room border, where the RHS mirrors: optimals.py:149-152).  One row per neighbour and RHS
-    evaluation: 8 KB at Nx = 2048 -- latency-bound, so plain point-to-point, no ring."""
-    above = below = None
-    reqs = []
-    if rank > 0:
-        above = torch.empty_like(block[0])
-        reqs.append(dist.isend(block[0].contiguous(), rank - 1, group=group))
-        reqs.append(dist.irecv(above, rank - 1, group=group))
-    if rank < world - 1:
-        below = torch.empty_like(block[-1])
-        reqs.append(dist.isend(block[-1].contiguous(), rank + 1, group=group))
-        reqs.append(dist.irecv(below, rank + 1, group=group))
-    for r in reqs:
-        r.wait()
-    return above, below
-
-
-def padded_block(block, above, below):
-    """Stack the halo rows (or the mirrored second line at the room border) around the block: (rows+2, Nx)."""
-    top = above if above is not None else block[1]
-    bot = below if below is not None else block[-2]
-    return torch.cat([top[None], block, bot[None]], dim=0)
-
-
-def error_norm_allreduce(local_sumsq, local_max, device="cpu"):
-    """Scalar reduction of one RK attempt: sum of squared scaled errors and max |y| (scipy rk.py:146-147)."""
-    t = torch.tensor([float(local_sumsq)], dtype=torch.float64, device=device)
-    m = torch.tensor([float(local_max)], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dist.all_reduce(m, op=dist.ReduceOp.MAX)
-    return float(t.item()), float(m.item())
 
 
 # ---------------------------------------------------------------------------------------------- row-block HJB solve
@@ -179,36 +155,43 @@ class DistHaloComm(_HaloComm):
         self.ranks = list(range(dist.get_world_size())) if ranks is None else list(ranks)
         assert len(self.ranks) == shard.world
         self.host_staged = dist.get_backend(group) != "nccl"
+        self.halo_bytes = self.send_up.numel() * self.send_up.element_size()      # one message to one neighbour
+        if self.host_staged:      # gloo: persistent host mirrors of the staging buffers (no allocation per exchange)
+            mk = lambda t: torch.empty(t.shape, dtype=t.dtype, device="cpu")
+            self._h = {n: mk(getattr(self, n)) for n in ("send_up", "recv_up", "send_dn", "recv_dn")}
+            self._h_red = torch.empty(2, dtype=torch.float64)
+            self._h_all = [torch.empty(2, dtype=torch.float64) for _ in range(shard.world)]
 
     def allgather_red(self):
         if self.host_staged:
-            loc = self.red_local.cpu()
-            parts = [torch.empty_like(loc) for _ in range(self.shard.world)]
-            dist.all_gather(parts, loc, group=self.group)
-            self.red_all.copy_(torch.stack(parts))
-        else:
+            self._h_red.copy_(self.red_local)
+            dist.all_gather(self._h_all, self._h_red, group=self.group)
+            self.red_all.copy_(torch.stack(self._h_all))
+        else:       # RCCL: 16 bytes per rank, enqueued on the launch stream -- no host synchronisation
             dist.all_gather_into_tensor(self.red_all, self.red_local, group=self.group)
 
     def exchange_halo(self):
+        """send_up -> the upper neighbour's recv_dn, send_dn -> the lower neighbour's recv_up: one batched pair of
+        point-to-point messages per side (xGMI is point-to-point: no ring), straight between the staging buffers."""
         sh = self.shard
-        stage = (lambda t: t.cpu()) if self.host_staged else (lambda t: t)
-        ops, post = [], []
+        ops = []
+        if self.host_staged:
+            for n in ("send_up", "send_dn"):
+                self._h[n].copy_(getattr(self, n))
+        buf = (lambda n: self._h[n]) if self.host_staged else (lambda n: getattr(self, n))
         if sh.has_up:
             peer = self.ranks[sh.rank - 1]
-            rbuf = torch.empty_like(stage(self.recv_up))
-            ops += [dist.P2POp(dist.isend, stage(self.send_up), peer, group=self.group),
-                    dist.P2POp(dist.irecv, rbuf, peer, group=self.group)]
-            post.append((self.recv_up, rbuf))
+            ops += [dist.P2POp(dist.isend, buf("send_up"), peer, group=self.group),
+                    dist.P2POp(dist.irecv, buf("recv_up"), peer, group=self.group)]
         if sh.has_dn:
             peer = self.ranks[sh.rank + 1]
-            rbuf = torch.empty_like(stage(self.recv_dn))
-            ops += [dist.P2POp(dist.isend, stage(self.send_dn), peer, group=self.group),
-                    dist.P2POp(dist.irecv, rbuf, peer, group=self.group)]
-            post.append((self.recv_dn, rbuf))
+            ops += [dist.P2POp(dist.isend, buf("send_dn"), peer, group=self.group),
+                    dist.P2POp(dist.irecv, buf("recv_dn"), peer, group=self.group)]
         for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        for dst, src in post:
-            dst.copy_(src)
+            req.wait()          # (nccl: waits on the stream, not on the host)
+        if self.host_staged:
+            for n in ("recv_up", "recv_dn"):
+                getattr(self, n).copy_(self._h[n])
 
 
 class ThreadWorld:
@@ -281,12 +264,15 @@ class DistStepComm(_StepComm):
         super().__init__(dist.get_rank(group), dist.get_world_size(group))
         self.group = group
         self.host_staged = dist.get_backend(group) != "nccl"
+        self._h = None
 
     def allreduce(self):
         if self.host_staged:
-            t = self.buf.cpu()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            self.buf.copy_(t)
+            if self._h is None or self._h.numel() != self.buf.numel():
+                self._h = torch.empty(self.buf.numel(), dtype=self.buf.dtype)
+            self._h.copy_(self.buf)
+            dist.all_reduce(self._h, op=dist.ReduceOp.SUM, group=self.group)
+            self.buf.copy_(self._h)
         else:
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
 
@@ -312,12 +298,25 @@ class ThreadStepComm(_StepComm):
 
 
 # ---------------------------------------------------------------------------------------------- one call for a façade
-def dist_sharding(halo=8, group=None):
-    """`sharding=` argument of simulations.simulation for a torch.distributed job (one process per GPU): row blocks of
-    the HJB grid with `halo` rows (>= 7), collectives over the group's backend (nccl = RCCL over xGMI, or gloo)."""
+def dist_sharding(halo=8, by_key=True):
+    """`sharding=` argument of simulations.simulation for a torch.distributed job (one process per GPU): ONE simulation
+    on all ranks.  HJB: keys first, then row blocks (key_row_plan; by_key=False: every key over all ranks) with `halo`
+    rows (>= 7), each key's collectives on its own sub-group (nccl = RCCL over xGMI, or gloo); agents replicated, one
+    all-reduce per step over the whole world.  Returns engine -> ({key: halo comm or None}, step comm)."""
     def make(eng):
-        sh = RowShard(eng.Ny, dist.get_rank(group), dist.get_world_size(group), halo)
-        return (DistHaloComm(sh, eng.Nx, eng.tdtype, eng.device, group=group), DistStepComm(group))
+        world, rank = dist.get_world_size(), dist.get_rank()
+        plan = key_row_plan(eng.n_keys, world) if by_key else [tuple(range(world))] * eng.n_keys
+        comms = {}
+        for k, ranks in enumerate(plan):
+            # (every rank creates every group, member or not, in the same order: torch.distributed requires it)
+            grp = dist.new_group(list(ranks)) if 1 < len(ranks) < world else None
+            if rank in ranks:
+                sh = RowShard(eng.Ny, ranks.index(rank), len(ranks), halo)
+                comms[k] = DistHaloComm(sh, eng.Nx, eng.tdtype, eng.device, group=grp, ranks=ranks)
+            else:
+                comms[k] = None
+        eng.key_plan = plan
+        return comms, DistStepComm(None)
     return make
 
 
