@@ -9,14 +9,21 @@ key happens once per nt steps, exactly where run() does it (before step 0), INSI
 default --steps 1000 the timed region is one complete run: K solves + 1000 steps.  For other K the region holds
 ceil(K/nt) solve rounds.  Inputs (potentials, agent state) are resident in HBM when the clock starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload metro_station|slalom|exit_opposite|room_test]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload metro_station|open_room|slalom|exit_opposite|room_test]
+                    [--mode auto|sharded|ensemble]
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its own member of an ensemble of the
-workload (own initial placement and noise seed; "replicas only"): value = N * K /
-max-over-ranks time, scaling = weak.
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL):
+  sharded   ONE simulation on N GPUs as SURVEY 8e lays it out -- keys first (independent solves on disjoint rank groups),
+            then row blocks of the HJB grid with halo exchange, agents replicated with one all-reduce per step.
+            value = K / max-over-ranks time, scaling = strong.  Default (`auto`) for metro_station and open_room; the
+            line also carries an `ensemble` object measured right after it, for comparison.
+  ensemble  every rank runs its own member of an ensemble (own placement and noise seed, no data-path collective):
+            value = N * K / max-over-ranks time = aggregate replica throughput, scaling = weak.  Default for the small
+            rooms ("replicas only" where halos cost more than they save).
 """
 import argparse
 import copy
+import hashlib
 import json
 import os
 import sys
@@ -32,9 +39,21 @@ WORKLOADS = {   # name -> (room, grid_step, T, recompute)
     "slalom": ("slalom", 0.1, 20.0, False),
     "exit_opposite": ("exit_opposite", 0.1, 20.0, False),
     "room_test": ("room_test", 0.05, 20.0, False),
-    "open_room": ("open_room", 0.1, 20.0, True),      # configs[4] on ONE GPU: 4096^2, 500k agents, recompute=True
+    "open_room": ("open_room", 0.1, 20.0, True),      # configs[4]: 4096^2, 500k agents, recompute=True
 }
+SHARDED_BY_DEFAULT = ("metro_station", "open_room")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def csrc_hash():
+    """sha256 over the kernel sources: profiles/*pmc*.json carry it, so a counter file of other kernels is never quoted"""
+    hsh = hashlib.sha256()
+    d = os.path.join(REPO, "optimal_crowds_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            hsh.update(name.encode())
+            hsh.update(open(os.path.join(d, name), "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def build_sim(workload, seed=20240807, wall_search_radius=-1.0, sharding=None):
@@ -52,7 +71,8 @@ def build_sim(workload, seed=20240807, wall_search_radius=-1.0, sharding=None):
 
 
 def solve_round(sim):
-    """what run() does before the first step: one HJB solve per key (m = 0 at step 0)."""
+    """what run() does before the first step: one HJB solve per key (m = 0 at step 0).  Sharded: a rank solves only
+    the keys (or row blocks of keys) its group holds; the others' stats are None."""
     stats = []
     for k, key in enumerate(sim._key_names):
         st, _ = sim._engine.solve(k, sim.T, sim._nt0, m=None)
@@ -80,79 +100,125 @@ def run_steps(sim, K, nt, timed_stats=None):
         done += 1
 
 
-def cpu_baseline(sim, cfg, n_attempt, budget_s=20.0):
-    """The oracle's C restatement (oracle/liboc_oracle.so: float64, OpenMP) timed on this host on a bounded sample
-    of the same workload, then scaled by the GPU run's own work counts:
-      HJB   : full-grid RHS / stage-combination / vels passes -> one RK attempt = 6 RHS + 7 combinations,
-              one output slice = 1 combination + 1 vels; x (attempts, nt-1 slices) of the GPU solve, per key
-      GCFM  : complete synchronous step (lookup, all-pairs with cutoff, wall search, integration) for a sample of
-              agents against all N, scaled to the active agents.
-    kind = "port" (the reference itself cannot travel to this box)."""
-    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+def host_cores():
+    """(threads to use, what limits them): the CPUs this process may run on, capped by the container's CPU quota"""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except Exception:
+        pass
+    return (min(aff, quota) if quota else aff), {"host_cpus": os.cpu_count(), "affinity": aff, "cgroup_quota": quota}
+
+
+def cpu_baseline(sim, cfg, workload, budget_s=25.0):
+    """The oracle's C restatement (oracle/liboc_oracle.so: float64, OpenMP, kind = "port": the reference itself is
+    Python and cannot travel to this box) timed on this host's cores, all of those this process may use:
+      HJB   one COMPLETE solve of key 0 up to the dense output (every RK attempt: occ_rk45_solve, the same algorithm
+            as the GPU's) + the dense output and direction field of a sample of slices, scaled to nt - 1 slices;
+      GCFM  one COMPLETE synchronous step of all agents (lookup, all pairs with the cutoff test, nearest wall cell,
+            integration) on the state the GPU run ended with -- or, if a probe says it would take longer than the
+            budget, a contiguous share of the agents against all, scaled.
+    value = nt / (K t_solve + nt t_step): the same "one complete run" the GPU line times.  For the two small rooms the
+    NumPy/SciPy-stack restatement (oracle/oc_oracle.py: the reference's own software stack, effectively one core) is
+    timed beside it."""
+    cores, lim = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     from oracle import oc_oracle_c as occ
     P = occ.params(cfg, sim.room_length, sim.room_height, sim.Nx, sim.Ny)
-    n = sim.Nx * sim.Ny
     key = sim._key_names[0]
     V = np.ascontiguousarray(sim.Vs[key])
     m = np.zeros_like(V)
-    rng = np.random.RandomState(1)
-    phi = np.exp(rng.normal(size=n))
-    Ks = [rng.normal(size=n) for _ in range(7)]
-
-    def timeit(fn, share):
-        fn()
-        t0 = time.perf_counter()
-        k = 0
-        while time.perf_counter() - t0 < budget_s * share or k < 2:
-            fn()
-            k += 1
-        return (time.perf_counter() - t0) / k, k
-    t_rhs, n_rhs = timeit(lambda: occ.hjb_rhs(P, phi, V, m), 0.12)
-    t_lin3, _ = timeit(lambda: occ.lincomb(phi, Ks[:3], np.ones(3)), 0.06)
-    t_lin7, _ = timeit(lambda: occ.lincomb(phi, Ks, np.ones(7)), 0.06)
-    t_vels, n_vels = timeit(lambda: occ.vels(P, phi), 0.1)
     nt = sim._nt0
-    t_attempt = 6 * t_rhs + 5 * t_lin3 + 2 * t_lin7            # stages 1-5 average 3 arrays; y_new and error use 6-7
-    t_hjb = n_attempt * t_attempt + (nt - 1) * (t_lin7 + t_vels)
-    # GCFM sample on the current state
-    st = sim._engine.get_state()
+    ns = min(nt - 1, 24)                                    # sample of output slices
+    keep = sorted(set(int(k) for k in np.linspace(1, nt - 1, ns)))
+    t0 = time.perf_counter()
+    phi, st = occ.rk45_solve(P, V, m, sim.T, nt, keep=keep)
+    t_attempts_and_sample = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    phi1, _ = occ.rk45_solve(P, V, m, sim.T, nt, keep=keep[:1])
+    t_attempts = time.perf_counter() - t0                   # (a second solve: what the sample's dense output cost)
+    t_dense = max(t_attempts_and_sample - t_attempts, 0.0) / max(len(keep) - 1, 1)
+    t0 = time.perf_counter()
+    for q in range(len(keep)):
+        occ.vels(P, phi[q])
+    t_vels = (time.perf_counter() - t0) / len(keep)
+    t_hjb = t_attempts + (nt - 1) * (t_dense + t_vels)
+    # ---- GCFM: complete step(s) on the current state
+    stt = sim._engine.get_state()
     N = sim.N
     wms = [occ.WallMap(sim._X0, sim._Y0, sim.Vs[k]) for k in sim._key_names]
     rects = [[sim._room["targets"][t] for t in sim._possible[k]] for k in sim._key_names]
+    rng = np.random.RandomState(1)
     noise = rng.normal(size=(N, 2))
-    ns = min(N, 256)
-    t0 = time.perf_counter()
-    done = 0
-    while done < N and (time.perf_counter() - t0 < budget_s * 0.5 or done == 0):
-        occ.step_sync(P, st["x"], st["y"], st["vx"], st["vy"], sim._v_des, st["status"], sim._key_of,
-                      [None] * len(wms), sim._X0, sim._Y0, wms, rects, noise, i0=done, i1=min(N, done + ns))
-        done = min(N, done + ns)
-    t_agent = (time.perf_counter() - t0) / done
-    t_step = t_agent * int(st["status"].sum())
+
+    def part(i0, i1):
+        t = time.perf_counter()
+        occ.step_sync(P, stt["x"], stt["y"], stt["vx"], stt["vy"], sim._v_des, stt["status"], sim._key_of,
+                      [None] * len(wms), sim._X0, sim._Y0, wms, rects, noise, i0=i0, i1=i1)
+        return time.perf_counter() - t
+    n_probe = min(N, 512)
+    t_probe = part(0, n_probe)
+    est = t_probe / n_probe * N
+    gcfm_budget = max(budget_s - t_attempts_and_sample - t_attempts, 5.0)
+    if est <= gcfm_budget:
+        t_step, share = part(0, N), N
+    else:
+        share = max(n_probe, int(N * gcfm_budget / est))
+        t_step = part(0, share) / share * N
     K = len(sim._key_names)
     value = nt / (K * t_hjb + nt * t_step)
-    return {"value": value, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": "C/OpenMP float64 oracle on %d threads: %d full-grid RHS (%.4f s), stage combinations, %d vels "
-                      "(%.4f s) -> one RK attempt %.3f s x %d attempts + %d output slices per key; GCFM: complete "
-                      "synchronous step for %d of %d agents vs all agents (%.2e s/agent); scaled to K=%d keys, "
-                      "nt=%d steps" % (cores, n_rhs, t_rhs, n_vels, t_vels, t_attempt, n_attempt, nt - 1, done, N,
-                                       t_agent, K, nt),
-            "t_hjb_solve_s": t_hjb, "t_step_s": t_step}
+    out = {"value": value, "unit": "steps/s", "cores": cores, "kind": "port",
+           "sample": "C/OpenMP float64 oracle on %d threads (%s): HJB = one complete RK45 solve of one key, %d attempts "
+                     "(%.2f s) + dense output and direction field of %d of %d slices (%.4f + %.4f s each, scaled); "
+                     "GCFM = one synchronous step of %d of %d agents against all (%.2f s%s); value = nt / (K t_solve + "
+                     "nt t_step), K = %d, nt = %d" % (cores, json.dumps(lim), st["n_attempt"], t_attempts, len(keep),
+                                                      nt - 1, t_dense, t_vels, share, N, t_step,
+                                                      "" if share == N else ", scaled", K, nt),
+           "t_hjb_solve_s": t_hjb, "t_step_s": t_step, "rk_attempts": st["n_attempt"], **lim}
+    if workload in ("room_test", "exit_opposite") and os.environ.get("OC_BENCH_NUMPY_STACK", "1") != "0":
+        out["numpy_stack"] = numpy_stack_baseline(sim, cfg, stt)
+    return out
+
+
+def numpy_stack_baseline(sim, cfg, stt, steps=2):
+    """the NumPy/SciPy-stack restatement of the reference (oracle/oc_oracle.py, float64) on this host:
+    one complete HJB solve of one key (its own RK45 in NumPy, every slice through vels) and `steps` sequential steps
+    in the reference's update order."""
+    from oracle import oc_oracle as oc
+    room = sim._room
+    np.random.seed(sim._seed)
+    o = oc.Simulation(room, sim.T, cfg=cfg, mode="sequential")
+    key = o.key_names[0]
+    t0 = time.perf_counter()
+    o.targets[key].compute_optimal_velocity(0.0, np.zeros_like(o.V))
+    t_solve = time.perf_counter() - t0
+    o.x, o.y, o.vx, o.vy = (stt[n].copy() for n in ("x", "y", "vx", "vy"))
+    o.status = stt["status"].astype(bool).copy()
+    o.inside = int(o.status.sum())
+    for k in o.key_names[1:]:                       # (the lookup needs a field for every key: reuse the solved one)
+        o.targets[k].vx_opt, o.targets[k].vy_opt = o.targets[key].vx_opt, o.targets[key].vy_opt
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o.step()
+    t_step = (time.perf_counter() - t0) / steps
+    K, nt = len(o.key_names), sim._nt0
+    return {"value": nt / (K * t_solve + nt * t_step), "unit": "steps/s", "cores": 1, "kind": "port (NumPy/SciPy stack)",
+            "t_hjb_solve_s": t_solve, "t_step_s": t_step,
+            "sample": "oracle/oc_oracle.py: one complete solve of one key + %d sequential steps of %d agents" % (steps, sim.N)}
 
 
 def gcfm_work(sim, cfg, t_forces_s, t_step_s):
     """SURVEY 8d's algorithmic work of one GCFM step on the state the run ended with (untimed): ordered pairs
     P = N_a (N_a - 1), of which P_near lie within the cutoff (counted here with torch on the GPU, float64), nominal
     8 flop per far pair and 60 per near pair; 88 B of state traffic per active agent.  The far pairs are never
-    visited (tile boxes and neighbour lists cull them), so the all-pairs figure is an equivalent rate, not executed
-    flops; the near-pair figure is what the pair kernel really evaluates."""
-    import torch
+    visited (tile boxes and neighbour lists cull them): only the near-pair figure is an executed rate."""
     a = sim._engine.agents
     act = a["status"].bool()
     x, y = a["x"][act], a["y"][act]
     na = int(x.numel())
-    c2 = float(cfg["repulsion_cutoff"]) ** 2
     near = 0
     for i0 in range(0, na, 2048):
         dx = x[i0:i0 + 2048, None] - x[None, :]
@@ -160,53 +226,68 @@ def gcfm_work(sim, cfg, t_forces_s, t_step_s):
         near += int(((dx * dx + dy * dy).sqrt() < float(cfg["repulsion_cutoff"])).sum().item())
     near -= na                                              # the agent itself
     P = na * (na - 1)
-    f_all = 8.0 * (P - near) + 60.0 * near
     return {"active_agents": na, "ordered_pairs": P, "near_pairs": near,
-            "flop_all_pairs_equivalent": f_all, "flop_near_pairs": 60.0 * near,
-            "all_pairs_equivalent_TFLOPs": f_all / t_forces_s / 1e12,
+            "flop_near_pairs": 60.0 * near,
             "near_pair_TFLOPs": 60.0 * near / t_forces_s / 1e12,
             "near_pair_frac_of_fp32_vector_peak": 60.0 * near / t_forces_s / 157.3e12,
+            "all_pairs_equivalent_flop": 8.0 * (P - near) + 60.0 * near,
             "state_bytes_frac_of_hbm_peak": 88.0 * na / t_step_s / (HBM_PEAK_GBS * 1e9)}
 
 
+def pmc_file(pattern):
+    """newest committed PMC summary whose kernels are the ones in this tree (stamped with csrc_hash), else None"""
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(REPO, "profiles", pattern)))):
+        try:
+            d = json.load(open(f))
+            if d.get("csrc_sha") == csrc_hash():
+                return d
+        except Exception:
+            pass
+    return None
+
+
 def pmc_traffic(workload):
-    """HBM bytes per k_out launch from the committed PMC summary (profiles/rNN_pmc_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command, gfx950 FETCH_SIZE x2 correction applied by
-    tools/collect_profiles.py).  Counters cannot be collected from inside the timed run, hence the file; None if
-    absent or for another workload."""
-    import glob
-    if workload != "metro_station":
+    """HBM bytes per k_out launch from the committed PMC summary (profiles/rNN_pmc_traffic*.json: separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes of this very command, gfx950 FETCH_SIZE x2 correction applied by
+    tools/collect_profiles.py).  Counters cannot be collected from inside the timed run, hence the file; null if the
+    file is absent, belongs to another workload or was taken with other kernel sources."""
+    d = pmc_file("r*_pmc_traffic*.json")
+    if not d or d.get("workload", "metro_station") != workload:
         return None
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
-    for f in reversed(files):
-        try:
-            v = json.load(open(f)).get("k_out_hbm_bytes_per_launch")
-            if v:
-                return v
-        except Exception:
-            pass
-    return None
+    return d.get("k_out_hbm_bytes_per_launch")
 
 
-def pmc_valu(workload, counter="SQ_INSTS_VALU"):
-    """A per-launch SQ counter of k_forces (default: wave-level VALU instructions) from the committed summary
-    (profiles/rNN_pmc_step_kernels.txt, tools/pmc_step.sh: rocprofv3 --pmc passes of this very command); None if
-    absent or for another workload."""
-    import glob
-    import re
-    if workload != "metro_station":
+def pmc_step(workload):
+    d = pmc_file("r*_pmc_step*.json")
+    if not d or d.get("workload", "metro_station") != workload:
         return None
-    for f in reversed(sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_step_kernels.txt")))):
-        try:
-            txt = open(f).read()
-            blk = txt[txt.index("k_forces"):]
-            blk = blk[:blk.index("k_finish")] if "k_finish" in blk else blk
-            m = re.search(counter + r"\s+n=\d+\s+mean=([0-9.e+]+)", blk)
-            if m:
-                return float(m.group(1))
-        except Exception:
-            pass
-    return None
+    return d.get("k_forces")
+
+
+def measure(sim, args, nt, world, dist, red_dev):
+    """W warmup steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks."""
+    import torch
+    from optimal_crowds_amd import parallel
+    eng = sim._engine
+    K, W = args.steps, args.warmup
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    if W > 0:
+        run_steps(sim, W, nt)
+    barrier()
+    eng.set_profiling(1 | 4)        # HJB kernels on every 8th attempt, GCFM kernels on every 16th step (events cost gaps)
+    eng.reset_kernel_stats()
+    stats = []
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(sim, K, nt, stats)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return parallel.max_over_ranks(elapsed, device=red_dev), stats
 
 
 def main():
@@ -220,10 +301,11 @@ def main():
                     help="skip breakdown.gcfm_work (its torch kernels clutter a rocprofv3 kernel-stats run)")
     ap.add_argument("--wall-radius", type=float, default=-1.0,
                     help="diagnostic: wall search radius in m (default -1: per-agent radius from the 1e-12 m/s force bound)")
-    ap.add_argument("--mode", default="ensemble", choices=["ensemble", "sharded"],
-                    help="N > 1: ensemble = one independent simulation per GPU (default, weak scaling); sharded = ONE "
-                         "simulation on N GPUs: HJB grid in row blocks, agents replicated, one all-reduce per step "
-                         "(strong scaling; DESIGN.md section 7)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "ensemble", "sharded"],
+                    help="N > 1: sharded = ONE simulation on N GPUs (keys first, then HJB row blocks; agents replicated, one "
+                         "all-reduce per step; strong scaling) -- auto picks it for metro_station / open_room; ensemble = "
+                         "one independent simulation per GPU (aggregate replica throughput, weak scaling)")
+    ap.add_argument("--no-ensemble-line", action="store_true", help="sharded mode: do not also measure the ensemble")
     ap.add_argument("--tune", default="", help="launch-shape knobs, e.g. pair_split=4 (oc_set_tuning)")
     args = ap.parse_args()
 
@@ -233,24 +315,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-    # OC_BENCH_ONE_DEVICE=1 (rehearsal on a 1-GPU box): every rank uses cuda:0 and the timing reductions use gloo
+    # OC_BENCH_ONE_DEVICE=1 (rehearsal on a 1-GPU box): every rank uses cuda:0 and the collectives run over gloo
     one_dev = os.environ.get("OC_BENCH_ONE_DEVICE") == "1"
     torch.cuda.set_device(0 if one_dev else local_rank)
-    rank, world = parallel.init_distributed("gloo" if one_dev else "nccl")
+    backend = "gloo" if one_dev else "nccl"
+    rank, world = parallel.init_distributed(backend)
     dist = None
     if world > 1:
         import torch.distributed as dist
     red_dev = "cpu" if one_dev else "cuda"
 
     import optimal_crowds_amd.engine  # noqa: F401  (fails loudly without the HIP library)
+    mode = args.mode
+    if mode == "auto":
+        mode = "sharded" if args.workload in SHARDED_BY_DEFAULT else "ensemble"
+    sharded = mode == "sharded" and world > 1
     t_init = time.perf_counter()
-    sharded = args.mode == "sharded"
-    if sharded:     # one simulation on all ranks: same seed everywhere (replicated agents), row blocks of the HJB grid
-        # (N = 1: the same code path with a one-rank "world", to see what the sharded path itself costs)
-        shd = parallel.dist_sharding() if world > 1 else parallel.thread_sharding(0, parallel.ThreadWorld(1),
-                                                                                  parallel.ThreadWorld(1))
-        sim, cfg = build_sim(args.workload, wall_search_radius=args.wall_radius, sharding=shd)
-    else:           # N > 1: an ensemble -- every rank simulates its own member (own placement and noise seed)
+    if sharded:     # one simulation on all ranks: same seed everywhere (replicated agents)
+        sim, cfg = build_sim(args.workload, wall_search_radius=args.wall_radius, sharding=parallel.dist_sharding())
+    else:           # N = 1, or an ensemble: every rank simulates its own member (own placement and noise seed)
         sim, cfg = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius)
     t_init = time.perf_counter() - t_init
     eng = sim._engine
@@ -259,93 +342,104 @@ def main():
         eng.set_tuning(name, int(val))
     nt = sim._nt0
     K, W = args.steps, args.warmup
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- warmup (untimed): one solve round + W steps
-    if W > 0:
-        run_steps(sim, W, nt)
-    barrier()
-    # ---- timed region: exactly K steps (+ the solve rounds run() would do)
-    eng.set_profiling(1 | 4)        # HJB kernels always, GCFM kernels on every 16th step (event records cost gaps)
-    eng.reset_kernel_stats()
-    stats = []
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(sim, K, nt, stats)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(elapsed, device=red_dev)
+    elapsed, stats = measure(sim, args, nt, world, dist, red_dev)
 
     # ---- breakdown (untimed extras for the report)
-    t_hjb = sum(s["seconds"] for rnd in stats for s in rnd)
-    nfev = stats[0][0]["nfev"] if stats else 0
-    n_att = stats[0][0]["n_attempt"] if stats else 0
-    n_acc = stats[0][0]["n_accept"] if stats else 0
-    ncell = sim.Nx * sim.Ny
+    mine = [s for rnd in stats for s in rnd if s is not None]
+    t_hjb = sum(s["seconds"] for s in mine)
+    first = mine[0] if mine else None
     kstats = {}
     for name in ("hjb_out", "hjb_stage", "gcfm_forces", "gcfm_finish"):
         nl, ms, by = eng.kernel_stats(name)
-        kstats[name] = {"launches": nl, "avg_ms": (ms / nl if nl else None), "total_ms": ms,
-                        "algorithmic_GB_per_launch": (by / nl / 1e9 if nl else None),
-                        "achieved_GBps": (by / (ms * 1e-3) / 1e9 if ms > 0 else None)}
+        kstats[name] = {"launches_timed": nl, "avg_ms": (ms / nl if nl else None),
+                        "designed_GB_per_launch": (by / nl / 1e9 if nl else None),
+                        "achieved_GBps": (by / (ms * 1e-3) / 1e9 if ms > 0 and by > 0 else None)}
     # dominant HBM-bound kernel: the dense-output + direction-field writer (one launch per accepted RK step)
     roof = None
     ko = kstats["hjb_out"]
-    if ko["launches"]:
+    if ko["launches_timed"]:
         ach = ko["achieved_GBps"]
         roof = {"bound": "hbm", "kernel": "k_out (HJB dense output + direction-field writer)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.workload), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes)",
-                "launches": ko["launches"], "avg_launch_ms": ko["avg_ms"],
-                "algorithmic_GB_per_launch": ko["algorithmic_GB_per_launch"]}
+                "traffic": pmc_traffic(args.workload), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, "
+                "profiles/; null unless taken with these kernel sources)",
+                "launches_timed": ko["launches_timed"], "avg_launch_ms": ko["avg_ms"],
+                "algorithmic_GB_per_launch": ko["designed_GB_per_launch"]}
+    keys_n = len(sim._key_names)
+    parallelism = "single GPU"
+    if world > 1:
+        parallelism = ("one simulation on %d GPUs: keys first, then HJB row blocks; replicated agents" % world if sharded
+                       else "ensemble of %d replicas, one per GPU" % world)
+    kf, kn = kstats["gcfm_forces"], kstats["gcfm_finish"]
+    kernel_step_ms = (kf["avg_ms"] + kn["avg_ms"]) if kf["avg_ms"] and kn["avg_ms"] else None
     result = {
-        "metric": "sim steps/sec (HJB sweep + GCFM update), 2048^2 grid x 100k agents",
-        "value": (1 if sharded else world) * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong" if sharded else "weak",
-        "vs_baseline": None,
+        "metric": "sim steps/sec (HJB sweep + GCFM update), %s %d^2 grid x %d agents" % (args.workload, sim.Nx, sim.N),
+        "value": (1 if sharded or world == 1 else world) * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K,
+        "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
+        "scaling": "strong" if sharded else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %dx%d grid, %d agents, %d keys, T=%g (nt=%d)"
-                               % (args.workload, sim.Nx, sim.Ny, sim.N, len(sim._key_names), sim.T, nt)
+                               % (args.workload, sim.Nx, sim.Ny, sim.N, keys_n, sim.T, nt)
                    + (", recompute=True" if sim.recompute else ""),
-                   "parallelism": ("one simulation on %d GPUs: HJB row blocks + replicated agents" % world if sharded else
-                                   "ensemble of %d replicas, one per GPU" % world) if world > 1 else "single GPU",
+                   "parallelism": parallelism, "mode": "sharded" if sharded else ("ensemble" if world > 1 else "single"),
                    "noise": "device Philox", "agent_state": "f64", "pair_math": "f32", "hjb_state": "f32"},
         "roofline": roof,
-        "breakdown": {"hjb_solve_s_total": t_hjb, "hjb_solves": sum(len(r) for r in stats),
-                      "gcfm_ms_per_step": 1e3 * (elapsed - t_hjb) / K, "nfev": nfev, "rk_attempts": n_att,
-                      "rk_accepted": n_acc, "kernels": kstats, "init_s": t_init, "active_agents_end": int(eng.counters.cpu()[2])},
+        "breakdown": {"hjb_solve_s_total_this_rank": t_hjb, "hjb_solves_this_rank": len(mine),
+                      "gcfm_kernel_ms_per_step": kernel_step_ms,
+                      "gcfm_kernel_ms_note": "k_forces + k_finish HIP-event times, sampled every 16th step (the steps are "
+                                             "enqueued and drain behind later host work, so wall-clock differences do not "
+                                             "isolate them)",
+                      "nfev": first["nfev"] if first else None, "rk_attempts": first["n_attempt"] if first else None,
+                      "rk_accepted": first["n_accept"] if first else None, "kernels": kstats, "init_s": t_init,
+                      "active_agents_end": int(eng.counters.cpu()[2]), "csrc_sha": csrc_hash()},
     }
-    kf = kstats.get("gcfm_forces", {})
-    nv = pmc_valu(args.workload)
-    if kf.get("avg_ms") and nv:
+    if world > 1:
+        sc = getattr(eng, "_step_comm", None)
+        comms = [c for c in getattr(eng, "_halo_comms", {}).values() if c is not None] if sharded else []
+        rowc = [c for c in comms if c.shard.world > 1]
+        result["rccl"] = {
+            "backend": backend, "ranks": world, "mode": "sharded" if sharded else "ensemble",
+            "hjb_key_plan": [list(p) for p in getattr(eng, "key_plan", [])] if sharded else None,
+            "step_allreduces": sc.n_allreduce if (sharded and sc) else 0,
+            "step_allreduce_bytes": (eng._xchg.numel() * 8 if sharded and getattr(eng, "_xchg", None) is not None else 0),
+            "collectives_per_step": 1 if sharded else 0,
+            "hjb_allgathers_this_rank": sum(c.n_allgather for c in rowc),
+            "hjb_halo_exchanges_this_rank": sum(c.n_exchange for c in rowc),
+            "hjb_halo_message_bytes": (rowc[0].halo_bytes if rowc and hasattr(rowc[0], "halo_bytes") else 0),
+            "hjb_collectives_per_attempt": ({"allgather_16B_per_rank": 1, "neighbour_halo_exchange": 1} if rowc else {}),
+            "counts_cover": "warm-up + timed region",
+        }
+    nv = pmc_step(args.workload)
+    if kf.get("avg_ms") and nv and nv.get("SQ_INSTS_VALU"):
         # the step's dominant kernel is bound by vector-instruction issue, not by HBM or MFMA: a plain (unpacked) VALU
         # instruction of a wavefront occupies its SIMD for 4 cycles -> peak = 1024 SIMDs x 2.4 GHz / 4
         peak = 256 * 4 * 2.4e9 / 4
-        ach = nv / (kf["avg_ms"] * 1e-3)
+        ach = nv["SQ_INSTS_VALU"] / (kf["avg_ms"] * 1e-3)
         result["roofline_valu"] = {"bound": "valu-issue", "kernel": "k_forces (pair forces + wall search + lookup)",
                                    "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
-                                   "frac": ach / peak, "valu_instructions_per_launch": nv,
+                                   "frac": ach / peak, "valu_instructions_per_launch": nv["SQ_INSTS_VALU"],
                                    "avg_launch_ms": kf["avg_ms"], "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/)"}
-        wc, bc, nw = (pmc_valu(args.workload, c) for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES"))
+        wc, bc, nw = (nv.get(c) for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES"))
         if wc and bc and nw:
             # SQ_WAVE_CYCLES counts quad-cycles summed over the waves; SQ_BUSY_CYCLES is summed over the chip's 32
             # shader engines (8 XCDs x 4), so busy/32 is the launch's length in shader cycles
-            resident = 4.0 * wc / (bc / 32.0)
             result["roofline_valu"]["occupancy"] = {
-                "waves_per_simd_allowed_by_registers": 4, "waves_per_simd_hardware": 8,
-                "mean_resident_waves_per_simd": resident / 1024.0, "waves_per_launch": nw,
-                "mean_wave_lifetime_us": 4.0 * wc / nw / (bc / 32.0) * kf["avg_ms"] * 1e3,
-                "source": "SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAVES (profiles/)"}
-    if rank == 0 and kf.get("avg_ms") and not args.no_work_count:
-        result["breakdown"]["gcfm_work"] = gcfm_work(sim, cfg, kf["avg_ms"] * 1e-3,
-                                                     result["breakdown"]["gcfm_ms_per_step"] * 1e-3)
+                "waves_per_simd_hardware": 8, "mean_resident_waves_per_simd": 4.0 * wc / (bc / 32.0) / 1024.0,
+                "waves_per_launch": nw, "source": "SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAVES (profiles/)"}
+    if rank == 0 and kf.get("avg_ms") and not args.no_work_count and not sharded:
+        result["breakdown"]["gcfm_work"] = gcfm_work(sim, cfg, kf["avg_ms"] * 1e-3, (kernel_step_ms or 1.0) * 1e-3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(sim, cfg, n_att, budget_s=float(os.environ.get("OC_BENCH_CPU_BUDGET", "20")))
-        result["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        result["cpu_baseline"] = cpu_baseline(sim, cfg, args.workload,
+                                              budget_s=float(os.environ.get("OC_BENCH_CPU_BUDGET", "25")))
+    if sharded and not args.no_ensemble_line:
+        # the other way to use N GPUs, measured right after: one independent replica per GPU (no data-path collective)
+        eng.close()
+        del sim, eng
+        torch.cuda.empty_cache()
+        sim2, _ = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius)
+        el2, _ = measure(sim2, args, nt, world, dist, red_dev)
+        result["ensemble"] = {"value": world * K / el2, "unit": "steps/s (aggregate over %d independent replicas)" % world,
+                              "scaling": "weak", "ms_per_step_per_replica": 1e3 * el2 / K}
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

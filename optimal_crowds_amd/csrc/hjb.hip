@@ -307,9 +307,10 @@ __global__ void __launch_bounds__(1024) k_reduce_final(const double* __restrict_
 // parts: nparts pairs (sum of squared scaled errors, max |y_new|) -- the stage kernel's per-block partials, or the
 // ranks' pairs after the all-gather of a row-block solve (summed in rank order on every rank: identical decisions).
 // att_log[attempt]: bit 0 = a real attempt, bit 1 = accepted, bits 8.. = direction-field slices its k_out writes.
-// mailbox (pinned host memory): [0] ticks (control launches so far, written last), [1] done, [2] status, [3] attempts.
+// mailbox (pinned host memory): ONE word = ticks (control launches so far) + 2^32 * done -- a single store, so the host
+// never sees a torn pair and the kernel needs no system-scope fence.
 template <typename T>
-__global__ void __launch_bounds__(1024) k_control(HjbCtl<T>* __restrict__ ctl, const double* __restrict__ parts,
+__global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, const double* __restrict__ parts,
                                                   int nparts, double* __restrict__ t_steps, int t_cap,
                                                   int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox) {
     __shared__ double ls[16], lm[16];
@@ -322,10 +323,7 @@ __global__ void __launch_bounds__(1024) k_control(HjbCtl<T>* __restrict__ ctl, c
             ctl->do_scale = 0;
             const int tk = ++ctl->ticks;
             if (tk - 1 < log_cap) att_log[tk - 1] = 0;
-            mailbox[1] = 1.0;
-            __threadfence_system();
-            mailbox[0] = (double)tk;
-            __threadfence_system();
+            mailbox[0] = (double)tk + 4294967296.0;
         }
         return;
     }
@@ -418,12 +416,7 @@ __global__ void __launch_bounds__(1024) k_control(HjbCtl<T>* __restrict__ ctl, c
     }
     const int tk = ++c.ticks;
     if (tk - 1 < log_cap) att_log[tk - 1] = logw;
-    mailbox[1] = (double)c.done;
-    mailbox[2] = (double)c.status;
-    mailbox[3] = (double)c.n_attempt;
-    __threadfence_system();
-    mailbox[0] = (double)tk;
-    __threadfence_system();
+    mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
 }
 
 // dense output (scipy rk.py:560-575): phi = y_old + h * sum_p (sum_j K_j P_jp) x^(p+1)
@@ -911,6 +904,11 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
     const int hn = (hr.kind == 1 || hr.kind == 2) ? 4 : (hr.kind >= 3 ? 1 : 0);
     if (hn) interp_coeffs<T>(y, kk, A.p, in_scale, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
     auto clip = [&](T v) { return (v > lim_s) ? v : ((v < lim_s) ? lim_s : (T)0); };
+    // the controller's per-slice factors: fetched once (a load from the controller block inside the slice loop would
+    // put a memory round trip into every slice)
+    __shared__ T s_hx[HJB_MAXS][4];
+    if ((int)threadIdx.x < 4 * n_hx) s_hx[threadIdx.x >> 2][threadIdx.x & 3] = ctl->hx[threadIdx.x >> 2][threadIdx.x & 3];
+    __syncthreads();
     int it = 0;
     for (int k = k_lo; k < k_hi; ++k) {
         // t_eval[k] <-> slice nt - 1 - k of the field; k = 0 (phi = 1 at t = T) is never used (optimals.py:200-204)
@@ -919,10 +917,10 @@ __global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
         if (!want_v && !keep) continue;
         T h1, h2, h3, h4;
         if (n_hx) {                                 // the controller's table (uniform loads)
-            h1 = ctl->hx[k - k_lo][0];
-            h2 = ctl->hx[k - k_lo][1];
-            h3 = ctl->hx[k - k_lo][2];
-            h4 = ctl->hx[k - k_lo][3];
+            h1 = s_hx[k - k_lo][0];
+            h2 = s_hx[k - k_lo][1];
+            h3 = s_hx[k - k_lo][2];
+            h4 = s_hx[k - k_lo][3];
         } else {
             const double te = (k == nt - 1) ? 0.0 : (double)k * te_step + Tf;
             const double x = (te - t0) / hh;
@@ -1282,8 +1280,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     ctl_prepare_attempt(hc, true);
     OC_HIP_CHECK(hipMemcpyAsync(ctl, &hc, sizeof(hc), hipMemcpyHostToDevice, s));
     OC_HIP_CHECK(hipStreamSynchronize(s));          // (hc lives on this stack frame)
-    volatile double* mb = h->red_host + 2 * OC_MAX_WORLD + 4;
-    mb[0] = mb[1] = mb[2] = mb[3] = 0.0;
+    volatile double* mb = h->red_host + 2 * OC_MAX_WORLD + 4;      // ticks + 2^32 * done (k_control)
+    mb[0] = 0.0;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     double* mb_dev = (double*)h->red_mailbox_dev + 4;
 
@@ -1331,7 +1329,9 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
 
     // profiling: events around the stage pair and around k_out of every attempt; which of them were real / accepted is
     // known only afterwards (att_log), so the sums are formed after the solve
-    const bool prof = h->profiling && (h->prof_mode & 1);
+    // (an event record between two kernels costs 3-6 us of stream time: every 8th attempt is timed, the averages are the same)
+    const bool prof_on = h->profiling && (h->prof_mode & 1);
+    const int PROF_EVERY = 8;
     std::vector<hipEvent_t>& ev = h->hjb_events;
     size_t ev_used = 0;
     auto event = [&]() -> hipEvent_t {
@@ -1345,7 +1345,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         return e;
     };
     int enq = 0;
+    std::vector<int> ev_attempt;                   // attempt index of every group of 4 events
     auto enqueue_attempt = [&]() -> int {
+        const bool prof = prof_on && (enq % PROF_EVERY == 0);
+        if (prof) ev_attempt.push_back(enq);
         if (prof) event();
         hipLaunchKernelGGL((k_stage3<T, 1, false>), grid3, dim3(F3_NT), 0, s, SA);
         hipLaunchKernelGGL((k_stage3<T, 4, true>), grid3, dim3(F3_NT), 0, s, SA);
@@ -1356,10 +1359,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                 oc_set_error("hjb_solve_rows: the allgather_red callback failed");
                 return OC_ERR_STATE;
             }
-            hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(1024), 0, s, ctl, (const double*)sh->red_all, sh->world,
+            hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, ctl, (const double*)sh->red_all, sh->world,
                                h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev);
         } else {
-            hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(1024), 0, s, ctl, (const double*)h->red_partial, nb3,
+            hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, ctl, (const double*)h->red_partial, nb3,
                                h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev);
         }
         if (halos) {
@@ -1394,13 +1397,14 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         } else {
             // let the device catch up to within LAG attempts of what is enqueued (or finish)
             for (long spin = 0;; ++spin) {
-                if (mb[1] != 0.0 || mb[0] >= (double)(enq - LAG)) break;
+                const double w = mb[0];
+                if (w >= 4294967296.0 || w >= (double)(enq - LAG)) break;
                 if ((spin & 4095) == 4095 && hipStreamQuery(s) == hipSuccess) break;
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        done = mb[1] != 0.0;
-        if (!done && !sh && hipStreamQuery(s) == hipSuccess && mb[0] < (double)enq) {
+        done = mb[0] >= 4294967296.0;
+        if (!done && hipStreamQuery(s) == hipSuccess && mb[0] < (double)enq) {
             // the stream drained but the mailbox did not move: mapped memory is not visible -> read the device copy
             OC_HIP_CHECK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
             done = hc.done != 0;
@@ -1416,13 +1420,17 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     const int n_real = hc.n_attempt;
     std::vector<int32_t> log((size_t)std::min(enq, LOG_CAP));
     if (!log.empty()) OC_HIP_CHECK(hipMemcpy(log.data(), h->hjb_log, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost));
-    if (prof) {
+    for (size_t a = 0; a < log.size(); ++a)
+        if (log[a] & 2) stats.n_slices_written += log[a] >> 8;
+    if (prof_on) {
         oc_timer& ts = h->timers["hjb_stage"];
         oc_timer& to = h->timers["hjb_out"];
-        for (int a = 0; a < enq && (size_t)(4 * a + 3) < ev_used && (size_t)a < log.size(); ++a) {
+        for (size_t g = 0; g < ev_attempt.size() && 4 * g + 3 < ev_used; ++g) {
+            const int a = ev_attempt[g];
+            if ((size_t)a >= log.size()) break;
             float e1 = 0.f, e2 = 0.f;
-            (void)hipEventElapsedTime(&e1, ev[4 * a], ev[4 * a + 1]);
-            (void)hipEventElapsedTime(&e2, ev[4 * a + 2], ev[4 * a + 3]);
+            (void)hipEventElapsedTime(&e1, ev[4 * g], ev[4 * g + 1]);
+            (void)hipEventElapsedTime(&e2, ev[4 * g + 2], ev[4 * g + 3]);
             if (log[a] & 1) {           // a real attempt: 16 array passes (launch A 6, launch B 10)
                 ts.add_ms += e1;
                 ts.add_n += 1;
@@ -1433,12 +1441,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                 to.add_ms += e2;
                 to.add_n += 1;
                 to.bytes += sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2));
-                stats.n_slices_written += nv;
             }
         }
-    } else {
-        for (size_t a = 0; a < log.size(); ++a)
-            if (log[a] & 2) stats.n_slices_written += log[a] >> 8;
     }
     if (t_steps && t_steps_cap > 0) {
         t_steps[0] = t0;

@@ -320,9 +320,21 @@ def dist_sharding(halo=8, by_key=True):
     return make
 
 
-def thread_sharding(rank, tw_solve, tw_step, halo=8):
-    """The same for virtual ranks in threads of one process (tests): two ThreadWorld registries, one per collective."""
+def thread_sharding(rank, tw_solve, tw_step, halo=8, plan=None):
+    """The same for virtual ranks in threads of one process (tests): tw_step = ThreadWorld of all ranks (the step's
+    all-reduce); tw_solve = ThreadWorld of all ranks (every key in row blocks over all of them), or -- with `plan`
+    (key_row_plan) -- a list with one ThreadWorld per key, sized to the key's rank group."""
     def make(eng):
-        sh = RowShard(eng.Ny, rank, tw_solve.world, halo)
-        return (ThreadHaloComm(sh, eng.Nx, eng.tdtype, eng.device, tw_solve), ThreadStepComm(rank, tw_step))
+        if plan is None:
+            sh = RowShard(eng.Ny, rank, tw_solve.world, halo)
+            return (ThreadHaloComm(sh, eng.Nx, eng.tdtype, eng.device, tw_solve), ThreadStepComm(rank, tw_step))
+        comms = {}
+        for k, ranks in enumerate(plan):
+            if rank in ranks:
+                sh = RowShard(eng.Ny, ranks.index(rank), len(ranks), halo)
+                comms[k] = ThreadHaloComm(sh, eng.Nx, eng.tdtype, eng.device, tw_solve[k])
+            else:
+                comms[k] = None
+        eng.key_plan = plan
+        return comms, ThreadStepComm(rank, tw_step)
     return make

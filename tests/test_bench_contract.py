@@ -12,7 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_line_has_the_contract_fields():
-    env = dict(os.environ, OC_BENCH_CPU_BUDGET="1.5")
+    env = dict(os.environ, OC_BENCH_CPU_BUDGET="1.5", OC_BENCH_NUMPY_STACK="0")
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "room_test", "--steps", "60",
                           "--warmup", "5"], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -30,5 +30,54 @@ def test_bench_line_has_the_contract_fields():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
     assert "roofline_valu" not in d      # priced from the committed PMC passes of the default workload only
+    assert "room_test" in d["metric"] and d["config"]["mode"] == "single"
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "steps/s" and c["sample"]
+    assert c["host_cpus"] >= c["cores"] and c["rk_attempts"] > 100
+    b = d["breakdown"]
+    assert b["kernels"]["hjb_stage"]["achieved_GBps"] < 8000.0          # priced with the bytes the launch pair moves
+    assert b["gcfm_kernel_ms_per_step"] > 0
+
+
+def _torchrun_bench(workload, extra=()):
+    """the driver's N > 1 command (one rank per GPU) rehearsed on this one-GPU box: both ranks on cuda:0, collectives
+    over gloo (OC_BENCH_ONE_DEVICE=1) -- the same bench.py code path, communicators and library calls as over RCCL"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OC_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--workload", workload, "--no-cpu-baseline", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_sharded_keys_first():
+    """2 keys on 2 ranks: each rank solves one key whole (no solve-time collective), agents replicated, one all-reduce
+    per step; the line says what RCCL would have carried, and carries the ensemble figure beside it"""
+    d = _torchrun_bench("exit_opposite", ("--mode", "sharded"))
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["mode"] == "sharded" and d["value"] > 0
+    r = d["rccl"]
+    assert r["ranks"] == 2 and r["hjb_key_plan"] == [[0], [1]] and r["collectives_per_step"] == 1
+    assert r["step_allreduces"] == 25 and r["step_allreduce_bytes"] == 8 * (6 * 5056 + 64)       # 5000 agents -> 79 tiles
+    assert r["hjb_allgathers_this_rank"] == 0 and r["hjb_halo_exchanges_this_rank"] == 0
+    assert d["breakdown"]["hjb_solves_this_rank"] == 1
+    e = d["ensemble"]
+    assert e["scaling"] == "weak" and e["value"] > 0
+
+
+def test_bench_two_ranks_sharded_row_blocks():
+    """1 key on 2 ranks: two row blocks, an all-gather of the error norm and a halo exchange per RK attempt"""
+    d = _torchrun_bench("slalom", ("--mode", "sharded", "--no-ensemble-line"))
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "ensemble" not in d
+    r = d["rccl"]
+    assert r["hjb_key_plan"] == [[0, 1]] and r["step_allreduces"] == 25
+    assert r["hjb_halo_exchanges_this_rank"] >= 2 * d["breakdown"]["rk_attempts"]                 # warm-up + timed solve
+    assert r["hjb_allgathers_this_rank"] == r["hjb_halo_exchanges_this_rank"] + 6
+    assert r["hjb_halo_message_bytes"] == 2 * 8 * 1024 * 4

@@ -116,8 +116,11 @@ def test_row_block_solve_matches_single_solve(room_name, world, halo, dtype):
     for sh, st, *_ in parts:
         assert st["n_attempt"] == st0["n_attempt"] and st["n_accept"] == st0["n_accept"]
         assert st["nfev"] == st0["nfev"]
-        assert st["n_exchange"] == (st0["n_accept"] if world > 1 else 0)
-        assert st["n_allgather"] == st0["n_attempt"] + 3          # + select_initial_step's three norms
+        # attempts are enqueued in bursts of 8 without waiting for the controller (it runs on the device): every attempt
+        # carries its collectives, the few enqueued past the end of the solve are no-ops on the device
+        enq = st["n_allgather"] - 3                               # - select_initial_step's three norms
+        assert st0["n_attempt"] <= enq < st0["n_attempt"] + 8 and enq % 8 == 0
+        assert st["n_exchange"] == (enq if world > 1 else 0)
         assert st["h_abs0"] == pytest.approx(st0["h_abs0"], rel=1e-12)
     phi = _assemble(parts, Ny, 4)
     vx, vy = _assemble(parts, Ny, 2), _assemble(parts, Ny, 3)

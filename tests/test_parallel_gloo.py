@@ -1,5 +1,6 @@
-"""N > 1 host logic on CPU: world_size-2 gloo runs of the row-block HJB partition (halo exchange + scalar
-all-reduce) and of the bench's timing reductions.  The oracle's RHS stands in for the HIP kernel."""
+"""N > 1 host logic on CPU: world_size-2 gloo runs of the key-first / row-block HJB partition (the communicators the
+product uses: halo exchange + all-gather of the error norm), of the step's all-reduce and of the bench's timing
+reductions.  The oracle's RHS stands in for the HIP kernel in the row-block RK45 model."""
 import os
 import socket
 
@@ -17,50 +18,44 @@ def _free_port():
     return p
 
 
-def _rhs_block(padded, V_blk, m_blk, sigma, mu, g, dx):
-    """5-point RHS of optimals.py:144-164 on a row block given its two halo rows (columns mirror locally)."""
-    p = np.empty((padded.shape[0], padded.shape[1] + 2))
-    p[:, 1:-1] = padded
-    p[:, 0] = p[:, 2]
-    p[:, -1] = p[:, -3]
-    lap = (p[:-2, 1:-1] + p[2:, 1:-1] + p[1:-1, :-2] + p[1:-1, 2:] - 4 * p[1:-1, 1:-1]) / (dx * dx)
-    out = -0.5 * sigma ** 2 * lap - ((V_blk + g * m_blk) * p[1:-1, 1:-1]) / (mu * sigma ** 2)
-    out[V_blk < 0] = 0
-    return out
+class _StubEngine:
+    """what parallel.dist_sharding needs of an engine (no GPU here)"""
+
+    def __init__(self, n_keys, Ny, Nx):
+        self.n_keys, self.Ny, self.Nx, self.tdtype, self.device = n_keys, Ny, Nx, torch.float64, torch.device("cpu")
 
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    from oracle import oc_oracle as oc
     from optimal_crowds_amd import parallel
     r, w = parallel.init_distributed("gloo")
     assert (r, w) == (rank, world)
-    rng = np.random.RandomState(0)                       # same data on every rank
-    Ny, Nx = 37, 24
-    phi = np.exp(rng.normal(size=(Ny, Nx)))
-    V = np.where(rng.rand(Ny, Nx) < 0.15, -100.0, 0.0)
-    V[0], V[-1], V[:, 0], V[:, -1] = -100, -100, -100, -100
-    V[0, 5:9] = 1.0                                       # a target on the border: the mirror rows matter
-    V[-1, 10:14] = 1.0
-    m = rng.rand(Ny, Nx)
-    full = oc.hjb_rhs(phi.ravel(), V, m, 0.2, 5, -0.005, 0.05, 0.05).reshape(Ny, Nx)
-    r0, r1 = parallel.row_blocks(Ny, world)[rank]
-    blk = torch.as_tensor(phi[r0:r1].copy())
-    above, below = parallel.halo_exchange(blk, rank, world)
-    pad = parallel.padded_block(blk, above, below).numpy()
-    mine = _rhs_block(pad, V[r0:r1], m[r0:r1], 0.2, 5, -0.005, 0.05)
-    ok_rhs = np.array_equal(mine, full[r0:r1])
-    s, mx = parallel.error_norm_allreduce(float((mine ** 2).sum()), float(np.abs(mine).max()))
-    ok_red = abs(s - (full ** 2).sum()) <= 1e-9 * (full ** 2).sum() and mx == np.abs(full).max()
     tmax = parallel.max_over_ranks(1.0 + rank)
     tsum = parallel.sum_over_ranks(10.0)
-    keys = parallel.key_partition(5, world, rank)
-    q.put((rank, ok_rhs, ok_red, tmax, tsum, keys, (r0, r1)))
+    # keys first, then row blocks (SURVEY 8e): 2 keys on 2 ranks -> one whole key per rank, no solve-time collective;
+    # 1 key on 2 ranks -> two row blocks with a neighbour each
+    eng2 = _StubEngine(2, 64, 16)
+    comms2, step2 = parallel.dist_sharding(halo=8)(eng2)
+    held = [k for k in range(2) if comms2[k] is not None]
+    shape2 = [(comms2[k].shard.world, comms2[k].shard.g0, comms2[k].shard.g1) for k in held]
+    eng1 = _StubEngine(1, 64, 16)
+    comms1, step1 = parallel.dist_sharding(halo=8)(eng1)
+    sh = comms1[0].shard
+    # the two collectives of a row-block solve through the key's communicator
+    comms1[0].red_local.copy_(torch.tensor([1.0 + rank, 10.0 * (rank + 1)], dtype=torch.float64))
+    comms1[0].allgather_red()
+    red = comms1[0].red_all.clone().numpy()
+    comms1[0].send_up.fill_(100.0 + rank)
+    comms1[0].send_dn.fill_(200.0 + rank)
+    comms1[0].exchange_halo()
+    got = (float(comms1[0].recv_up[0, 0, 0]) if sh.has_up else None, float(comms1[0].recv_dn[0, 0, 0]) if sh.has_dn else None)
+    q.put((rank, tmax, tsum, eng2.key_plan, held, shape2, eng1.key_plan, (sh.world, sh.g0, sh.g1), red.tolist(), got,
+           (step1.rank, step1.world)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_row_block_rhs_and_reductions_world2():
+def test_key_first_plan_and_collectives_world2():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -72,11 +67,29 @@ def test_row_block_rhs_and_reductions_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok_rhs, ok_red, tmax, tsum, keys, rows in res:
-        assert ok_rhs and ok_red
+    for rank, tmax, tsum, plan2, held, shape2, plan1, shape1, red, got, stepc in res:
         assert tmax == 2.0 and tsum == 20.0
-    assert res[0][5] == [0, 2, 4] and res[1][5] == [1, 3]
-    assert res[0][6] == (0, 19) and res[1][6] == (19, 37)
+        assert plan2 == [(0,), (1,)] and held == [rank] and shape2 == [(1, 0, 64)]
+        assert plan1 == [(0, 1)] and shape1 == (2, 32 * rank, 32 * rank + 32)
+        assert red == [[1.0, 10.0], [2.0, 20.0]]
+        assert stepc == (rank, 2)
+    assert res[0][9] == (None, 101.0) and res[1][9] == (200.0, None)      # my lower neighbour's send_up / upper's send_dn
+
+
+def test_key_row_plan():
+    from optimal_crowds_amd import parallel
+    assert parallel.key_row_plan(2, 4) == [(0, 1), (2, 3)]                 # C4 on 4 GPUs: 2 keys x 2-way rows
+    assert parallel.key_row_plan(2, 8) == [(0, 1, 2, 3), (4, 5, 6, 7)]
+    assert parallel.key_row_plan(1, 8) == [tuple(range(8))]                # C5: one key over all ranks
+    assert parallel.key_row_plan(2, 1) == [(0,), (0,)]
+    assert parallel.key_row_plan(3, 2) == [(0,), (1,), (0,)]
+    assert parallel.key_row_plan(2, 3) == [(0, 1), (2,)]
+    for K in range(1, 6):
+        for W in range(1, 9):
+            plan = parallel.key_row_plan(K, W)
+            assert len(plan) == K and all(len(p) >= 1 for p in plan)
+            if W >= K:                                                      # every rank solves exactly one key
+                assert sorted(r for p in plan for r in p) == list(range(W))
 
 
 def test_row_blocks_cover_grid():

@@ -293,3 +293,83 @@ def test_simulation_run_sharded_matches_single_gpu():
             assert np.array_equal(st[f], res[0][0][f])
         d = np.hypot(st["x"] - ref[0]["x"], st["y"] - ref[0]["y"])
         assert np.median(d) <= 1e-6 and (d > 1e-3).mean() <= 0.1
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_simulation_run_keys_first_then_rows(world):
+    """SURVEY 8e "partition by key first": gold_b has two target keys.  2 virtual ranks = one whole key per rank (no
+    solve-time collective at all); 4 ranks = 2 keys x 2-way row blocks.  A rank holds no field of the other group's key,
+    the step's lookups for those agents are answered by the ranks that do and travel with the all-reduce.  Against the
+    same run on one engine: same exits, same horizons, positions as in the row-block test."""
+    import contextlib
+    import io
+    from optimal_crowds_amd import host, parallel, simulations
+    cfg = copy.deepcopy(host.load_config())
+    Tsim = 2.0
+
+    def make(sharding):
+        np.random.seed(12)
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim = simulations.simulation("gold_b", Tsim, True, config=cfg, noise="device", seed=11, record=False,
+                                         history=False, wall_search_radius=0.0, sharding=sharding)
+        return sim
+
+    def finish(sim):
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim.run()
+        st = sim._engine.get_state()
+        held = [k for k in range(len(sim._key_names)) if sim._engine.holds_key(k)]
+        out = (st, sim.inside, sim.simu_step, [sim.targets[k].nt_opt for k in sim.targets], held)
+        sim._engine.close()
+        return out
+
+    ref = finish(make(None))
+    plan = parallel.key_row_plan(2, world)
+    assert plan == ([(0,), (1,)] if world == 2 else [(0, 1), (2, 3)])
+    tw_keys = [parallel.ThreadWorld(len(r)) for r in plan]
+    tw_step = parallel.ThreadWorld(world)
+    lock = threading.Lock()
+    sims = [None] * world
+
+    def body(rank, tw):
+        with lock:          # np.random is process-global: the ranks construct one after the other
+            sims[rank] = make(parallel.thread_sharding(rank, tw_keys, tw_step, plan=plan))
+        tw.barrier.wait(timeout=120)
+        return finish(sims[rank])
+
+    res = _run_ranks(world, body)
+    for rank, (st, inside, nstep, nts, held) in enumerate(res):
+        assert held == [k for k in range(2) if rank in plan[k]]
+        assert (inside, nstep, nts) == (ref[1], ref[2], ref[3])
+        assert np.array_equal(st["status"], ref[0]["status"])
+        for f in ("x", "y", "vx", "vy"):
+            assert np.array_equal(st[f], res[0][0][f])                  # replicas bit-identical
+        d = np.hypot(st["x"] - ref[0]["x"], st["y"] - ref[0]["y"])
+        assert np.median(d) <= 1e-6 and (d > 1e-3).mean() <= 0.1
+
+
+def test_index_error_band_is_seen_by_every_rank():
+    """An agent in the reference's IndexError band (quirk Q8) is noticed by the rank that holds its key's field; the flag
+    travels with the exchange buffer, so EVERY rank reports it (and none blocks in the next collective)."""
+    from optimal_crowds_amd import parallel
+    world = 2
+    tw_keys = [parallel.ThreadWorld(1), parallel.ThreadWorld(1)]
+
+    def body(rank, tw):
+        eng, room, cfg, names = _new("gold_b")
+        x, y, vx, vy, vdes, key, status = _state(room, 2, n=500)
+        # one agent of key 1 inside the band x in [(Nx-3) dx, L - dx)
+        Nx = eng.Nx
+        x[7], key[7], status[7] = (Nx - 3) * cfg["grid_step"] + 0.01, 1, True
+        # keys dealt to ranks: rank r holds key r whole
+        eng.enable_sharding(*parallel.thread_sharding(rank, tw_keys, tw, plan=[(0,), (1,)])(eng))
+        for k in range(2):
+            eng.alloc_field(k, NT - 1)
+            eng.solve(k, T, NT)
+        eng.set_agents(x, y, vx, vy, vdes, key, status=status)
+        exited, bad, active = eng.step(3, seed=5)
+        eng.close()
+        return bad
+
+    res = _run_ranks(world, body)
+    assert res[0] == res[1] == 8                                        # 1 + agent index, on both ranks
