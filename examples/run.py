@@ -4,9 +4,12 @@
 
 `room` is a name of the packaged room library (room_test, gold_a, gold_b, exit_opposite, slalom, metro_station,
 open_room) or of a JSON file rooms/<room>.json in the working directory, exactly as in the reference."""
+import os
 import sys
 
-from optimal_crowds_amd import simulations          # was: from optimal_crowds import simulations
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))     # the repository root
+
+from optimal_crowds import simulations              # the reference's own import line (alias of optimal_crowds_amd)
 
 room = sys.argv[1] if len(sys.argv) > 1 else "room_test"
 T = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0

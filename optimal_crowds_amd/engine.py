@@ -23,6 +23,18 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def hjb_state_dtype(cfg, T, requested="float32"):
+    """The arithmetic type of the HJB state for horizon T.  float32 carries phi * 2^-e (csrc/hjb.hip, range management):
+    phi grows to e^(T V_target / (mu sigma^2)) while the far field stays at 1, so the scaled far field 2^-e -- and the
+    clip level lim * 2^-e -- leave float32's normal range when log2(e) T V_target / (mu sigma^2) - 64 exceeds ~118
+    (T > 25 s with the reference's config).  Beyond that the same kernels run in float64 (twice the bytes, no limit)."""
+    if requested not in ("float32", "f32", torch.float32):
+        return "float64"
+    hp = cfg["hjb_params"]
+    bits = 1.4426950408889634 * float(T) * abs(hp["target_potential"]) / (hp["mu"] * hp["sigma"] ** 2)
+    return "float32" if bits - 64.0 <= 118.0 else "float64"
+
+
 class Engine:
     def __init__(self, cfg, room_length, room_height, Nx, Ny, X0, Y0, n_keys, max_agents,
                  device="cuda:0", dtype="float32", wall_search_radius=0.0):

@@ -66,9 +66,9 @@ class optimals:
         if _sim is not None:
             self._engine = _sim._engine
         else:
-            from .engine import Engine
+            from .engine import Engine, hjb_state_dtype
             self._engine = Engine(var_config, self.room_length, self.room_height, self.Nx, self.Ny, self._X0,
-                                  self._Y0, 1, 16, device=device, dtype=dtype)
+                                  self._Y0, 1, 16, device=device, dtype=hjb_state_dtype(var_config, T, dtype))
             rects = np.array([var_room['targets'][t] for t in target.split(' or ') if t in var_room['targets']],
                              dtype=np.float64).reshape(-1, 4)
             self._engine.set_potential(0, self.V, rects)

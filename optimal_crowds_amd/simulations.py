@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import host, optimals as optimals_mod, pedestrians
-from .engine import Engine
+from .engine import Engine, hjb_state_dtype
 
 warnings.filterwarnings("ignore")
 
@@ -163,8 +163,10 @@ class simulation:
         self._nt0 = nt0
         if wall_search_radius is None:
             wall_search_radius = -1.0          # per-agent radius beyond which the wall force is < 1e-12 m/s
+        # float32 HJB state unless the horizon takes phi beyond what its range management covers (T > ~25 s): float64 then
+        self.hjb_dtype = hjb_state_dtype(var_config, T, dtype)
         self._engine = Engine(var_config, self.room_length, self.room_height, self.Nx, self.Ny, self._X0, self._Y0,
-                              len(key_names), self.N, device=device, dtype=dtype,
+                              len(key_names), self.N, device=device, dtype=self.hjb_dtype,
                               wall_search_radius=wall_search_radius)
         eng = self._engine
         # ---- potentials (reference simulations.py:104-121, 516-576; finalised like optimals.__init__ does, Q3)

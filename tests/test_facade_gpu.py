@@ -150,3 +150,42 @@ def test_run_without_a_round_trip_per_step_ends_where_the_stepwise_loop_ends():
     assert a[4] == b[4]
     assert a[5] == b[5] and a[5].startswith("Evacuation complete")
     assert np.array_equal(a[6], b[6])
+
+
+def test_long_horizon_switches_the_hjb_state_to_float64():
+    """T = 30 s: phi reaches e^150, beyond what float32's range management covers (the solve used to end with a NaN
+    error norm); the facade then runs the same kernels on a float64 state -- checked against the oracle's solve -- while
+    T = 20 s stays float32."""
+    from optimal_crowds_amd import simulations
+    from optimal_crowds_amd.engine import hjb_state_dtype
+    cfg = _cfg()
+    assert hjb_state_dtype(cfg, 20.0) == "float32" and hjb_state_dtype(cfg, 25.0) == "float32"
+    assert hjb_state_dtype(cfg, 30.0) == "float64" and hjb_state_dtype(cfg, 30.0, "float64") == "float64"
+    T = 30.0
+    np.random.seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim = simulations.simulation("gold_a", T, config=cfg, noise="host", record=False)
+        assert sim.hjb_dtype == "float64"
+        key = sim._key_names[0]
+        sim.targets[key].compute_optimal_velocity(0.0, None)
+    st = sim.targets[key].stats
+    assert st["n_rescale"] == 0 and st["n_slices_written"] == round(T / cfg["dt"]) - 1
+    opt = oc.Optimals(sim.Vs[key].copy(), T, sim.room_length, sim.room_height, cfg)
+    opt.compute_optimal_velocity(0.0, np.zeros((sim.Ny, sim.Nx)))
+    assert st["n_accept"] == opt.stats["n_accept"] and st["nfev"] == opt.stats["nfev"]
+    vx, vy = sim.targets[key].vx_opt, sim.targets[key].vy_opt
+    for s in (0, 700, 1498):
+        gx, gy, hx, hy = opt.vx_opt[s], opt.vy_opt[s], vx[s], vy[s]
+        assert not np.isnan(hx).any()
+        same = (np.hypot(gx, gy) > 0.5) == (np.hypot(hx, hy) > 0.5)
+        assert same.mean() >= 0.999
+        assert np.abs(hx - gx)[same].max() <= 1e-5 and np.abs(hy - gy)[same].max() <= 1e-5
+
+
+def test_reference_import_line_works_unmodified():
+    """`from optimal_crowds import simulations` (the reference's README recipe) resolves to this implementation"""
+    import optimal_crowds
+    from optimal_crowds import simulations as s1
+    from optimal_crowds_amd import simulations as s2
+    import optimal_crowds.optimals as o1
+    assert s1 is s2 and o1 is optimal_crowds.optimals and hasattr(s1, "simulation")
