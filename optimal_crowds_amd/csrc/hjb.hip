@@ -819,6 +819,124 @@ __global__ void __launch_bounds__(F3_NT) k_stage3(Stage3Args<T> A) {
     }
 }
 
+// ---- all six stages of an RK attempt in ONE launch ----------------------------------------------------------------
+// The same scheme as k_stage3 carried through the whole attempt: a TX x TY tile + a 6-cell halo (one ring per stencil
+// application), y, K0 and coef read once on the region, K1 .. K6 and y_new computed in registers with the stage's
+// working value going through a double-buffered LDS tile, and only what the rest of the step needs written back:
+// K2 .. K5 (K1 has no weight in y_new, the error or the dense output: B_1 = E_1 = P_1. = 0), K6, y_new.
+//   reads  y, K0, coef  (x the halo overlap, served by L2)      writes  K2, K3, K4, K5, K6, y_new     = 9 array passes
+// against 16 for the two k_stage3 launches.  The arithmetic per cell is the same sequence, so results are bit-identical.
+template <typename T, int TX, int TY, int NT>
+__global__ void __launch_bounds__(NT) k_stage6(Stage3Args<T> A) {
+    constexpr int NQ = 6, RW = TX + 2 * NQ, RH = TY + 2 * NQ, LS = RW + 2, NCELL = RW * RH, NC = (NCELL + NT - 1) / NT;
+    __shared__ T buf[2][RH][LS];
+    const HjbCtl<T>* __restrict__ ctl = A.ctl;
+    if (ctl->done) return;
+    const int par = ctl->parity;
+    T cc[NQ][6], he[7];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) cc[q][j] = q < 3 ? ctl->cA[q][j] : ctl->cB[q - 3][j];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) he[j] = ctl->he[j];
+    const T atol_s = ctl->atol_s, in_scale = ctl->in_scale;
+    const T* __restrict__ y = A.Y[par];
+    const T* __restrict__ k0 = A.KX[par];
+    T* const kout[5] = {A.KM[1], A.KM[2], A.KM[3], A.KM[4], A.KX[par ^ 1]};      // K2 .. K6
+    T* const ynew = A.Y[par ^ 1];
+    const int Ny = A.Ny, Nx = A.Nx;
+    const int nbx = (Nx + TX - 1) / TX, nby = (Ny + TY - 1) / TY, nb = nbx * nby;
+    const int per = (nb + 7) / 8;
+    const int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);        // XCD-aware order (tile_of_block)
+    if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
+    const int i0 = (logical / nbx) * TY - NQ, j0 = (logical % nbx) * TX - NQ;       // region origin
+    T yv[NC], kv[NQ + 1][NC], cf[NC], tq[NC];
+    int row[NC], col[NC], ring[NC];         // ring < 0: not a cell of the room
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        const int c = (int)threadIdx.x + NT * m;
+        row[m] = c / RW;
+        col[m] = c - row[m] * RW;
+        const int gi = i0 + row[m], gj = j0 + col[m];
+        const bool in = c < NCELL && gi >= 0 && gi < Ny && gj >= 0 && gj < Nx;
+        ring[m] = in ? min(min(row[m], RH - 1 - row[m]), min(col[m], RW - 1 - col[m])) : -1;
+        yv[m] = cf[m] = tq[m] = (T)0;
+#pragma unroll
+        for (int j = 0; j <= NQ; ++j) kv[j][m] = (T)0;
+        if (in) {
+            const int64_t idx = (int64_t)gi * Nx + gj;
+            yv[m] = y[idx] * in_scale;
+            kv[0][m] = k0[idx] * in_scale;
+            if (ring[m] >= 1) cf[m] = A.coef[idx];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+            if (ring[m] >= q) {
+                T t = (T)0;
+#pragma unroll
+                for (int j = 0; j <= q; ++j) t += cc[q][j] * kv[j][m];
+                t = yv[m] + t;
+                tq[m] = t;
+                buf[q & 1][row[m]][col[m]] = t;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+            if (ring[m] >= q + 1) {
+                const int gi = i0 + row[m], gj = j0 + col[m];
+                const int ru = (gi == 0) ? row[m] + 1 : row[m] - 1, rd = (gi == Ny - 1) ? row[m] - 1 : row[m] + 1;
+                const int cl = (gj == 0) ? col[m] + 1 : col[m] - 1, cr = (gj == Nx - 1) ? col[m] - 1 : col[m] + 1;
+                const T C = tq[m];
+                const T sum = buf[q & 1][ru][col[m]] + buf[q & 1][rd][col[m]] + buf[q & 1][row[m]][cl] +
+                              buf[q & 1][row[m]][cr] - (T)4 * C;
+                kv[q + 1][m] = (cf[m] != cf[m]) ? (T)0 : A.a_lap * sum - cf[m] * C;
+            }
+        }
+    }
+    double esum = 0.0, ymax = 0.0;
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        if (ring[m] >= NQ) {
+            const int gi = i0 + row[m], gj = j0 + col[m];
+            const int64_t idx = (int64_t)gi * Nx + gj;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) kout[q][idx] = kv[2 + q][m];
+            ynew[idx] = tq[m];
+            if (gi >= A.row_lo && gi < A.row_hi) {
+                T e = he[6] * kv[6][m];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) e += he[j] * kv[j][m];
+                const T sc = atol_s + fmax(fabs(yv[m]), fabs(tq[m])) * A.rtol;
+                const T qq = e / sc;
+                esum += (double)qq * (double)qq;
+                ymax = fmax(ymax, (double)fabs(tq[m]));
+            }
+        }
+    }
+    __shared__ double ls[NT / 64], lm[NT / 64];
+    esum = wave_sum(esum);
+    ymax = wave_max(ymax);
+    if ((threadIdx.x & 63) == 0) {
+        ls[threadIdx.x >> 6] = esum;
+        lm[threadIdx.x >> 6] = ymax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < NT / 64; ++q) {
+            a += ls[q];
+            b = fmax(b, lm[q]);
+        }
+        A.partial[2 * logical] = a;
+        A.partial[2 * logical + 1] = b;
+    }
+}
+
 // Dense output + direction field for every t_eval point of one accepted step, in one pass: the quartic
 // interpolant's coefficients Q = K^T P (scipy rk.py:178-180) stay in registers, each slice's phi goes through a
 // double-buffered LDS tile, and vels (optimals.py:168-186) writes the slice of the (padded) direction field.
@@ -879,7 +997,7 @@ __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_out(OutArgs<T> A) {
+__global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves per SIMD: at most 128 VGPRs
     __shared__ alignas(16) T tile[2][HT_LH][HT_LS];
     const HjbCtl<T>* __restrict__ ctl = A.ctl;
     if (!ctl->accepted) return;                     // a rejected attempt (or one past the end) has nothing to emit
@@ -1300,8 +1418,16 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     SA.Nx = S.Nx;
     SA.row_lo = own_lo;
     SA.row_hi = own_hi;
-    const int nb3 = ((S.Nx + F3_X - 1) / F3_X) * ((S.Ny + F3_Y - 1) / F3_Y);
+    // stage launches: 0 = two launches of three stages (k_stage3), else all six in one (k_stage6) with tile shape
+    // 1: 64 x 32 / 1024 threads, 2: 64 x 16 / 512, 3: 32 x 32 / 512, 4: 128 x 16 / 1024, 5: 64 x 64 / 1024
+    const int fuse = h->hjb_fuse;
+    const int f6x[6] = {F3_X, 64, 64, 32, 128, 64}, f6y[6] = {F3_Y, 32, 16, 32, 16, 64};
+    const int nb3 = ((S.Nx + f6x[fuse] - 1) / f6x[fuse]) * ((S.Ny + f6y[fuse] - 1) / f6y[fuse]);
     const dim3 grid3(8 * ((nb3 + 7) / 8));
+    if (nb3 > h->red_blocks) {
+        oc_set_error("hjb_solve: %d tiles exceed the reduction buffer (%d)", nb3, h->red_blocks);
+        return OC_ERR_STATE;
+    }
     OutArgs<T> OA;
     memset(&OA, 0, sizeof(OA));
     OA.ctl = ctl;
@@ -1350,8 +1476,16 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         const bool prof = prof_on && (enq % PROF_EVERY == 0);
         if (prof) ev_attempt.push_back(enq);
         if (prof) event();
-        hipLaunchKernelGGL((k_stage3<T, 1, false>), grid3, dim3(F3_NT), 0, s, SA);
-        hipLaunchKernelGGL((k_stage3<T, 4, true>), grid3, dim3(F3_NT), 0, s, SA);
+        switch (fuse) {
+            case 1: hipLaunchKernelGGL((k_stage6<T, 64, 32, 1024>), grid3, dim3(1024), 0, s, SA); break;
+            case 2: hipLaunchKernelGGL((k_stage6<T, 64, 16, 512>), grid3, dim3(512), 0, s, SA); break;
+            case 3: hipLaunchKernelGGL((k_stage6<T, 32, 32, 512>), grid3, dim3(512), 0, s, SA); break;
+            case 4: hipLaunchKernelGGL((k_stage6<T, 128, 16, 1024>), grid3, dim3(1024), 0, s, SA); break;
+            case 5: hipLaunchKernelGGL((k_stage6<T, 64, 64, 1024>), grid3, dim3(1024), 0, s, SA); break;
+            default:
+                hipLaunchKernelGGL((k_stage3<T, 1, false>), grid3, dim3(F3_NT), 0, s, SA);
+                hipLaunchKernelGGL((k_stage3<T, 4, true>), grid3, dim3(F3_NT), 0, s, SA);
+        }
         if (prof) event();
         if (sh) {
             hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, nb3, sh->red_local);
@@ -1431,10 +1565,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             float e1 = 0.f, e2 = 0.f;
             (void)hipEventElapsedTime(&e1, ev[4 * g], ev[4 * g + 1]);
             (void)hipEventElapsedTime(&e2, ev[4 * g + 2], ev[4 * g + 3]);
-            if (log[a] & 1) {           // a real attempt: 16 array passes (launch A 6, launch B 10)
+            if (log[a] & 1) {           // a real attempt: 16 array passes (launch A 6, launch B 10), or 9 in one launch
                 ts.add_ms += e1;
                 ts.add_n += 1;
-                ts.bytes += 16.0 * sizeof(T) * (double)n;
+                ts.bytes += (fuse ? 9.0 : 16.0) * sizeof(T) * (double)n;
             }
             if (log[a] & 2) {           // accepted: k_out read y + 6 stage arrays once, wrote 2 components per slice
                 const int nv = log[a] >> 8;

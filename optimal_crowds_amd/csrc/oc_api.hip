@@ -227,6 +227,9 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     } else if (!strcmp(name, "resort_every")) {
         OC_REQUIRE(value >= 1 && value <= 4096, "resort_every out of range");
         h->resort_every = value;
+    } else if (!strcmp(name, "hjb_fuse")) {
+        OC_REQUIRE(value >= 0 && value <= 5, "hjb_fuse out of range");
+        h->hjb_fuse = value;
     } else if (!strcmp(name, "seq_margin_mm")) {
         OC_REQUIRE(value >= 1 && value <= 1500, "seq_margin_mm out of range");
         h->seq_margin = 1e-3 * value;

