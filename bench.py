@@ -349,7 +349,7 @@ def main():
     t_hjb = sum(s["seconds"] for s in mine)
     first = mine[0] if mine else None
     kstats = {}
-    for name in ("hjb_out", "hjb_stage", "gcfm_forces", "gcfm_finish"):
+    for name in ("hjb_out", "hjb_stage", "gcfm_forces", "gcfm_finish", "density"):
         nl, ms, by = eng.kernel_stats(name)
         kstats[name] = {"launches_timed": nl, "avg_ms": (ms / nl if nl else None),
                         "designed_GB_per_launch": (by / nl / 1e9 if nl else None),

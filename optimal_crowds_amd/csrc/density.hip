@@ -3,7 +3,9 @@
 // (the reference's normaliser, quirk Q11; 2 pi sigma^2 with OC_FIX_DENSITY_NORM)
 // Agents are ordered by coarse cells of side R = trunc_sigmas*sigma; an output tile only visits the agents of the
 // coarse cells that intersect tile +- R (row-major keys make each coarse row one contiguous slot range).  Everything
-// inside those cells is summed exactly (no radial test), what is dropped is < exp(-trunc^2/2) relative.
+// inside those cells is summed (no radial test), what is dropped is < exp(-trunc^2/2) relative.  The exponential is
+// evaluated in its separable form exp(-dx^2/2s^2) exp(-dy^2/2s^2): equal to the reference's single exp of the sum up
+// to two float64 roundings per term.
 #include "oc_internal.h"
 #include <cmath>
 
@@ -53,19 +55,22 @@ __global__ void k_dens_cellstart(const uint32_t* __restrict__ keys_sorted, int N
     cs[c] = lo;
 }
 
-// block = 16 x 16 output cells
+// The Gaussian is separable: exp(-(dx^2 + dy^2)/(2 s^2)) = ex(column, agent) * ey(row, agent).  A block
+// owns DT_X x DT_Y = 32 x 16 output cells; per batch of DB agents it evaluates the 48 one-dimensional factors of every
+// agent once (24 exp per thread instead of one per cell and agent: 512 -> 48 per agent and tile) into LDS and then adds
+// the rank-one products: 2 outputs per thread, one float64 FMA and 1.5 LDS reads per output and agent.
+#define DT_X 32
+#define DT_Y 16
+#define DB 128
 template <typename T>
 __global__ void __launch_bounds__(256) k_density(DensParams P, const double2* __restrict__ spos,
                                                  const int32_t* __restrict__ cs, const double* __restrict__ X0,
                                                  const double* __restrict__ Y0, const float* __restrict__ Vall,
                                                  T* __restrict__ out) {
-    __shared__ double2 l_p[256];
+    __shared__ double lex[DB][DT_X], ley[DB][DT_Y];            // 48 KB
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int j = blockIdx.x * 16 + tx, i = blockIdx.y * 16 + ty;
-    const int j0 = blockIdx.x * 16, i0 = blockIdx.y * 16;
-    const int j1 = min(j0 + 15, P.Nx - 1), i1 = min(i0 + 15, P.Ny - 1);
-    const bool valid = (i < P.Ny && j < P.Nx);
-    const double X = valid ? X0[j] : 0.0, Y = valid ? Y0[i] : 0.0;
+    const int j0 = blockIdx.x * DT_X, i0 = blockIdx.y * DT_Y;
+    const int j1 = min(j0 + DT_X - 1, P.Nx - 1), i1 = min(i0 + DT_Y - 1, P.Ny - 1);
     // coarse cells intersecting tile +- cell
     auto cc = [&](double v, int n) {
         double f = floor(v / P.cell);
@@ -73,28 +78,55 @@ __global__ void __launch_bounds__(256) k_density(DensParams P, const double2* __
     };
     const int cx0 = cc(X0[j0] - P.cell, P.ncx), cx1 = cc(X0[j1] + P.cell, P.ncx);
     const int cy0 = cc(Y0[i0] - P.cell, P.ncy), cy1 = cc(Y0[i1] + P.cell, P.ncy);
-    double acc = 0.0;
+    // this thread's share of the factor table: agent fq of the batch, 24 of its 48 factors
+    const int fq = threadIdx.x & (DB - 1), fpart = threadIdx.x >> 7;
+    double acc0 = 0.0, acc1 = 0.0;
     for (int cy = cy0; cy <= cy1; ++cy) {
         const int s0 = cs[cy * P.ncx + cx0], s1 = cs[cy * P.ncx + cx1 + 1];
-        for (int base = s0; base < s1; base += 256) {
+        for (int base = s0; base < s1; base += DB) {
+            const int cnt = min(DB, s1 - base);
             __syncthreads();
-            int k = base + threadIdx.x;
-            if (k < s1) l_p[threadIdx.x] = spos[k];
-            __syncthreads();
-            int cnt = min(256, s1 - base);
-            if (valid) {
-                for (int q = 0; q < cnt; ++q) {
-                    double2 p = l_p[q];
-                    double ddx = X - p.x, ddy = Y - p.y;
-                    acc += exp(-(ddx * ddx + ddy * ddy) * P.inv2s2) * P.invC;
+            if (fq < cnt) {
+                const double2 p = spos[base + fq];
+                if (fpart == 0) {
+#pragma unroll 4
+                    for (int c = 0; c < 24; ++c) {
+                        const double d = X0[min(j0 + c, P.Nx - 1)] - p.x;
+                        lex[fq][c] = exp(-(d * d) * P.inv2s2) * P.invC;
+                    }
+                } else {
+#pragma unroll 4
+                    for (int c = 24; c < DT_X; ++c) {
+                        const double d = X0[min(j0 + c, P.Nx - 1)] - p.x;
+                        lex[fq][c] = exp(-(d * d) * P.inv2s2) * P.invC;
+                    }
+#pragma unroll 4
+                    for (int c = 0; c < DT_Y; ++c) {
+                        const double d = Y0[min(i0 + c, P.Ny - 1)] - p.y;
+                        ley[fq][c] = exp(-(d * d) * P.inv2s2);
+                    }
                 }
+            }
+            __syncthreads();
+            for (int q = 0; q < cnt; ++q) {
+                const double ey = ley[q][ty];
+                acc0 += lex[q][tx] * ey;
+                acc1 += lex[q][tx + 16] * ey;
             }
         }
     }
-    if (valid) {
-        size_t o = (size_t)i * P.Nx + j;
-        if (Vall && Vall[o] < 0.f) acc = 0.0;
-        out[o] = (T)acc;
+    const int i = i0 + ty;
+    if (i < P.Ny) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = j0 + tx + 16 * u;
+            if (j < P.Nx) {
+                const size_t o = (size_t)i * P.Nx + j;
+                double v = u ? acc1 : acc0;
+                if (Vall && Vall[o] < 0.f) v = 0.0;
+                out[o] = (T)v;
+            }
+        }
     }
 }
 
@@ -152,11 +184,14 @@ extern "C" int oc_density(oc_handle* h, int dtype, const oc_agents* a, double si
         nact_slots = N;
     }
     hipLaunchKernelGGL(k_dens_cellstart, dim3((ncell + 1 + 255) / 256), dim3(256), 0, s, kb, nact_slots, ncell, cs);
-    dim3 g((c.Nx + 15) / 16, (c.Ny + 15) / 16);
+    dim3 g((c.Nx + DT_X - 1) / DT_X, (c.Ny + DT_Y - 1) / DT_Y);
+    oc_timer_begin(h, "density", s);
     if (dtype == OC_F32)
         hipLaunchKernelGGL(k_density<float>, g, dim3(256), 0, s, P, spos, cs, h->X0, h->Y0, V_all, (float*)out);
     else
         hipLaunchKernelGGL(k_density<double>, g, dim3(256), 0, s, P, spos, cs, h->X0, h->Y0, V_all, (double*)out);
+    // algorithmic bytes: the agents' positions once + the grid written once (the kernel is bound by float64 exp / FMA)
+    oc_timer_end(h, "density", s, 16.0 * N + (dtype == OC_F32 ? 4.0 : 8.0) * (double)c.Nx * c.Ny);
     OC_HIP_CHECK(hipGetLastError());
     return OC_OK;
 }

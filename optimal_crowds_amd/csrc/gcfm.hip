@@ -678,7 +678,9 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 int il_cur = -1;
                 double2 pa = make_double2(0.0, 0.0);
                 float4 va = make_float4(0.f, 0.f, 0.f, 0.f), aux = va;
-                f2v sf = {0.f, 0.f};
+                // the chunk's sums are float64: every pair's float32 force is added exactly, so the result does not
+                // depend on how the launch shape (pair_split, chunk boundaries) groups the pairs
+                double sfx = 0.0, sfy = 0.0;
                 for (int tt = e_beg; tt < e_end; ++tt) {
                     const uint32_t e = lst[tt];
                     const int il = e >> 16, jA = e & 127, jB = (e >> 7) & 127;
@@ -687,11 +689,11 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                     const float2 hbA = L.l_head[w][jA], hbB = L.l_head[w][jB];
                     if (il != il_cur) {
                         if (il_cur >= 0) {
-                            atomicAdd(&L.accx[tl][il_cur], (double)sf.x);
-                            atomicAdd(&L.accy[tl][il_cur], (double)sf.y);
+                            atomicAdd(&L.accx[tl][il_cur], sfx);
+                            atomicAdd(&L.accy[tl][il_cur], sfy);
                         }
                         il_cur = il;
-                        sf = (f2v){0.f, 0.f};
+                        sfx = sfy = 0.0;
                         pa = L.li_pos[tl][il];
                         va = L.li_vel[tl][il];
                         aux = L.li_aux[tl][il];
@@ -708,13 +710,13 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                                    aux.y, va.w, aux.z, aux.w, (f2v){vbA.x, vbB.x}, (f2v){vbA.y, vbB.y},
                                    (f2v){vbA.z, vbB.z}, (f2v){vbA.w, vbB.w}, (f2v){hbA.x, hbB.x}, (f2v){hbA.y, hbB.y},
                                    b_max, db, neg_inv_eta_log2e, unit_dir, fx, fy);
-                        const f2v fA = {okA ? fx.x : 0.f, okA ? fy.x : 0.f}, fB = {okB ? fx.y : 0.f, okB ? fy.y : 0.f};
-                        sf += fA + fB;
+                        sfx += (double)(okA ? fx.x : 0.f) + (double)(okB ? fx.y : 0.f);
+                        sfy += (double)(okA ? fy.x : 0.f) + (double)(okB ? fy.y : 0.f);
                     }
                 }
                 if (il_cur >= 0) {
-                    atomicAdd(&L.accx[tl][il_cur], (double)sf.x);
-                    atomicAdd(&L.accy[tl][il_cur], (double)sf.y);
+                    atomicAdd(&L.accx[tl][il_cur], sfx);
+                    atomicAdd(&L.accy[tl][il_cur], sfy);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();

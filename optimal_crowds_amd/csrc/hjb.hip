@@ -311,22 +311,20 @@ __global__ void __launch_bounds__(1024) k_reduce_final(const double* __restrict_
 // never sees a torn pair and the kernel needs no system-scope fence.
 template <typename T>
 __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, const double* __restrict__ parts,
-                                                  int nparts, double* __restrict__ t_steps, int t_cap,
-                                                  int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox) {
-    __shared__ double ls[16], lm[16];
-    __shared__ int s_done;
-    if (threadIdx.x == 0) s_done = ctl->done;
-    __syncthreads();
-    if (s_done) {                               // an attempt enqueued past the end of the solve
-        if (threadIdx.x == 0) {
-            ctl->accepted = 0;
-            ctl->do_scale = 0;
-            const int tk = ++ctl->ticks;
-            if (tk - 1 < log_cap) att_log[tk - 1] = 0;
-            mailbox[0] = (double)tk + 4294967296.0;
-        }
-        return;
+                                                 int nparts, double* __restrict__ t_steps, int t_cap,
+                                                 int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox) {
+    // the controller block is worked on in LDS (one coalesced load, one coalesced store): thread 0's serial code would
+    // otherwise pay a memory round trip for every field it touches
+    __shared__ HjbCtl<T> c;
+    __shared__ double ls[4], lm[4];
+    constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
+    static_assert(sizeof(HjbCtl<T>) % 4 == 0, "controller block must be a whole number of words");
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&c);
+        for (int i = threadIdx.x; i < NW32; i += blockDim.x) dst[i] = src[i];
     }
+    // the attempt's error sums (issued together with the block's load; unused if the solve is over)
     const double2* __restrict__ p2 = reinterpret_cast<const double2*>(parts);
     double s = 0.0, m = 0.0;
     const int nth = blockDim.x;
@@ -342,81 +340,92 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
     }
     s = wave_sum(s);
     m = wave_max(m);
-    const int w = threadIdx.x >> 6, nw = (nth + 63) >> 6;
     if ((threadIdx.x & 63) == 0) {
-        ls[w] = s;
-        lm[w] = m;
+        ls[threadIdx.x >> 6] = s;
+        lm[threadIdx.x >> 6] = m;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    double esum = 0.0, ymax = 0.0;
-    for (int q = 0; q < nw; ++q) {
-        esum += ls[q];
-        ymax = fmax(ymax, lm[q]);
-    }
-    HjbCtl<T>& c = *ctl;
-    const double err = sqrt(esum) / sqrt(c.n_rms);
-    ++c.n_attempt;
-    c.accepted = 0;
-    c.do_scale = 0;
-    int logw = 1;
-    if (!(err == err)) {
-        c.status = OC_ERR_SOLVER - 100;         // NaN error norm (state overflow)
-        c.done = 1;
-    } else if (err < 1) {
-        double factor = (err == 0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
-        if (c.rejected) factor = fmin(1.0, factor);
-        const double hstep = fabs(c.hh);
-        c.h_abs *= factor;
-        c.h_min = fmin(c.h_min, hstep);
-        c.h_max = fmax(c.h_max, hstep);
-        c.accepted = 1;
-        c.out_parity = c.parity;
-        c.parity ^= 1;
-        c.out_t = c.t;
-        c.out_hh = c.hh;
-        c.out_unscale = ldexp(1.0, c.expo);
-        c.out_lim_s = (T)(c.lim * ldexp(1.0, -c.expo));
-        c.k_lo = c.k_next;
-        int nv = 0;
-        while (c.k_next < c.nt && ctl_te(c, c.k_next) >= c.t_new) {
-            nv += c.k_next >= 1 ? 1 : 0;
-            ++c.k_next;
-        }
-        c.k_hi = c.k_next;
-        c.n_hx = (c.k_hi - c.k_lo <= HJB_MAXS) ? c.k_hi - c.k_lo : 0;
-        for (int q = 0; q < c.n_hx; ++q) {      // dense output (rk.py:560-575): x = (t_eval - t_old) / h, powers 1..4
-            const double x = (ctl_te(c, c.k_lo + q) - c.t) / c.hh;
-            double xp = x;
-            for (int pp = 0; pp < 4; ++pp) {
-                c.hx[q][pp] = (T)(c.hh * xp);
-                xp *= x;
+    if (threadIdx.x == 0) {
+        int logw = 0;
+        if (c.done) {                               // an attempt enqueued past the end of the solve
+            c.accepted = 0;
+            c.do_scale = 0;
+        } else {
+            double esum = 0.0, ymax = 0.0;
+            for (int q = 0; q < (nth + 63) / 64; ++q) {
+                esum += ls[q];
+                ymax = fmax(ymax, lm[q]);
+            }
+            const double err = sqrt(esum) / sqrt(c.n_rms);
+            ++c.n_attempt;
+            c.accepted = 0;
+            c.do_scale = 0;
+            logw = 1;
+            if (!(err == err)) {
+                c.status = OC_ERR_SOLVER - 100;     // NaN error norm (state overflow)
+                c.done = 1;
+            } else if (err < 1) {
+                double factor = (err == 0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+                if (c.rejected) factor = fmin(1.0, factor);
+                const double hstep = fabs(c.hh);
+                c.h_abs *= factor;
+                c.h_min = fmin(c.h_min, hstep);
+                c.h_max = fmax(c.h_max, hstep);
+                c.accepted = 1;
+                c.out_parity = c.parity;
+                c.parity ^= 1;
+                c.out_t = c.t;
+                c.out_hh = c.hh;
+                c.out_unscale = ldexp(1.0, c.expo);
+                c.out_lim_s = (T)(c.lim * ldexp(1.0, -c.expo));
+                c.k_lo = c.k_next;
+                int nv = 0;
+                while (c.k_next < c.nt && ctl_te(c, c.k_next) >= c.t_new) {
+                    nv += c.k_next >= 1 ? 1 : 0;
+                    ++c.k_next;
+                }
+                c.k_hi = c.k_next;
+                c.n_hx = (c.k_hi - c.k_lo <= HJB_MAXS) ? c.k_hi - c.k_lo : 0;
+                for (int q = 0; q < c.n_hx; ++q) {  // dense output (rk.py:560-575): x = (t_eval - t_old) / h, powers 1..4
+                    const double x = (ctl_te(c, c.k_lo + q) - c.t) / c.hh;
+                    double xp = x;
+                    for (int pp = 0; pp < 4; ++pp) {
+                        c.hx[q][pp] = (T)(c.hh * xp);
+                        xp *= x;
+                    }
+                }
+                c.out_in_scale = c.in_scale;
+                c.in_scale = (T)1;
+                c.t = c.t_new;
+                ++c.n_accept;
+                if (c.n_tsteps < t_cap) t_steps[c.n_tsteps++] = c.t;
+                if (c.is_f32 && ymax > 0x1p64) {    // range management: keep max |y| near 2^32
+                    const int e = (int)floor(log2(ymax)) - 32;
+                    c.in_scale = (T)ldexp(1.0, -e);
+                    c.do_scale = 1;
+                    c.expo += e;
+                    ++c.n_rescale;
+                }
+                c.rejected = 0;
+                logw |= 2 | (nv << 8);
+                if (-(c.t - c.tf) >= 0) c.done = 1; // direction = -1
+                else ctl_prepare_attempt(c, true);
+            } else {
+                c.h_abs *= fmax(0.2, 0.9 * pow(err, -0.2));
+                c.rejected = 1;
+                ctl_prepare_attempt(c, false);
             }
         }
-        c.out_in_scale = c.in_scale;
-        c.in_scale = (T)1;
-        c.t = c.t_new;
-        ++c.n_accept;
-        if (c.n_tsteps < t_cap) t_steps[c.n_tsteps++] = c.t;
-        if (c.is_f32 && ymax > 0x1p64) {        // range management: keep max |y| near 2^32
-            const int e = (int)floor(log2(ymax)) - 32;
-            c.in_scale = (T)ldexp(1.0, -e);
-            c.do_scale = 1;
-            c.expo += e;
-            ++c.n_rescale;
-        }
-        c.rejected = 0;
-        logw |= 2 | (nv << 8);
-        if (-(c.t - c.tf) >= 0) c.done = 1;     // direction = -1
-        else ctl_prepare_attempt(c, true);
-    } else {
-        c.h_abs *= fmax(0.2, 0.9 * pow(err, -0.2));
-        c.rejected = 1;
-        ctl_prepare_attempt(c, false);
+        const int tk = ++c.ticks;
+        if (tk - 1 < log_cap) att_log[tk - 1] = logw;
+        mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
     }
-    const int tk = ++c.ticks;
-    if (tk - 1 < log_cap) att_log[tk - 1] = logw;
-    mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
+    __syncthreads();
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(ctl);
+        for (int i = threadIdx.x; i < NW32; i += blockDim.x) dst[i] = src[i];
+    }
 }
 
 // dense output (scipy rk.py:560-575): phi = y_old + h * sum_p (sum_j K_j P_jp) x^(p+1)
@@ -937,6 +946,155 @@ __global__ void __launch_bounds__(NT) k_stage6(Stage3Args<T> A) {
     }
 }
 
+// ---- lean multi-stage kernel: four cells of a row per thread, no per-cell index arithmetic ------------------------
+// k_stage3 / k_stage6 deal the region's cells to the threads round-robin; that costs ~100 instructions of index and
+// predicate arithmetic per cell and stage (measured: 450 SIMD cycles per wavefront-cell-stage; the launch time scales
+// with the cell count, not with the bytes).  Here a thread owns FOUR consecutive cells of one region row for the whole
+// launch: its inputs are 16-byte loads, the working value of a stage goes to LDS as one ds_write_b128, the stencil
+// needs two ds_read_b128 (the rows above and below) and two scalars (the cells left and right of the vector), and all
+// addresses are fixed offsets from the thread's own slot.  Nothing is predicated inside the stages: every thread
+// computes every stage, values within NQ cells of the region's edge are garbage by then and are simply not stored
+// (halo NQ rows, and 4 ceil(NQ/4) columns so that vectors stay aligned).  The mirror ghosts of the room border
+// (optimals.py:149-152) are extra LDS stores by the threads of row 1 / Ny-2 and of the first / last vector of a row.
+//   NQ = 3: two launches per attempt (A: K1..K3 from y, K0; B: K4, K5, y_new, K6 + error), region 128 x 32 -> tile 120 x 26
+//   NQ = 6: one launch (writes K2..K6, y_new), region 128 x 32 -> tile 112 x 20
+// Same arithmetic per cell as k_stage3: bit-identical results.
+template <typename T, int NQ, int S0, bool FINAL, int RWV, int RH>
+__global__ void __launch_bounds__(RWV * RH) k_stageV(Stage3Args<T> A) {
+    constexpr int HX = 4 * ((NQ + 3) / 4), HY = NQ, RW = 4 * RWV, NT = RWV * RH;
+    constexpr int TX = RW - 2 * HX, TY = RH - 2 * HY, LS = RW + 8;
+    constexpr int NK = S0 + NQ;                     // stage derivatives alive at the end of the launch
+    static_assert(NQ == 3 || (NQ == 6 && S0 == 1 && FINAL), "three stages per launch, or the whole attempt");
+    __shared__ alignas(16) T buf[2][RH + 2][LS];    // slot of region cell (r, c): [r + 1][c + 4]; one spare ring
+    const HjbCtl<T>* __restrict__ ctl = A.ctl;
+    if (ctl->done) return;                          // an attempt enqueued past the end of the solve
+    const int par = ctl->parity;
+    T cc[NQ][6], he[7];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (NQ == 6) cc[q][j] = q < 3 ? ctl->cA[q][j] : ctl->cB[q - 3][j];
+            else cc[q][j] = FINAL ? ctl->cB[q][j] : ctl->cA[q][j];
+        }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) he[j] = FINAL ? ctl->he[j] : (T)0;
+    const T atol_s = ctl->atol_s, in_scale = ctl->in_scale;
+    const T* __restrict__ y = A.Y[par];
+    const T* kin[4] = {A.KX[par], A.KM[0], A.KM[1], A.KM[2]};
+    T* ynew = A.Y[par ^ 1];
+    const int Ny = A.Ny, Nx = A.Nx;
+    const int nbx = (Nx + TX - 1) / TX, nby = (Ny + TY - 1) / TY, nb = nbx * nby;
+    const int per = (nb + 7) / 8;
+    const int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);        // XCD-aware order (tile_of_block)
+    if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
+    const int vx = (int)threadIdx.x % RWV, ry = (int)threadIdx.x / RWV;
+    const int gi = (logical / nbx) * TY - HY + ry, gj = (logical % nbx) * TX - HX + 4 * vx;
+    const bool in = gi >= 0 && gi < Ny && gj >= 0 && gj < Nx;      // (Nx % 4 == 0: a vector is inside or outside as a whole)
+    const int64_t idx = (int64_t)gi * Nx + gj;
+    V4<T> yv, cf, kv[NK], t;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        yv.v[c] = cf.v[c] = t.v[c] = (T)0;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) kv[j].v[c] = (T)0;
+    }
+    if (in) {
+        yv = ld4(y + idx);
+        cf = ld4(A.coef + idx);
+#pragma unroll
+        for (int j = 0; j < S0; ++j) kv[j] = ld4(kin[j] + idx);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            yv.v[c] *= in_scale;                    // (1 unless the previous step ordered a rescale: exact)
+            kv[0].v[c] *= in_scale;
+        }
+    }
+    T* const slot0 = &buf[0][ry + 1][4 + 4 * vx];
+    constexpr int BUF = (RH + 2) * LS;              // elements between the two buffers
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        T* const slot = slot0 + (q & 1) * BUF;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            T acc = (T)0;
+#pragma unroll
+            for (int j = 0; j < S0 + q; ++j) acc += cc[q][j] * kv[j].v[c];
+            t.v[c] = yv.v[c] + acc;
+        }
+        if (in) {
+            st4(slot, t);
+            if (gi == 1 && ry >= 1) st4(slot - 2 * LS, t);                  // ghost row -1 = row 1
+            if (gi == Ny - 2 && ry + 2 <= RH - 1) st4(slot + 2 * LS, t);   // ghost row Ny = row Ny-2
+            if (gj == 0) slot[-1] = t.v[1];                                 // ghost column -1 = column 1
+            if (gj + 3 == Nx - 1) slot[4] = t.v[2];                         // ghost column Nx = column Nx-2
+        }
+        __syncthreads();
+        const V4<T> up = ld4(slot - LS), dn = ld4(slot + LS);
+        const T lft = slot[-1], rgt = slot[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const T C = t.v[c];
+            const T l = (c == 0) ? lft : t.v[c - 1], r = (c == 3) ? rgt : t.v[c + 1];
+            const T sum = up.v[c] + dn.v[c] + l + r - (T)4 * C;
+            kv[S0 + q].v[c] = (cf.v[c] != cf.v[c]) ? (T)0 : A.a_lap * sum - cf.v[c] * C;
+        }
+    }
+    const bool store = in && ry >= HY && ry < RH - HY && vx >= HX / 4 && vx < RWV - HX / 4;
+    double esum = 0.0, ymax = 0.0;
+    if (store) {
+        if (NQ == 6) {                              // K2 .. K5, K6 (K1 is not needed again), y_new
+            st4(A.KM[1] + idx, kv[2]);
+            st4(A.KM[2] + idx, kv[3]);
+            st4(A.KM[3] + idx, kv[4]);
+            st4(A.KM[4] + idx, kv[5]);
+            st4(A.KX[par ^ 1] + idx, kv[6]);
+        } else if (!FINAL) {
+            st4(A.KM[0] + idx, kv[S0]);
+            st4(A.KM[1] + idx, kv[S0 + 1]);
+            st4(A.KM[2] + idx, kv[S0 + 2]);
+        } else {
+            st4(A.KM[3] + idx, kv[S0]);
+            st4(A.KM[4] + idx, kv[S0 + 1]);
+            st4(A.KX[par ^ 1] + idx, kv[S0 + 2]);
+        }
+        if (FINAL) {
+            st4(ynew + idx, t);                     // the last stage's working value IS y_new
+            if (gi >= A.row_lo && gi < A.row_hi) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    T e = he[6] * kv[NK - 1].v[c];
+#pragma unroll
+                    for (int j = 0; j < NK - 1; ++j) e += he[j] * kv[j].v[c];
+                    const T sc = atol_s + fmax(fabs(yv.v[c]), fabs(t.v[c])) * A.rtol;
+                    const T qq = e / sc;
+                    esum += (double)qq * (double)qq;
+                    ymax = fmax(ymax, (double)fabs(t.v[c]));
+                }
+            }
+        }
+    }
+    if (FINAL) {
+        __shared__ double ls[NT / 64], lm[NT / 64];
+        esum = wave_sum(esum);
+        ymax = wave_max(ymax);
+        if ((threadIdx.x & 63) == 0) {
+            ls[threadIdx.x >> 6] = esum;
+            lm[threadIdx.x >> 6] = ymax;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0, b = 0.0;
+            for (int q = 0; q < NT / 64; ++q) {
+                a += ls[q];
+                b = fmax(b, lm[q]);
+            }
+            A.partial[2 * logical] = a;
+            A.partial[2 * logical + 1] = b;
+        }
+    }
+}
+
 // Dense output + direction field for every t_eval point of one accepted step, in one pass: the quartic
 // interpolant's coefficients Q = K^T P (scipy rk.py:178-180) stay in registers, each slice's phi goes through a
 // double-buffered LDS tile, and vels (optimals.py:168-186) writes the slice of the (padded) direction field.
@@ -1024,6 +1182,9 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
     auto clip = [&](T v) { return (v > lim_s) ? v : ((v < lim_s) ? lim_s : (T)0); };
     // the controller's per-slice factors: fetched once (a load from the controller block inside the slice loop would
     // put a memory round trip into every slice)
+    int bmask = 0;                                  // cells of this thread on the grid's border ring (written as 0)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bmask |= (gi < 1 || gi >= Ny - 1 || gj + q < 1 || gj + q >= Nx - 1) ? (1 << q) : 0;
     __shared__ T s_hx[HJB_MAXS][4];
     if ((int)threadIdx.x < 4 * n_hx) s_hx[threadIdx.x >> 2][threadIdx.x & 3] = ctl->hx[threadIdx.x >> 2][threadIdx.x & 3];
     __syncthreads();
@@ -1055,12 +1216,17 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
         T* vys = want_v ? A.vy_base + (size_t)(nt - 1 - k) * A.slice_elems : nullptr;
         const int buf = it & 1;
         ++it;
-        V4<T> ph;
+        // The tile holds the CLIPPED phi (optimals.py:172: every use below is of the clipped value), so each cell is
+        // clipped once instead of five times -- once as a centre and once by each of its four neighbours.
+        V4<T> pcl;
         if (valid) {
+            V4<T> ph;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
                 ph.v[q] = yq[q] + (((Q[q][0] * h1 + Q[q][1] * h2) + Q[q][2] * h3) + Q[q][3] * h4);
-            st4(&tile[buf][ry + 1][4 + 4 * cx], ph);
+                pcl.v[q] = clip(ph.v[q]);
+            }
+            st4(&tile[buf][ry + 1][4 + 4 * cx], pcl);
             if (keep) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) keep[idx + q] = (double)ph.v[q] * unscale;
@@ -1070,10 +1236,10 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
             V4<T> hp;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                hp.v[q] = hy[q] + (((hQ[q][0] * h1 + hQ[q][1] * h2) + hQ[q][2] * h3) + hQ[q][3] * h4);
+                hp.v[q] = clip(hy[q] + (((hQ[q][0] * h1 + hQ[q][1] * h2) + hQ[q][2] * h3) + hQ[q][3] * h4));
             st4(&tile[buf][hr.li][hr.lj], hp);
         } else if (hn == 1) {
-            tile[buf][hr.li][hr.lj] = hy[0] + (((hQ[0][0] * h1 + hQ[0][1] * h2) + hQ[0][2] * h3) + hQ[0][3] * h4);
+            tile[buf][hr.li][hr.lj] = clip(hy[0] + (((hQ[0][0] * h1 + hQ[0][1] * h2) + hQ[0][2] * h3) + hQ[0][3] * h4));
         }
         __syncthreads();
         if (vxs && valid) {
@@ -1083,13 +1249,13 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // central differences of the clipped phi (optimals.py:172-180); "north" = row i+1
-                const T pw = clip((q == 0) ? lft : ph.v[q - 1]), pe = clip((q == 3) ? rgt : ph.v[q + 1]);
-                const T ps = clip(up.v[q]), pn = clip(dn.v[q]);
-                const T pc = clip(clip(ph.v[q]));
+                const T pw = (q == 0) ? lft : pcl.v[q - 1], pe = (q == 3) ? rgt : pcl.v[q + 1];
+                const T ps = up.v[q], pn = dn.v[q];
+                const T pc = clip(pcl.v[q]);                // the reference clips the centre a second time (:177)
                 const T gx = (pe - pw) * A.inv2dx, gy = (pn - ps) * A.inv2dy;
                 T vxo, vyo;
                 direction_of<T>(gx, gy, A.mu * pc, A.lim, vxo, vyo);
-                const bool border = gi < 1 || gi >= Ny - 1 || gj + q < 1 || gj + q >= Nx - 1;
+                const bool border = (bmask >> q) & 1;
                 ox.v[q] = border ? (T)0 : vxo;
                 oy.v[q] = border ? (T)0 : vyo;
             }
@@ -1421,7 +1587,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // stage launches: 0 = two launches of three stages (k_stage3), else all six in one (k_stage6) with tile shape
     // 1: 64 x 32 / 1024 threads, 2: 64 x 16 / 512, 3: 32 x 32 / 512, 4: 128 x 16 / 1024, 5: 64 x 64 / 1024
     const int fuse = h->hjb_fuse;
-    const int f6x[6] = {F3_X, 64, 64, 32, 128, 64}, f6y[6] = {F3_Y, 32, 16, 32, 16, 64};
+    // 6: lean kernel (k_stageV), two launches of three stages, tile 120 x 26;  7: lean, all six, tile 112 x 20
+    const int f6x[8] = {F3_X, 64, 64, 32, 128, 64, 120, 112}, f6y[8] = {F3_Y, 32, 16, 32, 16, 64, 26, 20};
     const int nb3 = ((S.Nx + f6x[fuse] - 1) / f6x[fuse]) * ((S.Ny + f6y[fuse] - 1) / f6y[fuse]);
     const dim3 grid3(8 * ((nb3 + 7) / 8));
     if (nb3 > h->red_blocks) {
@@ -1482,6 +1649,11 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             case 3: hipLaunchKernelGGL((k_stage6<T, 32, 32, 512>), grid3, dim3(512), 0, s, SA); break;
             case 4: hipLaunchKernelGGL((k_stage6<T, 128, 16, 1024>), grid3, dim3(1024), 0, s, SA); break;
             case 5: hipLaunchKernelGGL((k_stage6<T, 64, 64, 1024>), grid3, dim3(1024), 0, s, SA); break;
+            case 6:
+                hipLaunchKernelGGL((k_stageV<T, 3, 1, false, 32, 32>), grid3, dim3(1024), 0, s, SA);
+                hipLaunchKernelGGL((k_stageV<T, 3, 4, true, 32, 32>), grid3, dim3(1024), 0, s, SA);
+                break;
+            case 7: hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32>), grid3, dim3(1024), 0, s, SA); break;
             default:
                 hipLaunchKernelGGL((k_stage3<T, 1, false>), grid3, dim3(F3_NT), 0, s, SA);
                 hipLaunchKernelGGL((k_stage3<T, 4, true>), grid3, dim3(F3_NT), 0, s, SA);
@@ -1568,7 +1740,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             if (log[a] & 1) {           // a real attempt: 16 array passes (launch A 6, launch B 10), or 9 in one launch
                 ts.add_ms += e1;
                 ts.add_n += 1;
-                ts.bytes += (fuse ? 9.0 : 16.0) * sizeof(T) * (double)n;
+                ts.bytes += ((fuse >= 1 && fuse != 6) ? 9.0 : 16.0) * sizeof(T) * (double)n;
             }
             if (log[a] & 2) {           // accepted: k_out read y + 6 stage arrays once, wrote 2 components per slice
                 const int nv = log[a] >> 8;

@@ -1,6 +1,7 @@
 // Handle lifetime, error reporting and kernel timers of liboc_hip.so.
 #include "oc_internal.h"
 #include <cstdarg>
+#include <cstdlib>
 #include <algorithm>
 
 static thread_local char g_err[1024] = "";
@@ -57,6 +58,10 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
     OC_HIP_CHECK(hipHostMalloc(&h->red_host, sizeof(double) * (2 * OC_MAX_WORLD + 8), hipHostMallocMapped));
     memset(h->red_host, 0, sizeof(double) * (2 * OC_MAX_WORLD + 8));
     OC_HIP_CHECK(hipHostGetDevicePointer(&h->red_mailbox_dev, h->red_host + 2 * OC_MAX_WORLD, 0));
+    if (const char* e = getenv("OC_HJB_FUSE")) {        // A/B of the stage-launch shapes over a whole test run
+        const int v = atoi(e);
+        if (v >= 0 && v <= 7) h->hjb_fuse = v;
+    }
     *out = h;
     return OC_OK;
 }
@@ -104,7 +109,7 @@ extern "C" int oc_set_profiling(oc_handle* h, int mode) {
 // between the 2 launches of a step cost ~14 us of a 144 us step, so the bench samples them)
 static bool timer_on(oc_handle* h, const char* name) {
     if (!h->profiling) return false;
-    if (name[0] == 'h') return (h->prof_mode & 1) != 0;
+    if (name[0] == 'h' || name[0] == 'd') return (h->prof_mode & 1) != 0;     // HJB kernels, density
     if (h->prof_mode & 2) return true;
     return (h->prof_mode & 4) && (h->prof_tick % 16 == 0);
 }
@@ -228,7 +233,7 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
         OC_REQUIRE(value >= 1 && value <= 4096, "resort_every out of range");
         h->resort_every = value;
     } else if (!strcmp(name, "hjb_fuse")) {
-        OC_REQUIRE(value >= 0 && value <= 5, "hjb_fuse out of range");
+        OC_REQUIRE(value >= 0 && value <= 7, "hjb_fuse out of range");
         h->hjb_fuse = value;
     } else if (!strcmp(name, "seq_margin_mm")) {
         OC_REQUIRE(value >= 1 && value <= 1500, "seq_margin_mm out of range");

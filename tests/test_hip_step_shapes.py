@@ -77,10 +77,10 @@ def test_pair_split_and_prep_blocks_do_not_change_the_step(dtype):
             st_r, out_r = ref[(1, steps)]
             assert out == out_r                                     # (exits, IndexError flag, active) per step
             assert np.array_equal(st["status"], st_r["status"])
-            # every pair force is bit-identical; the sums are float32 per list chunk and float64 across chunks, and
-            # the split changes the chunking: ~1e-7 relative on forces of a few m/s, x = x + 0.02 v.  (In this dense
-            # random crowd a perturbation grows ~5x per step, which is the dynamics, not the kernel.)
-            tx, tv = (2e-8, 2e-6) if steps == 1 else (2e-7, 2e-5)
+            # every pair force is bit-identical and the sums are float64 throughout (per list chunk and across chunks):
+            # the split only changes the order of float64 additions -- 1e-16 relative on forces of a few m/s.  (In
+            # this dense random crowd a perturbation grows ~5x per step, which is the dynamics, not the kernel.)
+            tx, tv = (1e-13, 1e-12) if steps == 1 else (1e-12, 1e-11)
             for f, tol in (("x", tx), ("y", tx), ("vx", tv), ("vy", tv)):
                 assert np.abs(st[f] - st_r[f]).max() <= tol, (split, prep, steps, f)
     with pytest.raises(Exception):

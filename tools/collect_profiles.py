@@ -14,8 +14,11 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+workload = sys.argv[2] if len(sys.argv) > 2 else "metro_station"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench                                           # noqa: E402  (csrc_hash: the stamp bench.py checks)
 G = os.path.join(REPO, "gpurun_out")
 P = os.path.join(REPO, "profiles")
 os.makedirs(P, exist_ok=True)
@@ -23,10 +26,11 @@ os.makedirs(P, exist_ok=True)
 
 def short(name):
     for k in ("k_out", "k_forces", "k_finish", "k_pack", "k_tile_lists", "k_cell_keys", "k_edt", "k_wallmap", "k_reduce_final",
-              "k_rhs", "k_lincomb", "k_scale", "k_fill", "k_make_coef", "k_norm_scaled", "k_density"):
+              "k_rhs", "k_lincomb", "k_scale", "k_fill", "k_make_coef", "k_norm_scaled", "k_density", "k_control",
+              "k_halo_stage", "k_seq_pairs"):
         if k + "<" in name or k + "(" in name:
             return k
-    for k in ("k_stage3<", "k_stage<"):
+    for k in ("k_stage3<", "k_stage6<", "k_stage<"):
         if k in name:
             a = name.index(k)
             return name[a:name.index(">", a) + 1].replace("float, ", "").replace(" ", "")
@@ -63,5 +67,22 @@ if traffic:
         traffic["k_out_hbm_bytes_per_launch"] = 2 * ko_f["avg_KB_per_launch"] * 1024 + ko_w["avg_KB_per_launch"] * 1024
         traffic["note"] = ("k_out: 2 x FETCH_SIZE (gfx950 correction for 16 B/lane reads) + WRITE_SIZE, KB -> bytes, "
                            "average over the launches of a --steps 20 run (separate --pmc passes)")
-    json.dump(traffic, open(os.path.join(P, tag + "_pmc_traffic.json"), "w"), indent=1)
+    traffic["csrc_sha"] = bench.csrc_hash()         # bench.py quotes the file only for the kernels it was taken with
+    traffic["workload"] = workload
+    json.dump(traffic, open(os.path.join(P, tag + "_pmc_traffic" + ("" if workload == "metro_station" else "_" + workload)
+                                         + ".json"), "w"), indent=1)
+# SQ counters of the step kernels (tools/pmc_step.sh): mean per launch -> JSON with the same stamp
+step_txt = os.path.join(G, tag + "_pmc_step.txt")
+if os.path.exists(step_txt):
+    import re
+    txt = open(step_txt).read()
+    shutil.copy(step_txt, os.path.join(P, tag + "_pmc_step_kernels.txt"))
+    step = {"csrc_sha": bench.csrc_hash(), "workload": workload}
+    for kn in ("k_forces", "k_finish"):
+        if kn in txt:
+            blk = txt[txt.index(kn):]
+            nxt = [blk.index(o) for o in ("k_forces", "k_finish") if o != kn and o in blk[1:]]
+            blk = blk[:min(nxt)] if nxt else blk
+            step[kn] = {m.group(1): float(m.group(2)) for m in re.finditer(r"(\w+)\s+n=\d+\s+mean=([0-9.e+]+)", blk)}
+    json.dump(step, open(os.path.join(P, tag + "_pmc_step.json"), "w"), indent=1)
 print("profiles:", sorted(os.listdir(P)))

@@ -1,5 +1,5 @@
 # The profile runs of profiles/README.md in one go (on the GPU box, from the repo root): bash tools/run_profiles.sh r01
-tag=${1:-r01}
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python bench.py > gpurun_out/${tag}_bench_plain.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python bench.py --no-work-count > gpurun_out/${tag}_bench.log 2>&1 || exit 1
