@@ -946,16 +946,57 @@ __global__ void __launch_bounds__(NT) k_stage6(Stage3Args<T> A) {
     }
 }
 
+// value of the previous / next lane of the wavefront (DPP wave shifts: no LDS traffic; lane 0 / 63 get 0)
+__device__ __forceinline__ float lane_prev(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));      // wave_shr:1
+}
+__device__ __forceinline__ float lane_next(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));      // wave_shl:1
+}
+// the same within rows of 16 lanes (k_out: 16 vectors = one 64-cell tile row)
+__device__ __forceinline__ float row_prev(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));      // row_shr:1
+}
+__device__ __forceinline__ float row_next(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, false));      // row_shl:1
+}
+__device__ __forceinline__ double row_prev(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x111, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x111, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double row_next(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x101, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x101, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double lane_prev(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double lane_next(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // ---- lean multi-stage kernel: four cells of a row per thread, no per-cell index arithmetic ------------------------
 // k_stage3 / k_stage6 deal the region's cells to the threads round-robin; that costs ~100 instructions of index and
 // predicate arithmetic per cell and stage (measured: 450 SIMD cycles per wavefront-cell-stage; the launch time scales
 // with the cell count, not with the bytes).  Here a thread owns FOUR consecutive cells of one region row for the whole
 // launch: its inputs are 16-byte loads, the working value of a stage goes to LDS as one ds_write_b128, the stencil
-// needs two ds_read_b128 (the rows above and below) and two scalars (the cells left and right of the vector), and all
-// addresses are fixed offsets from the thread's own slot.  Nothing is predicated inside the stages: every thread
+// needs two ds_read_b128 (the rows above and below) at fixed offsets from the thread's own slot, and the cells left
+// and right of the vector come from the neighbouring LANES (DPP wave shifts; as LDS scalars their 16-byte stride made
+// them 4-way bank-conflicted: 55 % of the LDS cycles of the first version).  Nothing is predicated inside the stages: every thread
 // computes every stage, values within NQ cells of the region's edge are garbage by then and are simply not stored
 // (halo NQ rows, and 4 ceil(NQ/4) columns so that vectors stay aligned).  The mirror ghosts of the room border
-// (optimals.py:149-152) are extra LDS stores by the threads of row 1 / Ny-2 and of the first / last vector of a row.
+// (optimals.py:149-152): rows -1 / Ny are extra LDS stores by the threads of rows 1 / Ny-2, columns -1 / Nx are the
+// vector's own cells 1 / 2.
 //   NQ = 3: two launches per attempt (A: K1..K3 from y, K0; B: K4, K5, y_new, K6 + error), region 128 x 32 -> tile 120 x 26
 //   NQ = 6: one launch (writes K2..K6, y_new), region 128 x 32 -> tile 112 x 20
 // Same arithmetic per cell as k_stage3: bit-identical results.
@@ -1026,12 +1067,13 @@ __global__ void __launch_bounds__(RWV * RH) k_stageV(Stage3Args<T> A) {
             st4(slot, t);
             if (gi == 1 && ry >= 1) st4(slot - 2 * LS, t);                  // ghost row -1 = row 1
             if (gi == Ny - 2 && ry + 2 <= RH - 1) st4(slot + 2 * LS, t);   // ghost row Ny = row Ny-2
-            if (gj == 0) slot[-1] = t.v[1];                                 // ghost column -1 = column 1
-            if (gj + 3 == Nx - 1) slot[4] = t.v[2];                         // ghost column Nx = column Nx-2
         }
+        // left / right neighbours of the vector: the adjacent lanes' cells (a region row is RWV consecutive lanes; what
+        // crosses a row's end is region-edge garbage by construction), or the mirror cell at the room's border
+        const T lft_n = lane_prev(t.v[3]), rgt_n = lane_next(t.v[0]);
+        const T lft = (gj == 0) ? t.v[1] : lft_n, rgt = (gj + 3 == Nx - 1) ? t.v[2] : rgt_n;
         __syncthreads();
         const V4<T> up = ld4(slot - LS), dn = ld4(slot + LS);
-        const T lft = slot[-1], rgt = slot[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const T C = t.v[c];
@@ -1219,6 +1261,8 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
         // The tile holds the CLIPPED phi (optimals.py:172: every use below is of the clipped value), so each cell is
         // clipped once instead of five times -- once as a centre and once by each of its four neighbours.
         V4<T> pcl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pcl.v[q] = (T)0;
         if (valid) {
             V4<T> ph;
 #pragma unroll
@@ -1241,10 +1285,13 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
         } else if (hn == 1) {
             tile[buf][hr.li][hr.lj] = clip(hy[0] + (((hQ[0][0] * h1 + hQ[0][1] * h2) + hQ[0][2] * h3) + hQ[0][3] * h4));
         }
+        // left / right neighbours of the vector: the adjacent lanes of the 16-lane row (DPP; as LDS scalars at a 16-byte
+        // stride they were 4-way bank-conflicted), the tile's halo columns for the first and the last vector
+        const T lft_n = row_prev(pcl.v[3]), rgt_n = row_next(pcl.v[0]);
         __syncthreads();
         if (vxs && valid) {
             const V4<T> up = ld4(&tile[buf][ry][4 + 4 * cx]), dn = ld4(&tile[buf][ry + 2][4 + 4 * cx]);
-            const T lft = tile[buf][ry + 1][3 + 4 * cx], rgt = tile[buf][ry + 1][8 + 4 * cx];
+            const T lft = (cx == 0) ? tile[buf][ry + 1][3] : lft_n, rgt = (cx == 15) ? tile[buf][ry + 1][4 + HT_X] : rgt_n;
             V4<T> ox, oy;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
