@@ -229,21 +229,25 @@ int oc_density(oc_handle* h, int dtype, const oc_agents* a, double sigma, const 
 /* ---- introspection for bench.py / tests --------------------------------------------------------------------- */
 /* With profiling enabled every launch of a named kernel class is bracketed by HIP events on its own stream.
  * oc_kernel_stats returns, since the last reset: number of launches, summed event time (ms) and summed
- * ALGORITHMIC bytes (DESIGN.md section "Rooflines").  Classes: "hjb_stage" (one RK attempt = 6 fused stage
- * launches), "hjb_out" (dense output + direction-field writer), "gcfm_forces", "gcfm_finish" (the two launches of a step).  Synchronises. */
+ * bytes the launch is DESIGNED to move (DESIGN.md section "Rooflines").  Classes: "hjb_stage" (the stage launch(es) of
+ * one RK attempt: 9 array passes), "hjb_out" (dense output + direction-field writer), "gcfm_forces", "gcfm_finish" (the
+ * two launches of a step), "density".  The HJB classes are sampled (every 8th attempt).  Synchronises. */
 /* mode bits: 1 = HJB kernels, 2 = GCFM kernels every step, 4 = GCFM kernels every 16th step; 0 = off */
 int oc_set_profiling(oc_handle* h, int mode);
 int oc_kernel_stats(oc_handle* h, const char* name, int64_t* launches, double* total_ms, double* total_bytes);
 int oc_reset_kernel_stats(oc_handle* h);
-/* 0 = three RK stages per launch (default), 1 = simple one-array-pass kernels (cross-check),
- * 2 = one fused launch per stage (the arithmetic of all three is identical). */
+/* 0 = the product path (default): all six stages of an RK attempt in one launch, step controller on the device (no host
+ *     round trip per attempt); 1 = simple one-array-pass kernels, 2 = one fused launch per stage -- both with the step
+ *     controller on the host, kept as cross-checks (the arithmetic per cell of all three is identical). */
 int oc_set_hjb_variant(oc_handle* h, int variant);
 /* Launch-shape knobs of the step kernels (results do not depend on them beyond float64 summation order):
  *   "pair_split"  1, 2 or 4 pair wavefronts per tile of 64 agents (default 4)
  *   "prep_blocks" upper limit of the blocks of the force kernel that do the wall search / field lookup of the tiles
  *                 (default 256; the launch uses the fewest blocks that give every prep wavefront the same tile count)
  *   "resort_every" same as oc_set_resort_every
- *   "seq_margin_mm" displacement bound M of oc_gcfm_step_sequential in millimetres (default 250) */
+ *   "seq_margin_mm" displacement bound M of oc_gcfm_step_sequential in millimetres (default 250)
+ *   "hjb_fuse"     stage launches of an RK attempt of the product path: 0 = one launch of six stages (default),
+ *                  1 = two launches of three */
 int oc_set_tuning(oc_handle* h, const char* name, int value);
 
 /* Opt-in corrections of reference quirks (SURVEY.md quirk register, section 8f-4).  Default 0: every entry point is

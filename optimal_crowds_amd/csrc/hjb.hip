@@ -121,6 +121,12 @@ __host__ __device__ inline double ctl_te(const HjbCtl<T>& c, int k) {      // np
     return (k == c.nt - 1) ? 0.0 : (double)k * c.te_step + c.Tfinal;
 }
 
+// Fused multiply-add, written out: the library is compiled with -ffp-contract=off (the float64 index decisions of the
+// agent step must round like NumPy), so the HJB kernels ask for their FMAs explicitly -- ALL variants in the same
+// places, so that they stay bit-identical to each other: a_0 k_0 + a_1 k_1 + ... is one rounding per term instead of two.
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename T>
 struct Lin8 {   // out = base + sum_j c[j] * K[j]
     const T* k[8];
@@ -143,6 +149,14 @@ __global__ void k_make_coef(const float* __restrict__ V, const T* __restrict__ m
     }
 }
 
+// hjb(t, phi, m) at one cell (optimals.py:154-160): a_lap (N + S + W + E - 4 C) - coef C, the one expression every
+// variant evaluates (4 C is exact, so the fused form of the sum rounds like the reference's)
+template <typename T>
+__device__ __forceinline__ T rhs_value(T up, T dn, T lft, T rgt, T C, T a_lap, T cf) {
+    const T sum = fma_t((T)-4, C, up + dn + lft + rgt);
+    return a_lap * sum - cf * C;
+}
+
 template <typename T>
 __device__ __forceinline__ T rhs_point(const T* __restrict__ p, const T* __restrict__ coef, int i, int j, int Ny,
                                        int Nx, T a_lap) {
@@ -154,9 +168,8 @@ __device__ __forceinline__ T rhs_point(const T* __restrict__ p, const T* __restr
     int jl = (j == 0) ? 1 : j - 1;
     int jr = (j == Nx - 1) ? Nx - 2 : j + 1;
     T C = p[c];
-    T s = p[(int64_t)iu * Nx + j] + p[(int64_t)id * Nx + j] + p[(int64_t)i * Nx + jl] + p[(int64_t)i * Nx + jr] -
-          (T)4 * C;
-    return a_lap * s - cf * C;
+    return rhs_value(p[(int64_t)iu * Nx + j], p[(int64_t)id * Nx + j], p[(int64_t)i * Nx + jl], p[(int64_t)i * Nx + jr], C,
+                     a_lap, cf);
 }
 
 template <typename T>
@@ -175,7 +188,7 @@ __global__ void k_lincomb(const T* __restrict__ base, Lin8<T> L, T* __restrict__
     T acc = (T)0;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        if (j < L.n) acc += L.c[j] * L.k[j][i];
+        if (j < L.n) acc = fma_t(L.c[j], L.k[j][i], acc);
     out[i] = base[i] + acc;
 }
 
@@ -245,7 +258,7 @@ __global__ void k_err_norm(const T* __restrict__ y, const T* __restrict__ ynew, 
         T e = (T)0;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (j < E.n) e += E.c[j] * E.k[j][i];
+            if (j < E.n) e = fma_t(E.c[j], E.k[j][i], e);
         T yn = ynew[i];
         T sc = atol + fmax(fabs(y[i]), fabs(yn)) * rtol;
         T v = e / sc;
@@ -437,7 +450,7 @@ __global__ void k_dense(const T* __restrict__ yold, Lin8<T> W /* c_j = h * sum_p
     T acc = (T)0;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        if (j < W.n) acc += W.c[j] * W.k[j][i];
+        if (j < W.n) acc = fma_t(W.c[j], W.k[j][i], acc);
     T v = yold[i] + acc;
     if (out) out[i] = v;
     if (keep) keep[i] = (double)v * unscale;
@@ -594,7 +607,7 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
         for (int j = 0; j < S; ++j) {
             kreg[j] = ld4(A.k[j] + idx);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) tv.v[q] += A.c[j] * kreg[j].v[q];
+            for (int q = 0; q < 4; ++q) tv.v[q] = fma_t(A.c[j], kreg[j].v[q], tv.v[q]);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) tv.v[q] = yv.v[q] + tv.v[q];
@@ -611,7 +624,7 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
         for (int j = 0; j < S; ++j) {
             V4<T> kv = ld4(A.k[j] + hidx);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc.v[q] += A.c[j] * kv.v[q];
+            for (int q = 0; q < 4; ++q) acc.v[q] = fma_t(A.c[j], kv.v[q], acc.v[q]);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) hv.v[q] = hv.v[q] + acc.v[q];
@@ -620,7 +633,7 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
         const int64_t hidx = (int64_t)hr.gi * Nx + hr.gj;
         T acc = (T)0;
 #pragma unroll
-        for (int j = 0; j < S; ++j) acc += A.c[j] * A.k[j][hidx];
+        for (int j = 0; j < S; ++j) acc = fma_t(A.c[j], A.k[j][hidx], acc);
         tile[hr.li][hr.lj] = A.y[hidx] + acc;
     }
     __syncthreads();
@@ -637,8 +650,7 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
         for (int q = 0; q < 4; ++q) {
             const T C = tv.v[q];
             const T l = (q == 0) ? lft : tv.v[q - 1], r = (q == 3) ? rgt : tv.v[q + 1];
-            const T sum = up.v[q] + dn.v[q] + l + r - (T)4 * C;
-            f.v[q] = (cf.v[q] != cf.v[q]) ? (T)0 : A.a_lap * sum - cf.v[q] * C;
+            f.v[q] = (cf.v[q] != cf.v[q]) ? (T)0 : rhs_value(up.v[q], dn.v[q], l, r, C, A.a_lap, cf.v[q]);
         }
         st4(A.out + idx, f);
         if (FINAL && gi >= A.row_lo && gi < A.row_hi) {
@@ -646,7 +658,7 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
             for (int q = 0; q < 4; ++q) {
                 T e = A.he6 * f.v[q];
 #pragma unroll
-                for (int j = 0; j < S; ++j) e += A.he[j] * kreg[j].v[q];
+                for (int j = 0; j < S; ++j) e = fma_t(A.he[j], kreg[j].v[q], e);
                 const T sc = A.atol + fmax(fabs(yv.v[q]), fabs(tv.v[q])) * A.rtol;
                 const T qq = e / sc;
                 esum += (double)qq * (double)qq;
@@ -670,34 +682,8 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
     }
 }
 
-// ---- three RK stages per launch ---------------------------------------------------------------------------------
-// One RK attempt is 6 right-hand sides, each needing the previous ones on a 1-cell halo.  k_stage3 evaluates THREE of
-// them on a 64 x 16 tile in one launch: the inputs (y, the earlier K's, coef) are read once on the tile + a 3-cell
-// halo (70 x 22 cells), every intermediate stays in registers, and only the stage's working value y + h sum a_sj K_j
-// goes through LDS for the stencil, on a region that shrinks by one ring per stage.  Two launches per attempt:
-//   A  reads y, K0, coef                 writes K1, K2, K3               6 array passes
-//   B  reads y, K0..K3, coef             writes K4, K5, y_new, K6        10 array passes (+ the error norm)
-// against 39 passes for one launch per stage; the halo re-reads (1.5x) are served by L2.  The arithmetic per cell is
-// the sequence of k_stage, so the results are bit-identical.  Cells are dealt to threads round-robin over the region
-// (cell = thread + F3_NT m), all loops unrolled.
-#ifndef F3_X
-#define F3_X 64
-#endif
-#ifndef F3_Y
-#define F3_Y 16
-#endif
-#define F3_H 3
-#define F3_RW (F3_X + 2 * F3_H)
-#define F3_RH (F3_Y + 2 * F3_H)
-#define F3_LS (F3_RW + 2)
-#define F3_NCELL (F3_RW * F3_RH)
-#ifndef F3_NT
-#define F3_NT 512               // threads per tile: 3-4 cells each -> ~64 registers, full occupancy (the launch is latency-
-#endif                          // bound per block: load burst, three short stencil rounds, store burst)
-#define F3_NC ((F3_NCELL + F3_NT - 1) / F3_NT)
-
 template <typename T>
-struct Stage3Args {
+struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     const HjbCtl<T>* ctl;   // roles of the buffers (parity), coefficients, atol: written by k_control
     T* Y[2];                // y / y_new
     T* KX[2];               // K0 / K6 (FSAL: they swap on every accepted step)
@@ -708,243 +694,6 @@ struct Stage3Args {
     int Ny, Nx;
     int row_lo, row_hi;     // rows whose error / max|y| this launch accounts for
 };
-
-template <typename T, int S0, bool FINAL>
-__global__ void __launch_bounds__(F3_NT) k_stage3(Stage3Args<T> A) {
-    __shared__ T buf[2][F3_RH][F3_LS];
-    const HjbCtl<T>* __restrict__ ctl = A.ctl;
-    if (ctl->done) return;                          // an attempt enqueued past the end of the solve
-    // launch A: K1, K2, K3 from y, K0;  launch B (FINAL): K4, K5, y_new, K6 from y, K0 .. K3
-    const int par = ctl->parity;
-    T cc[3][6], he[7];
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) cc[q][j] = FINAL ? ctl->cB[q][j] : ctl->cA[q][j];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) he[j] = FINAL ? ctl->he[j] : (T)0;
-    const T atol_s = ctl->atol_s, in_scale = ctl->in_scale;
-    const T* __restrict__ y = A.Y[par];
-    const T* kin[4] = {A.KX[par], A.KM[0], A.KM[1], A.KM[2]};
-    T* kout[3] = {FINAL ? A.KM[3] : A.KM[0], FINAL ? A.KM[4] : A.KM[1], FINAL ? A.KX[par ^ 1] : A.KM[2]};
-    T* ynew = A.Y[par ^ 1];
-    const int Ny = A.Ny, Nx = A.Nx;
-    const int nbx = (Nx + F3_X - 1) / F3_X, nby = (Ny + F3_Y - 1) / F3_Y, nb = nbx * nby;
-    const int per = (nb + 7) / 8;
-    const int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);        // XCD-aware order (tile_of_block)
-    if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
-    const int i0 = (logical / nbx) * F3_Y - F3_H, j0 = (logical % nbx) * F3_X - F3_H;   // region origin
-    T yv[F3_NC], kv[S0 + 3][F3_NC], cf[F3_NC], tq[F3_NC];
-    int row[F3_NC], col[F3_NC], ring[F3_NC];        // ring < 0: not a cell of the room
-#pragma unroll
-    for (int m = 0; m < F3_NC; ++m) {
-        const int c = (int)threadIdx.x + F3_NT * m;
-        row[m] = c / F3_RW;
-        col[m] = c - row[m] * F3_RW;
-        const int gi = i0 + row[m], gj = j0 + col[m];
-        const bool in = c < F3_NCELL && gi >= 0 && gi < Ny && gj >= 0 && gj < Nx;
-        ring[m] = in ? min(min(row[m], F3_RH - 1 - row[m]), min(col[m], F3_RW - 1 - col[m])) : -1;
-        yv[m] = cf[m] = tq[m] = (T)0;
-#pragma unroll
-        for (int j = 0; j < S0 + 3; ++j) kv[j][m] = (T)0;
-        if (in) {
-            const int64_t idx = (int64_t)gi * Nx + gj;
-            yv[m] = y[idx] * in_scale;              // (1 unless the previous step ordered a rescale: exact)
-#pragma unroll
-            for (int j = 0; j < S0; ++j) kv[j][m] = kin[j][idx];
-            kv[0][m] *= in_scale;
-            if (ring[m] >= 1) cf[m] = A.coef[idx];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        // the stage's working value on the region that is still complete: rings >= q
-#pragma unroll
-        for (int m = 0; m < F3_NC; ++m) {
-            if (ring[m] >= q) {
-                T t = (T)0;
-#pragma unroll
-                for (int j = 0; j < S0 + q; ++j) t += cc[q][j] * kv[j][m];
-                t = yv[m] + t;
-                tq[m] = t;
-                buf[q & 1][row[m]][col[m]] = t;
-            }
-        }
-        __syncthreads();
-        // its right-hand side one ring further in; mirror ghosts at the room border (optimals.py:149-152)
-#pragma unroll
-        for (int m = 0; m < F3_NC; ++m) {
-            if (ring[m] >= q + 1) {
-                const int gi = i0 + row[m], gj = j0 + col[m];
-                const int ru = (gi == 0) ? row[m] + 1 : row[m] - 1, rd = (gi == Ny - 1) ? row[m] - 1 : row[m] + 1;
-                const int cl = (gj == 0) ? col[m] + 1 : col[m] - 1, cr = (gj == Nx - 1) ? col[m] - 1 : col[m] + 1;
-                const T C = tq[m];
-                const T sum = buf[q & 1][ru][col[m]] + buf[q & 1][rd][col[m]] + buf[q & 1][row[m]][cl] +
-                              buf[q & 1][row[m]][cr] - (T)4 * C;
-                kv[S0 + q][m] = (cf[m] != cf[m]) ? (T)0 : A.a_lap * sum - cf[m] * C;
-            }
-        }
-    }
-    double esum = 0.0, ymax = 0.0;
-#pragma unroll
-    for (int m = 0; m < F3_NC; ++m) {
-        if (ring[m] >= F3_H) {
-            const int gi = i0 + row[m], gj = j0 + col[m];
-            const int64_t idx = (int64_t)gi * Nx + gj;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) kout[q][idx] = kv[S0 + q][m];
-            if (FINAL) {
-                ynew[idx] = tq[m];
-                if (gi >= A.row_lo && gi < A.row_hi) {
-                    T e = he[6] * kv[S0 + 2][m];
-#pragma unroll
-                    for (int j = 0; j < S0 + 2; ++j) e += he[j] * kv[j][m];
-                    const T sc = atol_s + fmax(fabs(yv[m]), fabs(tq[m])) * A.rtol;
-                    const T qq = e / sc;
-                    esum += (double)qq * (double)qq;
-                    ymax = fmax(ymax, (double)fabs(tq[m]));
-                }
-            }
-        }
-    }
-    if (FINAL) {
-        __shared__ double ls[F3_NT / 64], lm[F3_NT / 64];
-        esum = wave_sum(esum);
-        ymax = wave_max(ymax);
-        if ((threadIdx.x & 63) == 0) {
-            ls[threadIdx.x >> 6] = esum;
-            lm[threadIdx.x >> 6] = ymax;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double a = 0.0, b = 0.0;
-            for (int q = 0; q < F3_NT / 64; ++q) {
-                a += ls[q];
-                b = fmax(b, lm[q]);
-            }
-            A.partial[2 * logical] = a;
-            A.partial[2 * logical + 1] = b;
-        }
-    }
-}
-
-// ---- all six stages of an RK attempt in ONE launch ----------------------------------------------------------------
-// The same scheme as k_stage3 carried through the whole attempt: a TX x TY tile + a 6-cell halo (one ring per stencil
-// application), y, K0 and coef read once on the region, K1 .. K6 and y_new computed in registers with the stage's
-// working value going through a double-buffered LDS tile, and only what the rest of the step needs written back:
-// K2 .. K5 (K1 has no weight in y_new, the error or the dense output: B_1 = E_1 = P_1. = 0), K6, y_new.
-//   reads  y, K0, coef  (x the halo overlap, served by L2)      writes  K2, K3, K4, K5, K6, y_new     = 9 array passes
-// against 16 for the two k_stage3 launches.  The arithmetic per cell is the same sequence, so results are bit-identical.
-template <typename T, int TX, int TY, int NT>
-__global__ void __launch_bounds__(NT) k_stage6(Stage3Args<T> A) {
-    constexpr int NQ = 6, RW = TX + 2 * NQ, RH = TY + 2 * NQ, LS = RW + 2, NCELL = RW * RH, NC = (NCELL + NT - 1) / NT;
-    __shared__ T buf[2][RH][LS];
-    const HjbCtl<T>* __restrict__ ctl = A.ctl;
-    if (ctl->done) return;
-    const int par = ctl->parity;
-    T cc[NQ][6], he[7];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) cc[q][j] = q < 3 ? ctl->cA[q][j] : ctl->cB[q - 3][j];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) he[j] = ctl->he[j];
-    const T atol_s = ctl->atol_s, in_scale = ctl->in_scale;
-    const T* __restrict__ y = A.Y[par];
-    const T* __restrict__ k0 = A.KX[par];
-    T* const kout[5] = {A.KM[1], A.KM[2], A.KM[3], A.KM[4], A.KX[par ^ 1]};      // K2 .. K6
-    T* const ynew = A.Y[par ^ 1];
-    const int Ny = A.Ny, Nx = A.Nx;
-    const int nbx = (Nx + TX - 1) / TX, nby = (Ny + TY - 1) / TY, nb = nbx * nby;
-    const int per = (nb + 7) / 8;
-    const int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);        // XCD-aware order (tile_of_block)
-    if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
-    const int i0 = (logical / nbx) * TY - NQ, j0 = (logical % nbx) * TX - NQ;       // region origin
-    T yv[NC], kv[NQ + 1][NC], cf[NC], tq[NC];
-    int row[NC], col[NC], ring[NC];         // ring < 0: not a cell of the room
-#pragma unroll
-    for (int m = 0; m < NC; ++m) {
-        const int c = (int)threadIdx.x + NT * m;
-        row[m] = c / RW;
-        col[m] = c - row[m] * RW;
-        const int gi = i0 + row[m], gj = j0 + col[m];
-        const bool in = c < NCELL && gi >= 0 && gi < Ny && gj >= 0 && gj < Nx;
-        ring[m] = in ? min(min(row[m], RH - 1 - row[m]), min(col[m], RW - 1 - col[m])) : -1;
-        yv[m] = cf[m] = tq[m] = (T)0;
-#pragma unroll
-        for (int j = 0; j <= NQ; ++j) kv[j][m] = (T)0;
-        if (in) {
-            const int64_t idx = (int64_t)gi * Nx + gj;
-            yv[m] = y[idx] * in_scale;
-            kv[0][m] = k0[idx] * in_scale;
-            if (ring[m] >= 1) cf[m] = A.coef[idx];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-        for (int m = 0; m < NC; ++m) {
-            if (ring[m] >= q) {
-                T t = (T)0;
-#pragma unroll
-                for (int j = 0; j <= q; ++j) t += cc[q][j] * kv[j][m];
-                t = yv[m] + t;
-                tq[m] = t;
-                buf[q & 1][row[m]][col[m]] = t;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < NC; ++m) {
-            if (ring[m] >= q + 1) {
-                const int gi = i0 + row[m], gj = j0 + col[m];
-                const int ru = (gi == 0) ? row[m] + 1 : row[m] - 1, rd = (gi == Ny - 1) ? row[m] - 1 : row[m] + 1;
-                const int cl = (gj == 0) ? col[m] + 1 : col[m] - 1, cr = (gj == Nx - 1) ? col[m] - 1 : col[m] + 1;
-                const T C = tq[m];
-                const T sum = buf[q & 1][ru][col[m]] + buf[q & 1][rd][col[m]] + buf[q & 1][row[m]][cl] +
-                              buf[q & 1][row[m]][cr] - (T)4 * C;
-                kv[q + 1][m] = (cf[m] != cf[m]) ? (T)0 : A.a_lap * sum - cf[m] * C;
-            }
-        }
-    }
-    double esum = 0.0, ymax = 0.0;
-#pragma unroll
-    for (int m = 0; m < NC; ++m) {
-        if (ring[m] >= NQ) {
-            const int gi = i0 + row[m], gj = j0 + col[m];
-            const int64_t idx = (int64_t)gi * Nx + gj;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) kout[q][idx] = kv[2 + q][m];
-            ynew[idx] = tq[m];
-            if (gi >= A.row_lo && gi < A.row_hi) {
-                T e = he[6] * kv[6][m];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) e += he[j] * kv[j][m];
-                const T sc = atol_s + fmax(fabs(yv[m]), fabs(tq[m])) * A.rtol;
-                const T qq = e / sc;
-                esum += (double)qq * (double)qq;
-                ymax = fmax(ymax, (double)fabs(tq[m]));
-            }
-        }
-    }
-    __shared__ double ls[NT / 64], lm[NT / 64];
-    esum = wave_sum(esum);
-    ymax = wave_max(ymax);
-    if ((threadIdx.x & 63) == 0) {
-        ls[threadIdx.x >> 6] = esum;
-        lm[threadIdx.x >> 6] = ymax;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int q = 0; q < NT / 64; ++q) {
-            a += ls[q];
-            b = fmax(b, lm[q]);
-        }
-        A.partial[2 * logical] = a;
-        A.partial[2 * logical + 1] = b;
-    }
-}
 
 // value of the previous / next lane of the wavefront (DPP wave shifts: no LDS traffic; lane 0 / 63 get 0)
 __device__ __forceinline__ float lane_prev(float v) {
@@ -986,9 +735,9 @@ __device__ __forceinline__ double lane_next(double v) {
 }
 
 // ---- lean multi-stage kernel: four cells of a row per thread, no per-cell index arithmetic ------------------------
-// k_stage3 / k_stage6 deal the region's cells to the threads round-robin; that costs ~100 instructions of index and
-// predicate arithmetic per cell and stage (measured: 450 SIMD cycles per wavefront-cell-stage; the launch time scales
-// with the cell count, not with the bytes).  Here a thread owns FOUR consecutive cells of one region row for the whole
+// (Round 1's multi-stage kernels dealt the region's cells to the threads round-robin; that cost ~100 instructions of
+// index and predicate arithmetic per cell and stage -- 450 SIMD cycles per wavefront-cell-stage, the launch time scaled
+// with the cell count, not with the bytes.)  Here a thread owns FOUR consecutive cells of one region row for the whole
 // launch: its inputs are 16-byte loads, the working value of a stage goes to LDS as one ds_write_b128, the stencil
 // needs two ds_read_b128 (the rows above and below) at fixed offsets from the thread's own slot, and the cells left
 // and right of the vector come from the neighbouring LANES (DPP wave shifts; as LDS scalars their 16-byte stride made
@@ -999,7 +748,7 @@ __device__ __forceinline__ double lane_next(double v) {
 // vector's own cells 1 / 2.
 //   NQ = 3: two launches per attempt (A: K1..K3 from y, K0; B: K4, K5, y_new, K6 + error), region 128 x 32 -> tile 120 x 26
 //   NQ = 6: one launch (writes K2..K6, y_new), region 128 x 32 -> tile 112 x 20
-// Same arithmetic per cell as k_stage3: bit-identical results.
+// Same arithmetic per cell as k_stage (one stage per launch, the cross-check variant): bit-identical results.
 template <typename T, int NQ, int S0, bool FINAL, int RWV, int RH>
 __global__ void __launch_bounds__(RWV * RH) k_stageV(Stage3Args<T> A) {
     constexpr int HX = 4 * ((NQ + 3) / 4), HY = NQ, RW = 4 * RWV, NT = RWV * RH;
@@ -1040,6 +789,9 @@ __global__ void __launch_bounds__(RWV * RH) k_stageV(Stage3Args<T> A) {
 #pragma unroll
         for (int j = 0; j < NK; ++j) kv[j].v[c] = (T)0;
     }
+    V4<T> al;                                       // the wall mask (coef = NaN: optimals.py:162) folded into the two
+#pragma unroll                                      // coefficients once: a wall cell evaluates 0 * sum - 0 * C = 0 in
+    for (int c = 0; c < 4; ++c) al.v[c] = (T)0;     // every stage, without a compare and a select per stage
     if (in) {
         yv = ld4(y + idx);
         cf = ld4(A.coef + idx);
@@ -1049,6 +801,9 @@ __global__ void __launch_bounds__(RWV * RH) k_stageV(Stage3Args<T> A) {
         for (int c = 0; c < 4; ++c) {
             yv.v[c] *= in_scale;                    // (1 unless the previous step ordered a rescale: exact)
             kv[0].v[c] *= in_scale;
+            const bool wall = cf.v[c] != cf.v[c];
+            al.v[c] = wall ? (T)0 : A.a_lap;
+            cf.v[c] = wall ? (T)0 : cf.v[c];
         }
     }
     T* const slot0 = &buf[0][ry + 1][4 + 4 * vx];
@@ -1060,7 +815,7 @@ __global__ void __launch_bounds__(RWV * RH) k_stageV(Stage3Args<T> A) {
         for (int c = 0; c < 4; ++c) {
             T acc = (T)0;
 #pragma unroll
-            for (int j = 0; j < S0 + q; ++j) acc += cc[q][j] * kv[j].v[c];
+            for (int j = 0; j < S0 + q; ++j) acc = fma_t(cc[q][j], kv[j].v[c], acc);
             t.v[c] = yv.v[c] + acc;
         }
         if (in) {
@@ -1078,8 +833,7 @@ __global__ void __launch_bounds__(RWV * RH) k_stageV(Stage3Args<T> A) {
         for (int c = 0; c < 4; ++c) {
             const T C = t.v[c];
             const T l = (c == 0) ? lft : t.v[c - 1], r = (c == 3) ? rgt : t.v[c + 1];
-            const T sum = up.v[c] + dn.v[c] + l + r - (T)4 * C;
-            kv[S0 + q].v[c] = (cf.v[c] != cf.v[c]) ? (T)0 : A.a_lap * sum - cf.v[c] * C;
+            kv[S0 + q].v[c] = rhs_value(up.v[c], dn.v[c], l, r, C, al.v[c], cf.v[c]);
         }
     }
     const bool store = in && ry >= HY && ry < RH - HY && vx >= HX / 4 && vx < RWV - HX / 4;
@@ -1107,7 +861,7 @@ __global__ void __launch_bounds__(RWV * RH) k_stageV(Stage3Args<T> A) {
                 for (int c = 0; c < 4; ++c) {
                     T e = he[6] * kv[NK - 1].v[c];
 #pragma unroll
-                    for (int j = 0; j < NK - 1; ++j) e += he[j] * kv[j].v[c];
+                    for (int j = 0; j < NK - 1; ++j) e = fma_t(he[j], kv[j].v[c], e);
                     const T sc = atol_s + fmax(fabs(yv.v[c]), fabs(t.v[c])) * A.rtol;
                     const T qq = e / sc;
                     esum += (double)qq * (double)qq;
@@ -1176,7 +930,7 @@ __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* 
             for (int pp = 0; pp < 4; ++pp) {
                 T acc = (T)0;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc += kk[j].v[q] * P[j][pp];
+                for (int j = 0; j < 6; ++j) acc = fma_t(kk[j].v[q], P[j][pp], acc);
                 Q[q][pp] = acc;
             }
         }
@@ -1190,7 +944,7 @@ __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* 
         for (int pp = 0; pp < 4; ++pp) {
             T acc = (T)0;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc += kk[j] * P[j][pp];
+            for (int j = 0; j < 6; ++j) acc = fma_t(kk[j], P[j][pp], acc);
             Q[0][pp] = acc;
         }
     }
@@ -1267,7 +1021,7 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
             V4<T> ph;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                ph.v[q] = yq[q] + (((Q[q][0] * h1 + Q[q][1] * h2) + Q[q][2] * h3) + Q[q][3] * h4);
+                ph.v[q] = yq[q] + fma_t(Q[q][3], h4, fma_t(Q[q][2], h3, fma_t(Q[q][1], h2, Q[q][0] * h1)));
                 pcl.v[q] = clip(ph.v[q]);
             }
             st4(&tile[buf][ry + 1][4 + 4 * cx], pcl);
@@ -1280,10 +1034,10 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
             V4<T> hp;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                hp.v[q] = clip(hy[q] + (((hQ[q][0] * h1 + hQ[q][1] * h2) + hQ[q][2] * h3) + hQ[q][3] * h4));
+                hp.v[q] = clip(hy[q] + fma_t(hQ[q][3], h4, fma_t(hQ[q][2], h3, fma_t(hQ[q][1], h2, hQ[q][0] * h1))));
             st4(&tile[buf][hr.li][hr.lj], hp);
         } else if (hn == 1) {
-            tile[buf][hr.li][hr.lj] = clip(hy[0] + (((hQ[0][0] * h1 + hQ[0][1] * h2) + hQ[0][2] * h3) + hQ[0][3] * h4));
+            tile[buf][hr.li][hr.lj] = clip(hy[0] + fma_t(hQ[0][3], h4, fma_t(hQ[0][2], h3, fma_t(hQ[0][1], h2, hQ[0][0] * h1))));
         }
         // left / right neighbours of the vector: the adjacent lanes of the 16-lane row (DPP; as LDS scalars at a 16-byte
         // stride they were 4-way bank-conflicted), the tile's halo columns for the first and the last vector
@@ -1631,12 +1385,11 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     SA.Nx = S.Nx;
     SA.row_lo = own_lo;
     SA.row_hi = own_hi;
-    // stage launches: 0 = two launches of three stages (k_stage3), else all six in one (k_stage6) with tile shape
-    // 1: 64 x 32 / 1024 threads, 2: 64 x 16 / 512, 3: 32 x 32 / 512, 4: 128 x 16 / 1024, 5: 64 x 64 / 1024
+    // stage launches of an attempt (k_stageV): hjb_fuse 0 = all six stages in one launch (tile 112 x 20), 1 = two launches of
+    // three stages (tile 120 x 26; measured slower, kept as a cross-check of the other)
     const int fuse = h->hjb_fuse;
-    // 6: lean kernel (k_stageV), two launches of three stages, tile 120 x 26;  7: lean, all six, tile 112 x 20
-    const int f6x[8] = {F3_X, 64, 64, 32, 128, 64, 120, 112}, f6y[8] = {F3_Y, 32, 16, 32, 16, 64, 26, 20};
-    const int nb3 = ((S.Nx + f6x[fuse] - 1) / f6x[fuse]) * ((S.Ny + f6y[fuse] - 1) / f6y[fuse]);
+    const int tx = fuse == 0 ? 112 : 120, ty = fuse == 0 ? 20 : 26;
+    const int nb3 = ((S.Nx + tx - 1) / tx) * ((S.Ny + ty - 1) / ty);
     const dim3 grid3(8 * ((nb3 + 7) / 8));
     if (nb3 > h->red_blocks) {
         oc_set_error("hjb_solve: %d tiles exceed the reduction buffer (%d)", nb3, h->red_blocks);
@@ -1690,20 +1443,11 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         const bool prof = prof_on && (enq % PROF_EVERY == 0);
         if (prof) ev_attempt.push_back(enq);
         if (prof) event();
-        switch (fuse) {
-            case 1: hipLaunchKernelGGL((k_stage6<T, 64, 32, 1024>), grid3, dim3(1024), 0, s, SA); break;
-            case 2: hipLaunchKernelGGL((k_stage6<T, 64, 16, 512>), grid3, dim3(512), 0, s, SA); break;
-            case 3: hipLaunchKernelGGL((k_stage6<T, 32, 32, 512>), grid3, dim3(512), 0, s, SA); break;
-            case 4: hipLaunchKernelGGL((k_stage6<T, 128, 16, 1024>), grid3, dim3(1024), 0, s, SA); break;
-            case 5: hipLaunchKernelGGL((k_stage6<T, 64, 64, 1024>), grid3, dim3(1024), 0, s, SA); break;
-            case 6:
-                hipLaunchKernelGGL((k_stageV<T, 3, 1, false, 32, 32>), grid3, dim3(1024), 0, s, SA);
-                hipLaunchKernelGGL((k_stageV<T, 3, 4, true, 32, 32>), grid3, dim3(1024), 0, s, SA);
-                break;
-            case 7: hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32>), grid3, dim3(1024), 0, s, SA); break;
-            default:
-                hipLaunchKernelGGL((k_stage3<T, 1, false>), grid3, dim3(F3_NT), 0, s, SA);
-                hipLaunchKernelGGL((k_stage3<T, 4, true>), grid3, dim3(F3_NT), 0, s, SA);
+        if (fuse == 0) {
+            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32>), grid3, dim3(1024), 0, s, SA);
+        } else {
+            hipLaunchKernelGGL((k_stageV<T, 3, 1, false, 32, 32>), grid3, dim3(1024), 0, s, SA);
+            hipLaunchKernelGGL((k_stageV<T, 3, 4, true, 32, 32>), grid3, dim3(1024), 0, s, SA);
         }
         if (prof) event();
         if (sh) {
@@ -1784,10 +1528,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             float e1 = 0.f, e2 = 0.f;
             (void)hipEventElapsedTime(&e1, ev[4 * g], ev[4 * g + 1]);
             (void)hipEventElapsedTime(&e2, ev[4 * g + 2], ev[4 * g + 3]);
-            if (log[a] & 1) {           // a real attempt: 16 array passes (launch A 6, launch B 10), or 9 in one launch
+            if (log[a] & 1) {           // a real attempt: 9 array passes in one launch (two launches: 6 + 10)
                 ts.add_ms += e1;
                 ts.add_n += 1;
-                ts.bytes += ((fuse >= 1 && fuse != 6) ? 9.0 : 16.0) * sizeof(T) * (double)n;
+                ts.bytes += (fuse == 0 ? 9.0 : 16.0) * sizeof(T) * (double)n;
             }
             if (log[a] & 2) {           // accepted: k_out read y + 6 stage arrays once, wrote 2 components per slice
                 const int nv = log[a] >> 8;

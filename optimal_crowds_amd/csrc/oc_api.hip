@@ -60,7 +60,7 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
     OC_HIP_CHECK(hipHostGetDevicePointer(&h->red_mailbox_dev, h->red_host + 2 * OC_MAX_WORLD, 0));
     if (const char* e = getenv("OC_HJB_FUSE")) {        // A/B of the stage-launch shapes over a whole test run
         const int v = atoi(e);
-        if (v >= 0 && v <= 7) h->hjb_fuse = v;
+        if (v >= 0 && v <= 1) h->hjb_fuse = v;
     }
     *out = h;
     return OC_OK;
@@ -233,7 +233,7 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
         OC_REQUIRE(value >= 1 && value <= 4096, "resort_every out of range");
         h->resort_every = value;
     } else if (!strcmp(name, "hjb_fuse")) {
-        OC_REQUIRE(value >= 0 && value <= 7, "hjb_fuse out of range");
+        OC_REQUIRE(value >= 0 && value <= 1, "hjb_fuse out of range");
         h->hjb_fuse = value;
     } else if (!strcmp(name, "seq_margin_mm")) {
         OC_REQUIRE(value >= 1 && value <= 1500, "seq_margin_mm out of range");

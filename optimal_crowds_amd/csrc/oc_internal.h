@@ -119,7 +119,7 @@ struct oc_handle {
     int prof_mode = 0;
     int64_t prof_tick = 0;          // GCFM step counter for sampled timers
     int hjb_variant = 0;
-    int hjb_fuse = 0;               // stage launches of an RK attempt: 0 = 2 x three stages, 1..5 = all six in one (tile shapes, hjb.hip)
+    int hjb_fuse = 0;               // stage launches of an RK attempt: 0 = all six stages in one, 1 = 2 x three stages (hjb.hip)
     std::map<std::string, oc_timer> timers;
 };
 

@@ -1,6 +1,6 @@
 # A/B of the HJB stage-launch shapes on the GPU box: bash tools/ab_hjb.sh [workload]
 wl=${1:-metro_station}
-for f in ${FUSE:-0 5 6 7}; do
+for f in ${FUSE:-0 1}; do
   python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-work-count --tune hjb_fuse=$f > gpurun_out/ab_hjb_${wl}_$f.json 2> gpurun_out/ab_hjb_${wl}_$f.err || { echo "fuse $f failed"; tail -3 gpurun_out/ab_hjb_${wl}_$f.err; continue; }
   python - $f gpurun_out/ab_hjb_${wl}_$f.json <<'PY'
 import json, sys
