@@ -58,3 +58,10 @@ def describe(a):
         return "empty"
     return "n=%d max=%.3e p99=%.3e p99.99=%.3e frac>1e-2=%.2e" % (
         a.size, a.max(), np.percentile(a, 99), np.percentile(a, 99.99), (a > 1e-2).mean())
+
+
+def assert_steps_acceptable(err):
+    """err: the float64 oracle's error norm of every step the float32 GPU solve accepted.  The GPU's own norm of the same
+    step is a float32 evaluation of a sum that hovers just below 1 (the controller aims there), so a step or two may read
+    1.0x in float64; none may be a step the oracle would clearly have rejected."""
+    assert (err < 1.1).all() and (err >= 1.0).sum() <= 3, (float(err.max()), int((err >= 1.0).sum()))

@@ -162,7 +162,7 @@ def test_t20_fp32_range_management_vs_oracle():
     eng.close()
 
 
-from hjb_compare import clear_cells, describe, direction_errors, phi_errors      # noqa: E402
+from hjb_compare import assert_steps_acceptable, clear_cells, describe, direction_errors, phi_errors      # noqa: E402
 
 
 def test_c4_value_grid_and_direction_field_vs_c_oracle(c4):
@@ -195,7 +195,7 @@ def test_c4_value_grid_and_direction_field_vs_c_oracle(c4):
     assert abs(fst["n_accept"] - st["n_accept"]) <= 5
     forced_phi, zst = occ.rk45_solve(P, V, zero, sim.T, nt, keep=keep, forced=st["t_steps"])
     assert zst["n_accept"] == st["n_accept"]
-    assert (zst["err"] < 1.0).all(), "a GPU step the float64 controller would have rejected: %g" % zst["err"].max()
+    assert_steps_acceptable(zst["err"])
     vx, vy = eng.field_interior(0)
     for q, s in enumerate(slices):
         for ref, name in ((free_phi[q], "free"), (forced_phi[q], "forced")):
@@ -230,7 +230,8 @@ def test_c4_float64_mode_reproduces_the_oracle_at_full_size(c4):
     got = phi_keep.cpu().numpy().reshape(2, -1)
     P = occ.params(cfg, sim.room_length, sim.room_height, sim.Nx, sim.Ny)
     want, zst = occ.rk45_solve(P, V, np.zeros_like(V), sim.T, nt, keep=keep, forced=st["t_steps"])
-    assert zst["n_accept"] == st["n_accept"] and (zst["err"] < 1.0).all()
+    assert zst["n_accept"] == st["n_accept"]
+    assert_steps_acceptable(zst["err"])
     vx, vy = eng.field_interior(0)
     for q, k in enumerate(keep):
         point, avg = phi_errors(got[q], want[q], V, sim.Ny, sim.Nx)
@@ -269,7 +270,8 @@ def test_t20_fp32_error_alone_on_the_gpu_step_sequence():
     st, phi_keep = eng.solve(0, T, nt, keep=keep, want_steps=True)
     P = occ.params(cfg, room["room_length"], room["room_height"], Nx, Ny)
     want, zst = occ.rk45_solve(P, V, np.zeros_like(V), T, nt, keep=keep, forced=st["t_steps"])
-    assert zst["n_accept"] == st["n_accept"] and (zst["err"] < 1.0).all()
+    assert zst["n_accept"] == st["n_accept"]
+    assert_steps_acceptable(zst["err"])
     got = phi_keep.cpu().numpy().reshape(len(keep), -1)
     vx, vy = (t.double().cpu().numpy() for t in eng.field_interior(0))
     for q, s in enumerate(slices):

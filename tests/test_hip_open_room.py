@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import oc_oracle as oc                     # noqa: E402  (checker only)
 from oracle import oc_oracle_c as occ                  # noqa: E402
-from hjb_compare import clear_cells, describe, direction_errors, phi_errors      # noqa: E402
+from hjb_compare import assert_steps_acceptable, clear_cells, describe, direction_errors, phi_errors      # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -69,7 +69,8 @@ def test_open_room_recompute_loop(c5):
                 m64 = m.double().cpu().numpy()
                 assert m64.max() > 1.0 and (m64[V < 0] == 0).all()          # a real crowd density, masked on walls
                 want, zst = occ.rk45_solve(P, V, m64, sim.T, nt, keep=keep, forced=st["t_steps"])
-                assert zst["n_accept"] == st["n_accept"] and (zst["err"] < 1.0).all()
+                assert zst["n_accept"] == st["n_accept"]
+    assert_steps_acceptable(zst["err"])
                 vx, vy = eng.field_interior(0)
                 for q, sl in enumerate(slices):
                     point, avg = phi_errors(got[q], want[q], V, sim.Ny, sim.Nx)
