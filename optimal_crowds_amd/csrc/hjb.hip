@@ -76,18 +76,9 @@ struct HjbCtl {
     T hx[HJB_MAXS][4];                  // computed in the kernel)
 };
 
-// first part of an attempt (rk.py:121-137): clamp the step, end time, coefficient tables
+// first part of an attempt (rk.py:121-137): clamp the step, its end time ...
 template <typename T>
-__host__ __device__ inline void ctl_prepare_attempt(HjbCtl<T>& c, bool new_step) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#define TAB_A dRK_A
-#define TAB_B dRK_B
-#define TAB_E dRK_E
-#else
-#define TAB_A RK_A
-#define TAB_B RK_B
-#define TAB_E RK_E
-#endif
+__host__ __device__ inline void ctl_prepare_step(HjbCtl<T>& c, bool new_step) {
     const double direction = -1.0;
     const double min_step = 10 * fabs(nextafter(c.t, direction * INFINITY) - c.t);
     if (new_step) {
@@ -104,16 +95,41 @@ __host__ __device__ inline void ctl_prepare_attempt(HjbCtl<T>& c, bool new_step)
     c.h_abs = fabs(hh);
     c.hh = hh;
     c.t_new = t_new;
-    for (int q = 0; q < 3; ++q)
-        for (int j = 0; j < 6; ++j) {
-            c.cA[q][j] = j < 1 + q ? (T)(TAB_A[1 + q][j] * hh) : (T)0;
-            c.cB[q][j] = q < 2 ? (j < 4 + q ? (T)(TAB_A[4 + q][j] * hh) : (T)0) : (T)(TAB_B[j] * hh);
-        }
-    for (int j = 0; j < 7; ++j) c.he[j] = (T)(TAB_E[j] * hh);
     c.atol_s = (T)(c.atol0 * ldexp(1.0, -c.expo));
+}
+
+// ... and entry e (0 .. 42) of its coefficient tables: h a_sj of stages 1-3 (cA), of stages 4, 5 and the y_new row (cB),
+// h E_j (he).  On the device the entries are dealt to the lanes of k_control.
+template <typename T>
+__host__ __device__ inline void ctl_prepare_entry(HjbCtl<T>& c, int e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TAB_A dRK_A
+#define TAB_B dRK_B
+#define TAB_E dRK_E
+#else
+#define TAB_A RK_A
+#define TAB_B RK_B
+#define TAB_E RK_E
+#endif
+    const double hh = c.hh;
+    if (e < 18) {
+        const int q = e / 6, j = e % 6;
+        c.cA[q][j] = j < 1 + q ? (T)(TAB_A[1 + q][j] * hh) : (T)0;
+    } else if (e < 36) {
+        const int q = (e - 18) / 6, j = (e - 18) % 6;
+        c.cB[q][j] = q < 2 ? (j < 4 + q ? (T)(TAB_A[4 + q][j] * hh) : (T)0) : (T)(TAB_B[j] * hh);
+    } else if (e < 43) {
+        c.he[e - 36] = (T)(TAB_E[e - 36] * hh);
+    }
 #undef TAB_A
 #undef TAB_B
 #undef TAB_E
+}
+
+template <typename T>
+__host__ __device__ inline void ctl_prepare_attempt(HjbCtl<T>& c, bool new_step) {     // (the host's first attempt)
+    ctl_prepare_step(c, new_step);
+    for (int e = 0; e < 43; ++e) ctl_prepare_entry(c, e);
 }
 
 template <typename T>
@@ -398,15 +414,7 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
                     ++c.k_next;
                 }
                 c.k_hi = c.k_next;
-                c.n_hx = (c.k_hi - c.k_lo <= HJB_MAXS) ? c.k_hi - c.k_lo : 0;
-                for (int q = 0; q < c.n_hx; ++q) {  // dense output (rk.py:560-575): x = (t_eval - t_old) / h, powers 1..4
-                    const double x = (ctl_te(c, c.k_lo + q) - c.t) / c.hh;
-                    double xp = x;
-                    for (int pp = 0; pp < 4; ++pp) {
-                        c.hx[q][pp] = (T)(c.hh * xp);
-                        xp *= x;
-                    }
-                }
+                c.n_hx = (c.k_hi - c.k_lo <= HJB_MAXS) ? c.k_hi - c.k_lo : 0;      // (table: the lanes, below)
                 c.out_in_scale = c.in_scale;
                 c.in_scale = (T)1;
                 c.t = c.t_new;
@@ -422,16 +430,30 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
                 c.rejected = 0;
                 logw |= 2 | (nv << 8);
                 if (-(c.t - c.tf) >= 0) c.done = 1; // direction = -1
-                else ctl_prepare_attempt(c, true);
+                else ctl_prepare_step(c, true);
             } else {
                 c.h_abs *= fmax(0.2, 0.9 * pow(err, -0.2));
                 c.rejected = 1;
-                ctl_prepare_attempt(c, false);
+                ctl_prepare_step(c, false);
             }
         }
         const int tk = ++c.ticks;
         if (tk - 1 < log_cap) att_log[tk - 1] = logw;
         mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
+    }
+    __syncthreads();
+    // what does not depend on anything but the decision's scalars is dealt to the lanes: the next attempt's 43
+    // coefficients (threads 0..42) and the accepted step's dense-output factors (threads 64..; rk.py:560-575:
+    // x = (t_eval - t_old) / h, h x^1..4)
+    if (!c.done && (int)threadIdx.x < 43) ctl_prepare_entry(c, (int)threadIdx.x);
+    if (c.accepted && threadIdx.x >= 64 && (int)threadIdx.x - 64 < c.n_hx) {
+        const int q = (int)threadIdx.x - 64;
+        const double x = (ctl_te(c, c.k_lo + q) - c.out_t) / c.out_hh;
+        double xp = x;
+        for (int pp = 0; pp < 4; ++pp) {
+            c.hx[q][pp] = (T)(c.out_hh * xp);
+            xp *= x;
+        }
     }
     __syncthreads();
     {

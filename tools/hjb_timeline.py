@@ -7,7 +7,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-keys = ("k_stage3", "k_control", "k_out", "k_reduce_final", "k_halo_stage", "k_forces", "k_finish", "k_stage<", "k_scale")
+keys = ("k_stageV", "k_control", "k_out", "k_reduce_final", "k_halo_stage", "k_forces", "k_finish", "k_stage<", "k_scale", "k_density", "k_norm_scaled", "k_rhs", "k_fill", "k_lincomb")
 dur, gap = collections.defaultdict(list), collections.defaultdict(list)
 prev_end = None
 for r in rows:
@@ -15,8 +15,8 @@ for r in rows:
     k = next((q for q in keys if q in name), None)
     st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     if k:
-        if "k_stage3" in name:
-            k = "k_stage3 B" if "true" in name else "k_stage3 A"
+        if "k_stageV" in name and ", 3, " in name:
+            k = "k_stageV 3B" if "true" in name else "k_stageV 3A"
         dur[k].append(en - st)
         if prev_end is not None:
             gap[k].append(st - prev_end)
