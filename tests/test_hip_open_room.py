@@ -70,7 +70,7 @@ def test_open_room_recompute_loop(c5):
                 assert m64.max() > 1.0 and (m64[V < 0] == 0).all()          # a real crowd density, masked on walls
                 want, zst = occ.rk45_solve(P, V, m64, sim.T, nt, keep=keep, forced=st["t_steps"])
                 assert zst["n_accept"] == st["n_accept"]
-    assert_steps_acceptable(zst["err"])
+                assert_steps_acceptable(zst["err"])
                 vx, vy = eng.field_interior(0)
                 for q, sl in enumerate(slices):
                     point, avg = phi_errors(got[q], want[q], V, sim.Ny, sim.Nx)
