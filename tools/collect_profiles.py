@@ -37,10 +37,11 @@ def short(name):
     return name[:48]
 
 
-st = sorted(glob.glob(os.path.join(G, tag + "_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
+sfx = "" if workload == "metro_station" else "_" + workload
+st = sorted(glob.glob(os.path.join(G, tag + sfx + "_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if st:
-    shutil.copy(st[0], os.path.join(P, tag + "_bench_kernel_stats.csv"))
-for name in (tag + "_bench.log", tag + "_bench_plain.log"):
+    shutil.copy(st[0], os.path.join(P, tag + sfx + "_bench_kernel_stats.csv"))
+for name in (tag + sfx + "_bench.log", tag + sfx + "_bench_plain.log", tag + sfx + "_bench_steps20.log"):
     src = os.path.join(G, name)
     if os.path.exists(src):
         lines = [l for l in open(src) if l.startswith("{")]
@@ -48,7 +49,7 @@ for name in (tag + "_bench.log", tag + "_bench_plain.log"):
             open(os.path.join(P, name.replace(".log", ".json")), "w").write(lines[-1])
 
 traffic = {}
-for d, cname in ((tag + "_pmc_fetch", "FETCH_SIZE"), (tag + "_pmc_write", "WRITE_SIZE")):
+for d, cname in ((tag + sfx + "_pmc_fetch", "FETCH_SIZE"), (tag + sfx + "_pmc_write", "WRITE_SIZE")):
     f = sorted(glob.glob(os.path.join(G, d, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
     if not f:
         continue
@@ -72,6 +73,9 @@ if traffic:
     json.dump(traffic, open(os.path.join(P, tag + "_pmc_traffic" + ("" if workload == "metro_station" else "_" + workload)
                                          + ".json"), "w"), indent=1)
 # SQ counters of the step kernels (tools/pmc_step.sh): mean per launch -> JSON with the same stamp
+hjb_txt = os.path.join(G, tag + "_pmc_hjb.txt")
+if os.path.exists(hjb_txt):
+    shutil.copy(hjb_txt, os.path.join(P, tag + "_pmc_hjb_kernels.txt"))
 step_txt = os.path.join(G, tag + "_pmc_step.txt")
 if os.path.exists(step_txt):
     import re
