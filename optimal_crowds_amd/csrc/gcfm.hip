@@ -397,12 +397,12 @@ __device__ __forceinline__ void pair_term2(f2v Rx, f2v Ry, float vxi, float vyi,
     const f2v b_j = __builtin_elementwise_fma((f2v){-db, -db},
                                               __builtin_elementwise_min(sj * (f2v){inv_vdes_i, inv_vdes_i}, one),
                                               (f2v){b_max, b_max});                      // Q6: i's v_des
-    const f2v bj2 = b_j * b_j;
-    const f2v ib2_j = {__builtin_amdgcn_rcpf(bj2.x), __builtin_amdgcn_rcpf(bj2.y)};
     const f2v cj = __builtin_elementwise_fma(ex, hjx, ey * hjy);
     const f2v sn_j = __builtin_elementwise_fma(hjx, ey, -(hjy * ex));
-    const f2v aj = __builtin_elementwise_fma(cj * cj, ia2_j, sn_j * sn_j * ib2_j);
-    const f2v q_j = {__builtin_amdgcn_rsqf(aj.x), __builtin_amdgcn_rsqf(aj.y)};
+    // q_j = 1 / sqrt(c^2/a_j^2 + s^2/b_j^2) = b_j / sqrt(c^2 (b_j/a_j)^2 + s^2): no reciprocal of b_j^2 (a quarter-rate
+    // instruction per pair; b_j depends on the PAIR through i's v_des, quirk Q6, so it cannot be tabulated per agent)
+    const f2v aj = __builtin_elementwise_fma(cj * cj, (b_j * b_j) * ia2_j, sn_j * sn_j);
+    const f2v q_j = b_j * (f2v){__builtin_amdgcn_rsqf(aj.x), __builtin_amdgcn_rsqf(aj.y)};
     const f2v dist = r - q_i - q_j;
     const f2v den = one + vrel;
     const f2v arg = dist * (f2v){neg_inv_eta_log2e, neg_inv_eta_log2e} *
@@ -494,6 +494,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
     const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
     const bool unit_dir = (P.fix & OC_FIX_PAIR_FORCE) != 0;
     const double c = P.cutoff, c2 = c * c;
+    const float c2lo = (float)(c2 * (1.0 - 2e-6)), c2hi = (float)(c2 * (1.0 + 2e-6));
     const int k = it * 64 + lane;
     const int i = C.pidx[k];
     const double2 pi = L.li_pos[tl][lane];
@@ -501,6 +502,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
     const double ox = bi.x, oy = bi.y;             // origin of the box-relative float32 coordinates
     const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
     const f2v xi2 = {xi_f, xi_f}, yi2 = {yi_f, yi_f};
+    const float my_speed = L.li_vel[tl][lane].z, my_hx = L.li_aux[tl][lane].x, my_hy = L.li_aux[tl][lane].y;
     uint32_t* lst = L.list[w];
     int work = 0;                                   // list entries processed: the tile's measured work
     const int j0 = sub * NJ;                        // this share's records of a j-tile: j0 .. j0 + NJ - 1
@@ -614,9 +616,26 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 const int rs = bself * NJ + jl;
                 mw[rs >> 5] &= ~(0x80000000u >> (rs & 31));
             }
-            if (i < 0) {
+            if (i < 0 || !(my_speed > 0.f)) {           // no agent, or a stationary one: k = 0 for every j (Q19)
 #pragma unroll
                 for (int h = 0; h < NW; ++h) mw[h] = 0u;
+            }
+            // ---- field of view (pedestrians.py:259-262): k = max(h_i . e - cos 0.7 pi, 0) makes the force of every j
+            // outside i's 252-degree cone EXACTLY zero -- 30 % of the near pairs of a moving crowd.  Candidates that are
+            // surely outside (cos < -0.5886 against the threshold -0.58779, a margin 40 x the error of the box-relative
+            // float32 coordinates; pairs closer than 0.1 m are always kept) leave the list here, before phase 2 pays
+            // ~120 instructions for each.
+#pragma unroll
+            for (int h = 0; h < NW; ++h) {
+                uint32_t mm = mw[h];
+                while (mm) {
+                    const int q = __clz((int)mm);
+                    const uint32_t bit = 0x80000000u >> q;
+                    mm &= ~bit;
+                    const float ddx = L.l_rx[w][32 * h + q] - xi_f, ddy = L.l_ry[w][32 * h + q] - yi_f;
+                    const float dot = ddx * my_hx + ddy * my_hy, rr2 = ddx * ddx + ddy * ddy;
+                    if (dot < 0.f && rr2 > 0.01f && dot * dot > 0.34645f * rr2) mw[h] &= ~bit;
+                }
             }
             // list entries hold TWO candidates of one agent (an odd last one is paired with itself, masked).  Dense
             // tile pairs do not fit the list: rounds of 32 j each (64 agents x 16 entries = PAIR_LIST_CAP always fit)
@@ -699,14 +718,22 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                         aux = L.li_aux[tl][il];
                     }
                     const double dxA = pbA.x - pa.x, dyA = pbA.y - pa.y, dxB = pbB.x - pa.x, dyB = pbB.y - pa.y;
-                    const double d2A = dxA * dxA + dyA * dyA, d2B = dxB * dxB + dyB * dyB;
-                    // the reference's decision sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291);
-                    // coincident agents (d2 = 0: NaN in the reference) are skipped (deviation D1)
-                    const bool okA = d2A <= P.cut_d2max && d2A > 0.0;
-                    const bool okB = (e & (1u << 14)) && d2B <= P.cut_d2max && d2B > 0.0;
+                    // the reference's decision sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291) from the
+                    // float32 square of the float64-differenced vector wherever that cannot be wrong (it is good to
+                    // 3e-7 relative); the exact float64 comparison decides inside the band.  Coincident agents (d2 = 0:
+                    // NaN in the reference) are skipped (deviation D1).
+                    const f2v Rx = {(float)dxA, (float)dxB}, Ry = {(float)dyA, (float)dyB};
+                    const f2v r2f = __builtin_elementwise_fma(Rx, Rx, Ry * Ry);
+                    bool okA = r2f.x < c2lo, okB = r2f.y < c2lo;
+                    if ((!okA && r2f.x < c2hi) || (!okB && r2f.y < c2hi)) {         // (rare: |d - cutoff| < 4e-6 m)
+                        okA = okA || dxA * dxA + dyA * dyA <= P.cut_d2max;
+                        okB = okB || dxB * dxB + dyB * dyB <= P.cut_d2max;
+                    }
+                    okA = okA && r2f.x > 0.f;
+                    okB = okB && (e & (1u << 14)) && r2f.y > 0.f;
                     if (okA || okB) {
                         f2v fx, fy;
-                        pair_term2((f2v){(float)dxA, (float)dxB}, (f2v){(float)dyA, (float)dyB}, va.x, va.y, va.z, aux.x,
+                        pair_term2(Rx, Ry, va.x, va.y, va.z, aux.x,
                                    aux.y, va.w, aux.z, aux.w, (f2v){vbA.x, vbB.x}, (f2v){vbA.y, vbB.y},
                                    (f2v){vbA.z, vbB.z}, (f2v){vbA.w, vbB.w}, (f2v){hbA.x, hbB.x}, (f2v){hbA.y, hbB.y},
                                    b_max, db, neg_inv_eta_log2e, unit_dir, fx, fy);
