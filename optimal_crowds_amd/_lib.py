@@ -8,7 +8,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboc_hip.so")
+LIB_PATH = os.environ.get("OC_HIP_LIB") or os.path.join(HERE, "liboc_hip.so")     # (OC_HIP_LIB: A/B builds, tools/)
 CSRC = os.path.join(HERE, "csrc")
 
 OC_F32, OC_F64 = 0, 1

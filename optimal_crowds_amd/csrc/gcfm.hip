@@ -502,7 +502,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
     const double ox = bi.x, oy = bi.y;             // origin of the box-relative float32 coordinates
     const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
     const f2v xi2 = {xi_f, xi_f}, yi2 = {yi_f, yi_f};
-    const float my_speed = L.li_vel[tl][lane].z, my_hx = L.li_aux[tl][lane].x, my_hy = L.li_aux[tl][lane].y;
+    const float my_speed = L.li_vel[tl][lane].z;
     uint32_t* lst = L.list[w];
     int work = 0;                                   // list entries processed: the tile's measured work
     const int j0 = sub * NJ;                        // this share's records of a j-tile: j0 .. j0 + NJ - 1
@@ -619,23 +619,6 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
             if (i < 0 || !(my_speed > 0.f)) {           // no agent, or a stationary one: k = 0 for every j (Q19)
 #pragma unroll
                 for (int h = 0; h < NW; ++h) mw[h] = 0u;
-            }
-            // ---- field of view (pedestrians.py:259-262): k = max(h_i . e - cos 0.7 pi, 0) makes the force of every j
-            // outside i's 252-degree cone EXACTLY zero -- 30 % of the near pairs of a moving crowd.  Candidates that are
-            // surely outside (cos < -0.5886 against the threshold -0.58779, a margin 40 x the error of the box-relative
-            // float32 coordinates; pairs closer than 0.1 m are always kept) leave the list here, before phase 2 pays
-            // ~120 instructions for each.
-#pragma unroll
-            for (int h = 0; h < NW; ++h) {
-                uint32_t mm = mw[h];
-                while (mm) {
-                    const int q = __clz((int)mm);
-                    const uint32_t bit = 0x80000000u >> q;
-                    mm &= ~bit;
-                    const float ddx = L.l_rx[w][32 * h + q] - xi_f, ddy = L.l_ry[w][32 * h + q] - yi_f;
-                    const float dot = ddx * my_hx + ddy * my_hy, rr2 = ddx * ddx + ddy * ddy;
-                    if (dot < 0.f && rr2 > 0.01f && dot * dot > 0.34645f * rr2) mw[h] &= ~bit;
-                }
             }
             // list entries hold TWO candidates of one agent (an odd last one is paired with itself, masked).  Dense
             // tile pairs do not fit the list: rounds of 32 j each (64 agents x 16 entries = PAIR_LIST_CAP always fit)

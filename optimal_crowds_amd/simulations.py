@@ -347,8 +347,10 @@ class simulation:
                     (self.recompute and self.simu_step % self.recompute_step == 0):
                 active, done, bad, bad_step = eng.run_status()
                 if bad:
-                    # the reference raises inside the offending step (before time / simu_step advance)
+                    # the reference raises inside the offending step (before time / simu_step advance); up to LOOK - 1
+                    # further steps were already enqueued: the state goes back to what that step started from
                     self.simu_step, self.time = bad_step, self._time_at(first, bad_step)
+                    self._restore(bad_step)
                     raise IndexError("agent %d left the region covered by the floor field (index %d is out of "
                                      "bounds)" % (bad - 1, bad - 1))
                 self.inside = active
@@ -356,6 +358,22 @@ class simulation:
                     self.simu_step, self.time = done, self._time_at(first, done)
                     self.history._truncate(done)            # write_history marks the frame BEFORE step s as s
         self._status_host = eng.agents["status"].cpu().numpy().astype(bool)
+
+    def _restore(self, step):
+        """agent state := the recorder's slot `step` (the state after `step` steps).  Without a recorder
+        (record=False) the state after an IndexError raised by the enqueued loop is that of the last enqueued step."""
+        if self._rec is None or step >= self._rec.shape[0]:
+            return
+        a, r = self._engine.agents, self._rec[step]
+        a["x"].copy_(r[0]), a["y"].copy_(r[1]), a["vx"].copy_(r[2]), a["vy"].copy_(r[3])
+        a["status"].copy_(self._rec_status[step])
+        alive = (self._rec_status[:step + 1] != 0).sum(dim=0).clamp(max=step)      # steps each agent has taken
+        times = np.concatenate([[0.0], np.cumsum(np.full(step, self.dt))]) if step > 0 else np.zeros(1)
+        a["agent_time"].copy_(torch.as_tensor(times, device=alive.device)[alive])
+        self._status_host = a["status"].cpu().numpy().astype(bool)
+        self.inside = int(self._status_host.sum())
+        self.history._truncate(step + 1)
+        self._engine.agents_changed()
 
     def _time_at(self, first_step, step):
         """`time` after the loop has advanced from first_step to step, accumulated like the reference does (time += dt)"""

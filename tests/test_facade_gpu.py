@@ -193,3 +193,32 @@ def test_reference_import_line_works_unmodified():
     from optimal_crowds_amd import simulations as s2
     import optimal_crowds.optimals as o1
     assert s1 is s2 and o1 is optimal_crowds.optimals and hasattr(s1, "simulation")
+
+
+def test_index_error_in_the_enqueued_run_leaves_the_state_of_the_offending_step():
+    """An agent that walks into the reference's IndexError band (quirk Q8: x in [(Nx-3) dx, L - dx)) makes step() raise
+    inside that step.  run() with device noise enqueues 16 steps between two looks at the device-side status; when the
+    flag shows up, simu_step / time AND the agent state must be those the step-by-step loop stops with."""
+    from optimal_crowds_amd import simulations
+    cfg = _cfg()
+    cfg["grid_step"] = 0.1
+    room = {"room_length": 10.0, "room_height": 10.0,
+            "initial_boxes": {"b": [8.2, 5.0, 1.0, 3.0, 1.0, "door"]},
+            "targets": {"door": [9.95, 5.0, 0.3, 6.0]},         # reached only through the band 9.7 <= x < 9.8
+            "walls": {}, "holes": {}, "cylinders": {}}
+    out = []
+    for verbose in (False, True):
+        np.random.seed(4)
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim = simulations.simulation(room, 4.0, config=cfg, noise="device", seed=9, record=True)
+            with pytest.raises(IndexError):
+                sim.run(verbose=verbose)
+        st = sim._engine.get_state()
+        out.append((sim.simu_step, sim.time, sim.inside, st))
+        assert 5 < sim.simu_step < 150
+        sim._engine.close()
+    (s0, t0, in0, a), (s1, t1, in1, b) = out
+    assert (s0, t0, in0) == (s1, t1, in1)
+    for f in ("x", "y", "vx", "vy", "status"):
+        assert np.array_equal(a[f], b[f]), f
+    assert np.allclose(a["agent_time"], b["agent_time"], atol=1e-12)
