@@ -298,12 +298,14 @@ class simulation:
             self.levels.append(levels)
         else:
             exited, bad, active = eng.step(self.simu_step, noise=noise, seed=self._seed)
-        if bad:
-            raise IndexError("agent %d left the region covered by the floor field (index %d is out of bounds)"
-                             % (bad - 1, bad - 1))
         if exited:
             self.inside -= exited
             self._status_host = eng.agents["status"].cpu().numpy().astype(bool)
+        if bad:
+            # (the device has applied the whole synchronous step; the reference raises in the middle of its loop over
+            # the agents, before time / simu_step advance)
+            raise IndexError("agent %d left the region covered by the floor field (index %d is out of bounds)"
+                             % (bad - 1, bad - 1))
         self.time += dt
         self.simu_step += 1
         self._record(self.simu_step)
@@ -348,9 +350,10 @@ class simulation:
                 active, done, bad, bad_step = eng.run_status()
                 if bad:
                     # the reference raises inside the offending step (before time / simu_step advance); up to LOOK - 1
-                    # further steps were already enqueued: the state goes back to what that step started from
+                    # further steps were already enqueued: the state goes back to where the step-by-step loop stops,
+                    # the offending step applied
                     self.simu_step, self.time = bad_step, self._time_at(first, bad_step)
-                    self._restore(bad_step)
+                    self._restore(bad_step + 1)
                     raise IndexError("agent %d left the region covered by the floor field (index %d is out of "
                                      "bounds)" % (bad - 1, bad - 1))
                 self.inside = active
@@ -372,7 +375,7 @@ class simulation:
         a["agent_time"].copy_(torch.as_tensor(times, device=alive.device)[alive])
         self._status_host = a["status"].cpu().numpy().astype(bool)
         self.inside = int(self._status_host.sum())
-        self.history._truncate(step + 1)
+        self.history._truncate(step)
         self._engine.agents_changed()
 
     def _time_at(self, first_step, step):
