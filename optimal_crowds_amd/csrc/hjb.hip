@@ -972,9 +972,13 @@ __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* 
     }
 }
 
-template <typename T>
+// Tile = OX x OY cells with OX * OY = 1024 (256 threads x 4 consecutive cells of a row): 64 x 16, 128 x 8 or 256 x 4.  A
+// wider tile writes longer contiguous runs per row and slice (1 KB at 256 instead of 256 B), which is what counts where
+// the seven input arrays no longer come out of the Infinity Cache (4096 x 4096).
+template <typename T, int OX>
 __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves per SIMD: at most 128 VGPRs
-    __shared__ alignas(16) T tile[2][HT_LH][HT_LS];
+    constexpr int OY = 1024 / OX, VW = OX / 4, OLS = OX + 8;
+    __shared__ alignas(16) T tile[2][OY + 2][OLS];
     const HjbCtl<T>* __restrict__ ctl = A.ctl;
     if (!ctl->accepted) return;                     // a rejected attempt (or one past the end) has nothing to emit
     const int par = ctl->out_parity;
@@ -984,17 +988,32 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
     const int n_hx = ctl->n_hx;
     const T* __restrict__ y = A.Y[par];
     const T* const kk[6] = {A.KX[par], A.KM[1], A.KM[2], A.KM[3], A.KM[4], A.KX[par ^ 1]};     // K0, K2 .. K5, K6
-    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int cx = (int)threadIdx.x % VW, ry = (int)threadIdx.x / VW;
     const int Ny = A.Ny, Nx = A.Nx;
-    int i0, j0, logical;
-    if (!tile_of_block(Ny, Nx, i0, j0, logical)) return;
+    const int nbx = (Nx + OX - 1) / OX, nby = (Ny + OY - 1) / OY, nb = nbx * nby;
+    const int per = (nb + 7) / 8;
+    const int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);        // XCD-aware order (tile_of_block)
+    if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
+    const int i0 = (logical / nbx) * OY, j0 = (logical % nbx) * OX;
     const int gi = i0 + ry, gj = j0 + 4 * cx;
     const bool valid = gi < Ny && gj < Nx;
     const int64_t idx = (int64_t)gi * Nx + gj;
     const int64_t ncell = (int64_t)Ny * Nx;
     T yq[4], Q[4][4], hy[4], hQ[4][4];
     if (valid) interp_coeffs<T>(y, kk, A.p, in_scale, idx, 4, yq, Q);
-    const HaloRole hr = halo_role(i0, j0, Ny, Nx);
+    // halo of the tile: threads 0 .. VW-1 the row above (a vector each), the next VW the row below, then OY threads the
+    // column to the left and OY the column to the right (a cell each); cells outside the grid are never used
+    HaloRole hr;
+    {
+        const int hidx = (int)threadIdx.x;
+        hr.kind = 0;
+        hr.gi = hr.gj = hr.li = hr.lj = 0;
+        if (hidx < VW) { hr.kind = 1; hr.gi = i0 - 1; hr.gj = j0 + 4 * hidx; hr.li = 0; hr.lj = 4 + 4 * hidx; }
+        else if (hidx < 2 * VW) { const int l = hidx - VW; hr.kind = 2; hr.gi = i0 + OY; hr.gj = j0 + 4 * l; hr.li = OY + 1; hr.lj = 4 + 4 * l; }
+        else if (hidx < 2 * VW + OY) { const int l = hidx - 2 * VW; hr.kind = 3; hr.gi = i0 + l; hr.gj = j0 - 1; hr.li = l + 1; hr.lj = 3; }
+        else if (hidx < 2 * VW + 2 * OY) { const int l = hidx - 2 * VW - OY; hr.kind = 4; hr.gi = i0 + l; hr.gj = j0 + OX; hr.li = l + 1; hr.lj = 4 + OX; }
+        if (!(hr.gi >= 0 && hr.gi < Ny && hr.gj >= 0 && hr.gj < Nx)) hr.kind = 0;
+    }
     const int hn = (hr.kind == 1 || hr.kind == 2) ? 4 : (hr.kind >= 3 ? 1 : 0);
     if (hn) interp_coeffs<T>(y, kk, A.p, in_scale, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
     auto clip = [&](T v) { return (v > lim_s) ? v : ((v < lim_s) ? lim_s : (T)0); };
@@ -1061,13 +1080,13 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
         } else if (hn == 1) {
             tile[buf][hr.li][hr.lj] = clip(hy[0] + fma_t(hQ[0][3], h4, fma_t(hQ[0][2], h3, fma_t(hQ[0][1], h2, hQ[0][0] * h1))));
         }
-        // left / right neighbours of the vector: the adjacent lanes of the 16-lane row (DPP; as LDS scalars at a 16-byte
-        // stride they were 4-way bank-conflicted), the tile's halo columns for the first and the last vector
-        const T lft_n = row_prev(pcl.v[3]), rgt_n = row_next(pcl.v[0]);
+        // left / right neighbours of the vector: the adjacent lanes (DPP wave shifts; as LDS scalars at a 16-byte stride
+        // they were 4-way bank-conflicted), the tile's halo columns for the first and the last vector of a row
+        const T lft_n = lane_prev(pcl.v[3]), rgt_n = lane_next(pcl.v[0]);
         __syncthreads();
         if (vxs && valid) {
             const V4<T> up = ld4(&tile[buf][ry][4 + 4 * cx]), dn = ld4(&tile[buf][ry + 2][4 + 4 * cx]);
-            const T lft = (cx == 0) ? tile[buf][ry + 1][3] : lft_n, rgt = (cx == 15) ? tile[buf][ry + 1][4 + HT_X] : rgt_n;
+            const T lft = (cx == 0) ? tile[buf][ry + 1][3] : lft_n, rgt = (cx == VW - 1) ? tile[buf][ry + 1][4 + OX] : rgt_n;
             V4<T> ox, oy;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1114,6 +1133,16 @@ __global__ void k_halo_stage(const HjbCtl<T>* __restrict__ ctl, T* Y0, T* Y1, T*
 }
 
 // ------------------------------------------------------------------------------------------ host side
+template <typename T>
+void launch_out(int shape, int Nx, int Ny, hipStream_t s, const OutArgs<T>& OA) {
+    const int ox = shape == 2 ? 256 : (shape == 1 ? 128 : 64), oy = 1024 / ox;
+    const int nb = ((Nx + ox - 1) / ox) * ((Ny + oy - 1) / oy);
+    const dim3 grid(8 * ((nb + 7) / 8));
+    if (shape == 2) hipLaunchKernelGGL((k_out<T, 256>), grid, dim3(256), 0, s, OA);
+    else if (shape == 1) hipLaunchKernelGGL((k_out<T, 128>), grid, dim3(256), 0, s, OA);
+    else hipLaunchKernelGGL((k_out<T, 64>), grid, dim3(256), 0, s, OA);
+}
+
 template <typename T>
 struct Solver {
     oc_handle* h;
@@ -1496,7 +1525,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                                (T*)sh->recv_up, (T*)sh->recv_dn, lo, hi, hn, sh->has_up, sh->has_dn);
         }
         if (prof) event();
-        hipLaunchKernelGGL(k_out<T>, dim3(S.fused_grid()), dim3(256), 0, s, OA);
+        launch_out<T>(h->out_tile, S.Nx, S.Ny, s, OA);
         if (prof) event();
         ++enq;
         return OC_OK;
@@ -1812,7 +1841,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                     OA.Ny = S.Ny;
                     OA.Nx = S.Nx;
                     oc_timer_begin(h, "hjb_out", s);
-                    hipLaunchKernelGGL(k_out<T>, dim3(S.fused_grid()), dim3(256), 0, s, OA);
+                    launch_out<T>(h->out_tile, S.Nx, S.Ny, s, OA);
                     oc_timer_end(h, "hjb_out", s, sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2)));
                     stats.n_slices_written += nv;
                     // (the pinned block is rewritten only after the next attempt's reduction has been read: copy done)
