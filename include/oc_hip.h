@@ -246,6 +246,8 @@ int oc_set_hjb_variant(oc_handle* h, int variant);
  *                 (default 256; the launch uses the fewest blocks that give every prep wavefront the same tile count)
  *   "resort_every" same as oc_set_resort_every
  *   "seq_margin_mm" displacement bound M of oc_gcfm_step_sequential in millimetres (default 250)
+ *   "out_tile"     tile of the dense-output / direction-field writer: -1 = by grid size (default), 0 = 64 x 16,
+ *                  1 = 128 x 8, 2 = 256 x 4 cells
  *   "hjb_fuse"     stage launches of an RK attempt of the product path: 0 = one launch of six stages (default),
  *                  1 = two launches of three */
 int oc_set_tuning(oc_handle* h, const char* name, int value);

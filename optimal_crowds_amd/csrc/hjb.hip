@@ -724,25 +724,6 @@ __device__ __forceinline__ float lane_prev(float v) {
 __device__ __forceinline__ float lane_next(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));      // wave_shl:1
 }
-// the same within rows of 16 lanes (k_out: 16 vectors = one 64-cell tile row)
-__device__ __forceinline__ float row_prev(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));      // row_shr:1
-}
-__device__ __forceinline__ float row_next(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, false));      // row_shl:1
-}
-__device__ __forceinline__ double row_prev(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x111, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x111, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ double row_next(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x101, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x101, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 __device__ __forceinline__ double lane_prev(double v) {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, false);
@@ -1133,8 +1114,12 @@ __global__ void k_halo_stage(const HjbCtl<T>* __restrict__ ctl, T* Y0, T* Y1, T*
 }
 
 // ------------------------------------------------------------------------------------------ host side
+// k_out's tile: 128 x 8 cells while the step's seven input arrays fit the 256 MB Infinity Cache (C4: 6.18 TB/s against 5.69
+// with 64 x 16 and 6.04 with 256 x 4), 256 x 4 beyond (C5, 4096 x 4096: 5.44 TB/s against 4.59 / 5.11) -- or the caller's
+// choice (oc_set_tuning "out_tile")
 template <typename T>
 void launch_out(int shape, int Nx, int Ny, hipStream_t s, const OutArgs<T>& OA) {
+    if (shape < 0) shape = (7.0 * sizeof(T) * (double)Nx * Ny > 256e6) ? 2 : 1;
     const int ox = shape == 2 ? 256 : (shape == 1 ? 128 : 64), oy = 1024 / ox;
     const int nb = ((Nx + ox - 1) / ox) * ((Ny + oy - 1) / oy);
     const dim3 grid(8 * ((nb + 7) / 8));

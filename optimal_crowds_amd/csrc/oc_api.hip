@@ -233,7 +233,7 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
         OC_REQUIRE(value >= 1 && value <= 4096, "resort_every out of range");
         h->resort_every = value;
     } else if (!strcmp(name, "out_tile")) {
-        OC_REQUIRE(value >= 0 && value <= 2, "out_tile out of range");
+        OC_REQUIRE(value >= -1 && value <= 2, "out_tile out of range");
         h->out_tile = value;
     } else if (!strcmp(name, "hjb_fuse")) {
         OC_REQUIRE(value >= 0 && value <= 1, "hjb_fuse out of range");

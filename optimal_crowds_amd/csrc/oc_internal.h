@@ -119,7 +119,7 @@ struct oc_handle {
     int prof_mode = 0;
     int64_t prof_tick = 0;          // GCFM step counter for sampled timers
     int hjb_variant = 0;
-    int out_tile = 0;               // tile of k_out: 0 = 64 x 16, 1 = 128 x 8, 2 = 256 x 4 cells
+    int out_tile = -1;              // tile of k_out: -1 = by grid size, 0 = 64 x 16, 1 = 128 x 8, 2 = 256 x 4 cells
     int hjb_fuse = 0;               // stage launches of an RK attempt: 0 = all six stages in one, 1 = 2 x three stages (hjb.hip)
     std::map<std::string, oc_timer> timers;
 };
