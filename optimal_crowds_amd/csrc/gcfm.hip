@@ -50,6 +50,7 @@ struct GcfmParams {
     double drift;       // D: how far a tile box may grow beyond its sort-time box before the lists are invalid
     int32_t ncx, ncy, horder;
     uint32_t fix;       // OC_FIX_* bits (oc_set_fix_flags); 0 = the reference's behaviour
+    uint32_t diag;      // diagnostic builds of k_forces (oc_set_tuning "diag"): 1 = no phase 2, 2 = no prep work, 4 = no compaction either
 };
 
 #define NB_MAX 63
@@ -632,6 +633,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 for (int o = 32; o > 0; o >>= 1) all += __shfl_xor(all, o, 64);
                 if (all > PAIR_LIST_CAP) nround = NROUND;
             }
+            if (P.diag & 4u) nround = 0;
             for (int rd = 0; rd < nround; ++rd) {
                 uint32_t m[NW];
 #pragma unroll
@@ -683,7 +685,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 // the chunk's sums are float64: every pair's float32 force is added exactly, so the result does not
                 // depend on how the launch shape (pair_split, chunk boundaries) groups the pairs
                 double sfx = 0.0, sfy = 0.0;
-                for (int tt = e_beg; tt < e_end; ++tt) {
+                for (int tt = e_beg; tt < ((P.diag & 1u) ? e_beg : e_end); ++tt) {
                     const uint32_t e = lst[tt];
                     const int il = e >> 16, jA = e & 127, jB = (e >> 7) & 127;
                     const double2 pbA = L.l_pos[w][jA], pbB = L.l_pos[w][jB];
@@ -1182,7 +1184,7 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
         __builtin_amdgcn_s_setprio(3);
         for (int t = blockIdx.x * 4 + w; t < S.ntiles; t += nprep * 4) {
             const bool mine = t >= sh.lo && t < sh.hi;
-            if (mine || sh.lookup_all)
+            if ((mine || sh.lookup_all) && !(P.diag & 2u))
                 prep_tile(P, S, C, keys, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8], mine, mine || sh.lookup_all);
         }
         return;
@@ -1542,6 +1544,7 @@ GcfmParams make_params(const oc_handle* h) {
         P.ncy = (int)(c.room_height / P.cell) + 1;
     }
     P.fix = h->fix_flags;
+    P.diag = (uint32_t)h->diag;
     P.horder = 1;
     while ((1 << P.horder) < std::max(P.ncx, P.ncy)) ++P.horder;
     P.drift = 1.5 * c.v_max * c.dt * h->resort_every + 0.1;

@@ -232,6 +232,8 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     } else if (!strcmp(name, "resort_every")) {
         OC_REQUIRE(value >= 1 && value <= 4096, "resort_every out of range");
         h->resort_every = value;
+    } else if (!strcmp(name, "diag")) {
+        h->diag = value;
     } else if (!strcmp(name, "out_tile")) {
         OC_REQUIRE(value >= -1 && value <= 2, "out_tile out of range");
         h->out_tile = value;

@@ -102,6 +102,7 @@ struct oc_handle {
     bool packed_seq = false;    // the snapshot has only been advanced by sequential steps since its re-sort
     double seq_margin = 0.25;   // sequential mode: bound on one step's displacement (m), checked every round
     int pair_split = 4;         // pair wavefronts per tile (1, 2 or 4): occupancy / balance of k_forces (gcfm.hip)
+    int diag = 0;               // diagnostic builds of k_forces (gcfm.hip: GcfmParams::diag) -- results are WRONG with it
     int prep_blocks = 256;      // blocks of k_forces that do the wall search / field lookup of the tiles
     bool work_valid = false;    // tile_work holds a step's measured pair work (for the dispatch order)
     int work_tiles = -1;
