@@ -12,7 +12,9 @@
  *   - calls are asynchronous on `stream` unless the documentation says the function returns host values.
  *   - one handle per device and per simulation; a handle is not thread-safe.
  *   - grids are row-major (Ny, Nx): cell (i, j) = row i (y index), column j (x index), as in the reference.
- *   - `dtype` selects the arithmetic of the HJB state and direction field: OC_F32 (product) or OC_F64 (audit).
+ *   - `dtype` selects the arithmetic of the HJB state and direction field: OC_F32 (product) or OC_F64 (audit);
+ *     oc_hjb_solve / oc_hjb_solve_rows also take OC_F64_F32: float64 state and coef, float32 direction field (the
+ *     reference's field to 1e-6 without the float64 field's memory; register the field with oc_set_field(OC_F32)).
  */
 #ifndef OC_HIP_H
 #define OC_HIP_H
@@ -27,7 +29,7 @@ extern "C" {
 #define OC_ABI_VERSION 1
 
 typedef enum { OC_OK = 0, OC_ERR_ARG = -1, OC_ERR_HIP = -2, OC_ERR_STATE = -3, OC_ERR_SOLVER = -4 } oc_status;
-typedef enum { OC_F32 = 0, OC_F64 = 1 } oc_dtype;
+typedef enum { OC_F32 = 0, OC_F64 = 1, OC_F64_F32 = 2 } oc_dtype;
 
 typedef struct oc_handle oc_handle;
 

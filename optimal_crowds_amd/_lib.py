@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OC_HIP_LIB") or os.path.join(HERE, "liboc_hip.so")     # (OC_HIP_LIB: A/B builds, tools/)
 CSRC = os.path.join(HERE, "csrc")
 
-OC_F32, OC_F64 = 0, 1
+OC_F32, OC_F64, OC_F64_F32 = 0, 1, 2
 # opt-in corrections of reference quirks (oc_hip.h: oc_set_fix_flags); 'horizon' (Q9) is host logic in the facade
 FIX_BITS = {"lookup": 1, "wall_force": 2, "pair_force": 4, "density_norm": 8}
 

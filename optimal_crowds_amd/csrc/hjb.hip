@@ -904,8 +904,8 @@ struct OutArgs {
     T* KX[2];
     T* KM[5];
     T p[6][4];              // rows 0, 2, 3, 4, 5, 6 of P (row 1 is zero)
-    T* vx_base;             // direction field (nslice, Ny, Nx): slice nt - 1 - k  <->  t_eval[k]
-    T* vy_base;
+    void* vx_base;          // direction field (nslice, Ny, Nx) of the kernel's field type TO (= T, or float with a
+    void* vy_base;          // double state: OC_F64_F32): slice nt - 1 - k  <->  t_eval[k]
     size_t slice_elems;
     double* keep_base;      // audit: phi(t_eval[k]) unscaled, float64, slot keep_slot[k] (or NULL)
     const int32_t* keep_slot;
@@ -956,7 +956,7 @@ __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* 
 // Tile = OX x OY cells with OX * OY = 1024 (256 threads x 4 consecutive cells of a row): 64 x 16, 128 x 8 or 256 x 4.  A
 // wider tile writes longer contiguous runs per row and slice (1 KB at 256 instead of 256 B), which is what counts where
 // the seven input arrays no longer come out of the Infinity Cache (4096 x 4096).
-template <typename T, int OX>
+template <typename T, int OX, typename TO>
 __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves per SIMD: at most 128 VGPRs
     constexpr int OY = 1024 / OX, VW = OX / 4, OLS = OX + 8;
     __shared__ alignas(16) T tile[2][OY + 2][OLS];
@@ -1030,8 +1030,8 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
             xp *= x;
             h4 = (T)(hh * xp);
         }
-        T* vxs = want_v ? A.vx_base + (size_t)(nt - 1 - k) * A.slice_elems : nullptr;
-        T* vys = want_v ? A.vy_base + (size_t)(nt - 1 - k) * A.slice_elems : nullptr;
+        TO* vxs = want_v ? (TO*)A.vx_base + (size_t)(nt - 1 - k) * A.slice_elems : nullptr;
+        TO* vys = want_v ? (TO*)A.vy_base + (size_t)(nt - 1 - k) * A.slice_elems : nullptr;
         const int buf = it & 1;
         ++it;
         // The tile holds the CLIPPED phi (optimals.py:172: every use below is of the clipped value), so each cell is
@@ -1068,7 +1068,7 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
         if (vxs && valid) {
             const V4<T> up = ld4(&tile[buf][ry][4 + 4 * cx]), dn = ld4(&tile[buf][ry + 2][4 + 4 * cx]);
             const T lft = (cx == 0) ? tile[buf][ry + 1][3] : lft_n, rgt = (cx == VW - 1) ? tile[buf][ry + 1][4 + OX] : rgt_n;
-            V4<T> ox, oy;
+            V4<TO> ox, oy;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // central differences of the clipped phi (optimals.py:172-180); "north" = row i+1
@@ -1079,8 +1079,8 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
                 T vxo, vyo;
                 direction_of<T>(gx, gy, A.mu * pc, A.lim, vxo, vyo);
                 const bool border = (bmask >> q) & 1;
-                ox.v[q] = border ? (T)0 : vxo;
-                oy.v[q] = border ? (T)0 : vyo;
+                ox.v[q] = border ? (TO)0 : (TO)vxo;
+                oy.v[q] = border ? (TO)0 : (TO)vyo;
             }
             st4_nt(vxs + idx, ox);
             st4_nt(vys + idx, oy);
@@ -1117,15 +1117,15 @@ __global__ void k_halo_stage(const HjbCtl<T>* __restrict__ ctl, T* Y0, T* Y1, T*
 // k_out's tile: 128 x 8 cells while the step's seven input arrays fit the 256 MB Infinity Cache (C4: 6.18 TB/s against 5.69
 // with 64 x 16 and 6.04 with 256 x 4), 256 x 4 beyond (C5, 4096 x 4096: 5.44 TB/s against 4.59 / 5.11) -- or the caller's
 // choice (oc_set_tuning "out_tile")
-template <typename T>
+template <typename T, typename TO>
 void launch_out(int shape, int Nx, int Ny, hipStream_t s, const OutArgs<T>& OA) {
     if (shape < 0) shape = (7.0 * sizeof(T) * (double)Nx * Ny > 256e6) ? 2 : 1;
     const int ox = shape == 2 ? 256 : (shape == 1 ? 128 : 64), oy = 1024 / ox;
     const int nb = ((Nx + ox - 1) / ox) * ((Ny + oy - 1) / oy);
     const dim3 grid(8 * ((nb + 7) / 8));
-    if (shape == 2) hipLaunchKernelGGL((k_out<T, 256>), grid, dim3(256), 0, s, OA);
-    else if (shape == 1) hipLaunchKernelGGL((k_out<T, 128>), grid, dim3(256), 0, s, OA);
-    else hipLaunchKernelGGL((k_out<T, 64>), grid, dim3(256), 0, s, OA);
+    if (shape == 2) hipLaunchKernelGGL((k_out<T, 256, TO>), grid, dim3(256), 0, s, OA);
+    else if (shape == 1) hipLaunchKernelGGL((k_out<T, 128, TO>), grid, dim3(256), 0, s, OA);
+    else hipLaunchKernelGGL((k_out<T, 64, TO>), grid, dim3(256), 0, s, OA);
 }
 
 template <typename T>
@@ -1299,7 +1299,7 @@ void launch_stages_fused(Solver<T>& S, double hh, T atol_s, T rtol) {
 // watches the controller's tick count in a pinned mailbox only to stop when `done` is posted.  In a row-block solve the
 // ranks must enqueue the same number of attempts (every attempt holds collectives), so there the host synchronises
 // the stream once per burst of attempts and all ranks read the same `done` (their controllers are bit-identical).
-template <typename T>
+template <typename T, typename TO>
 int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, void* vx_out, void* vy_out,
                   const int32_t* keep_idx, int32_t n_keep, double* phi_keep, double* t_steps, int32_t t_steps_cap,
                   oc_hjb_stats* st, hipStream_t s, const oc_hjb_shard* sh) {
@@ -1442,8 +1442,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         for (int q = 0; q < 6; ++q)
             for (int pp = 0; pp < 4; ++pp) OA.p[q][pp] = (T)RK_P[rows[q]][pp];
     }
-    OA.vx_base = (T*)vx_out;
-    OA.vy_base = (T*)vy_out;
+    OA.vx_base = vx_out;
+    OA.vy_base = vy_out;
     OA.slice_elems = (size_t)S.Ny * S.Nx;
     OA.keep_base = phi_keep;
     OA.keep_slot = keep_slot_dev;
@@ -1510,7 +1510,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                                (T*)sh->recv_up, (T*)sh->recv_dn, lo, hi, hn, sh->has_up, sh->has_dn);
         }
         if (prof) event();
-        launch_out<T>(h->out_tile, S.Nx, S.Ny, s, OA);
+        launch_out<T, TO>(h->out_tile, S.Nx, S.Ny, s, OA);
         if (prof) event();
         ++enq;
         return OC_OK;
@@ -1573,7 +1573,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                 const int nv = log[a] >> 8;
                 to.add_ms += e2;
                 to.add_n += 1;
-                to.bytes += sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2));
+                to.bytes += sizeof(T) * 7.0 * (double)n + sizeof(TO) * 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2);
             }
         }
     }
@@ -1593,7 +1593,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     return OC_OK;
 }
 
-template <typename T>
+template <typename T, typename TO = T>
 int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, void* vx_out, void* vy_out,
                 const int32_t* keep_idx, int32_t n_keep, double* phi_keep, double* t_steps, int32_t t_steps_cap,
                 oc_hjb_stats* st, hipStream_t s, const oc_hjb_shard* sh = nullptr) {
@@ -1620,8 +1620,12 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
     const int RB = 1024;
     const bool use_fused = (h->hjb_variant != 1) && (c.Nx % 4 == 0);   // vector kernels need 16-byte rows
     if (h->hjb_variant == 0 && use_fused)        // the default: three stages per launch, controller on the device
-        return hjb_solve_dev<T>(h, coef_v, Tfinal, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, t_steps, t_steps_cap,
-                                st, s, sh);
+        return hjb_solve_dev<T, TO>(h, coef_v, Tfinal, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, t_steps, t_steps_cap,
+                                    st, s, sh);
+    if (sizeof(TO) != sizeof(T)) {
+        oc_set_error("the float64-state / float32-field mode needs the product path (Nx %% 4 == 0, hjb variant 0)");
+        return OC_ERR_ARG;
+    }
     if (sh) {
         oc_set_error("hjb_solve_rows needs the fused kernels (Nx %% 4 == 0, hjb variant 0)");
         return OC_ERR_ARG;
@@ -1814,8 +1818,8 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                     const int prow[6] = {0, 2, 3, 4, 5, 6};
                     for (int q = 0; q < 6; ++q)
                         for (int pp = 0; pp < 4; ++pp) OA.p[q][pp] = (T)RK_P[prow[q]][pp];
-                    OA.vx_base = (T*)vx_out;
-                    OA.vy_base = (T*)vy_out;
+                    OA.vx_base = vx_out;
+                    OA.vy_base = vy_out;
                     OA.slice_elems = slice_elems;
                     OA.keep_base = phi_keep;
                     OA.keep_slot = keep_slot_dev;
@@ -1826,7 +1830,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                     OA.Ny = S.Ny;
                     OA.Nx = S.Nx;
                     oc_timer_begin(h, "hjb_out", s);
-                    launch_out<T>(h->out_tile, S.Nx, S.Ny, s, OA);
+                    launch_out<T, T>(h->out_tile, S.Nx, S.Ny, s, OA);
                     oc_timer_end(h, "hjb_out", s, sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2)));
                     stats.n_slices_written += nv;
                     // (the pinned block is rewritten only after the next attempt's reduction has been read: copy done)
@@ -1962,6 +1966,9 @@ extern "C" int oc_hjb_solve(oc_handle* h, int dtype, const void* coef, double T,
     else if (dtype == OC_F64)
         rc = hjb_solve_t<double>(h, coef, T, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, t_steps, t_steps_cap,
                                  stats, s);
+    else if (dtype == OC_F64_F32)
+        rc = hjb_solve_t<double, float>(h, coef, T, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, t_steps, t_steps_cap,
+                                        stats, s);
     else {
         oc_set_error("bad dtype %d", dtype);
         return OC_ERR_ARG;
@@ -2003,6 +2010,9 @@ extern "C" int oc_hjb_solve_rows(oc_handle* h, int dtype, const void* coef_rows,
     else if (dtype == OC_F64)
         rc = hjb_solve_t<double>(h, coef_rows, T, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, nullptr, 0, stats, s,
                                  sh);
+    else if (dtype == OC_F64_F32)
+        rc = hjb_solve_t<double, float>(h, coef_rows, T, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, nullptr, 0, stats,
+                                        s, sh);
     else {
         oc_set_error("bad dtype %d", dtype);
         return OC_ERR_ARG;

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FIX_BITS, OC_F32, OC_F64, OcAgents, OcConfig, OcHjbStats, check
+from ._lib import FIX_BITS, OC_F32, OC_F64, OC_F64_F32, OcAgents, OcConfig, OcHjbStats, check
 
 LIM = 10e-3          # reference optimals.py:95
 
@@ -27,12 +27,13 @@ def hjb_state_dtype(cfg, T, requested="float32"):
     """The arithmetic type of the HJB state for horizon T.  float32 carries phi * 2^-e (csrc/hjb.hip, range management):
     phi grows to e^(T V_target / (mu sigma^2)) while the far field stays at 1, so the scaled far field 2^-e -- and the
     clip level lim * 2^-e -- leave float32's normal range when log2(e) T V_target / (mu sigma^2) - 64 exceeds ~118
-    (T > 25 s with the reference's config).  Beyond that the same kernels run in float64 (twice the bytes, no limit)."""
+    (T > 25 s with the reference's config).  Beyond that the same kernels run on a float64 state ('mixed': the direction
+    field stays float32, so its memory does not double)."""
     if requested not in ("float32", "f32", torch.float32):
-        return "float64"
+        return requested if requested == "mixed" else "float64"
     hp = cfg["hjb_params"]
     bits = 1.4426950408889634 * float(T) * abs(hp["target_potential"]) / (hp["mu"] * hp["sigma"] ** 2)
-    return "float32" if bits - 64.0 <= 118.0 else "float64"
+    return "float32" if bits - 64.0 <= 118.0 else "mixed"
 
 
 class Engine:
@@ -43,8 +44,14 @@ class Engine:
             raise _lib.OcError("no HIP device visible: optimal_crowds_amd needs an MI355X (there is no CPU path)")
         self.device = torch.device(device)
         self.dev_index = self.device.index or 0
-        self.dtype = OC_F32 if dtype in ("float32", "f32", torch.float32) else OC_F64
+        # dtype: 'float32' (product), 'float64' (audit: state AND field), 'mixed' (float64 HJB state, float32 field: the
+        # reference's direction field to 1e-6 -- no float32 ripple, DESIGN.md 3.1 -- without doubling the field's memory)
+        self.mixed = dtype == "mixed"
+        self.dtype = OC_F32 if dtype in ("float32", "f32", torch.float32) else OC_F64             # HJB state, coef, m
         self.tdtype = torch.float32 if self.dtype == OC_F32 else torch.float64
+        self.field_dtype = OC_F32 if self.mixed else self.dtype                                    # direction field
+        self.field_tdtype = torch.float32 if self.field_dtype == OC_F32 else torch.float64
+        self.solve_dtype = OC_F64_F32 if self.mixed else self.dtype
         self.Nx, self.Ny, self.n_keys = Nx, Ny, n_keys
         hp = cfg["hjb_params"]
         c = OcConfig()
@@ -196,8 +203,8 @@ class Engine:
         rc = self._key_rows(key)
         rows = rc.shard.Ny_local if rc is not None else self.Ny                  # row-sharded: this rank's block
         shape = (max(nslice, 0), rows, self.Nx)
-        vx = torch.zeros(shape, dtype=self.tdtype, device=self.device)
-        vy = torch.zeros(shape, dtype=self.tdtype, device=self.device)
+        vx = torch.zeros(shape, dtype=self.field_tdtype, device=self.device)
+        vy = torch.zeros(shape, dtype=self.field_tdtype, device=self.device)
         self.fields[key] = [vx, vy, nslice, 0]
         return vx, vy
 
@@ -222,9 +229,9 @@ class Engine:
         return out
 
     def vels(self, phi64, scale=1.0):
-        vx = torch.zeros((self.Ny, self.Nx), dtype=self.tdtype, device=self.device)
+        vx = torch.zeros((self.Ny, self.Nx), dtype=self.field_tdtype, device=self.device)
         vy = torch.zeros_like(vx)
-        check(self.lib.oc_hjb_vels(self.h, self.dtype, _ptr(phi64), float(scale), _ptr(vx), _ptr(vy), self.stream()))
+        check(self.lib.oc_hjb_vels(self.h, self.field_dtype, _ptr(phi64), float(scale), _ptr(vx), _ptr(vy), self.stream()))
         return vx, vy
 
     def solve(self, key, T, nt, m=None, keep=None, want_steps=False):
@@ -243,7 +250,7 @@ class Engine:
             st, _, phi_keep = self.solve_rows(key, T, nt, rc, m=m, keep=keep, field=(vx, vy))
             self.fields[key][3] = nt
             sh = rc.shard
-            check(self.lib.oc_set_field_rows(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt),
+            check(self.lib.oc_set_field_rows(self.h, key, self.field_dtype, _ptr(vx), _ptr(vy), nslice, int(nt),
                                              int(sh.row0), int(sh.Ny_local), int(sh.g0), int(sh.g1)))
             return st, phi_keep
         self.make_coef(key, m)
@@ -256,12 +263,12 @@ class Engine:
             phi_keep = torch.empty((n_keep, self.Ny, self.Nx), dtype=torch.float64, device=self.device)
         cap = 100000 if want_steps else 0
         tsteps = np.zeros(max(cap, 1))
-        check(self.lib.oc_hjb_solve(self.h, self.dtype, _ptr(self.coef), float(T), int(nt), _ptr(vx), _ptr(vy),
+        check(self.lib.oc_hjb_solve(self.h, self.solve_dtype, _ptr(self.coef), float(T), int(nt), _ptr(vx), _ptr(vy),
                                     keep_arr.ctypes.data_as(C.c_void_p) if keep_arr is not None else None, n_keep,
                                     _ptr(phi_keep), tsteps.ctypes.data_as(C.c_void_p) if cap else None, cap,
                                     C.byref(stats), self.stream()))
         self.fields[key][3] = nt
-        check(self.lib.oc_set_field(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt)))
+        check(self.lib.oc_set_field(self.h, key, self.field_dtype, _ptr(vx), _ptr(vy), nslice, int(nt)))
         st = stats.as_dict()
         if want_steps:
             st["t_steps"] = tsteps[:st["n_accept"] + 1].copy()
@@ -276,8 +283,8 @@ class Engine:
         coef_rows = self.coef[sh.rows()]
         if field is None:
             shape = (max(nt - 1, 0), sh.Ny_local, self.Nx)
-            field = (torch.zeros(shape, dtype=self.tdtype, device=self.device),
-                     torch.zeros(shape, dtype=self.tdtype, device=self.device))
+            field = (torch.zeros(shape, dtype=self.field_tdtype, device=self.device),
+                     torch.zeros(shape, dtype=self.field_tdtype, device=self.device))
         vx, vy = field
         stats = OcHjbStats()
         keep_arr = phi_keep = None
@@ -287,7 +294,7 @@ class Engine:
             n_keep = len(keep_arr)
             phi_keep = torch.empty((n_keep, sh.Ny_local, self.Nx), dtype=torch.float64, device=self.device)
         st = comm.struct()
-        rc = self.lib.oc_hjb_solve_rows(self.h, self.dtype, _ptr(coef_rows), float(T), int(nt), _ptr(vx), _ptr(vy),
+        rc = self.lib.oc_hjb_solve_rows(self.h, self.solve_dtype, _ptr(coef_rows), float(T), int(nt), _ptr(vx), _ptr(vy),
                                         C.byref(st), keep_arr.ctypes.data_as(C.c_void_p) if n_keep else None, n_keep,
                                         _ptr(phi_keep), C.byref(stats), self.stream())
         if comm.error is not None:
@@ -304,7 +311,7 @@ class Engine:
                              "halo >= 7 (the field is exact halo - 6 rows beyond the block)")
         nslice = int(vx.shape[0])
         self.fields[key] = [vx, vy, nslice, int(nt)]
-        check(self.lib.oc_set_field_rows(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt), int(shard.row0),
+        check(self.lib.oc_set_field_rows(self.h, key, self.field_dtype, _ptr(vx), _ptr(vy), nslice, int(nt), int(shard.row0),
                                          int(shard.Ny_local), int(shard.g0), int(shard.g1)))
 
     def set_field_horizon(self, key, nt):
@@ -315,10 +322,10 @@ class Engine:
         rc = self._key_rows(key)
         if rc is not None:
             sh = rc.shard
-            check(self.lib.oc_set_field_rows(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt),
+            check(self.lib.oc_set_field_rows(self.h, key, self.field_dtype, _ptr(vx), _ptr(vy), nslice, int(nt),
                                              int(sh.row0), int(sh.Ny_local), int(sh.g0), int(sh.g1)))
             return
-        check(self.lib.oc_set_field(self.h, key, self.dtype, _ptr(vx), _ptr(vy), nslice, int(nt)))
+        check(self.lib.oc_set_field(self.h, key, self.field_dtype, _ptr(vx), _ptr(vy), nslice, int(nt)))
 
     # ------------------------------------------------------------------ agents
     def set_agents(self, x, y, vx, vy, v_des, key, status=None, agent_time=None):

@@ -163,7 +163,8 @@ class simulation:
         self._nt0 = nt0
         if wall_search_radius is None:
             wall_search_radius = -1.0          # per-agent radius beyond which the wall force is < 1e-12 m/s
-        # float32 HJB state unless the horizon takes phi beyond what its range management covers (T > ~25 s): float64 then
+        # float32 HJB state unless the horizon takes phi beyond what its range management covers (T > ~25 s): 'mixed' then
+        # (float64 state, float32 field); dtype='mixed' / 'float64' can also be asked for
         self.hjb_dtype = hjb_state_dtype(var_config, T, dtype)
         self._engine = Engine(var_config, self.room_length, self.room_height, self.Nx, self.Ny, self._X0, self._Y0,
                               len(key_names), self.N, device=device, dtype=self.hjb_dtype,

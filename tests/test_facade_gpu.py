@@ -154,18 +154,19 @@ def test_run_without_a_round_trip_per_step_ends_where_the_stepwise_loop_ends():
 
 def test_long_horizon_switches_the_hjb_state_to_float64():
     """T = 30 s: phi reaches e^150, beyond what float32's range management covers (the solve used to end with a NaN
-    error norm); the facade then runs the same kernels on a float64 state -- checked against the oracle's solve -- while
-    T = 20 s stays float32."""
+    error norm); the facade then runs the same kernels on a float64 state ('mixed': the direction field stays float32)
+    -- checked against the oracle's solve -- while T = 20 s stays float32."""
     from optimal_crowds_amd import simulations
     from optimal_crowds_amd.engine import hjb_state_dtype
     cfg = _cfg()
     assert hjb_state_dtype(cfg, 20.0) == "float32" and hjb_state_dtype(cfg, 25.0) == "float32"
-    assert hjb_state_dtype(cfg, 30.0) == "float64" and hjb_state_dtype(cfg, 30.0, "float64") == "float64"
+    assert hjb_state_dtype(cfg, 30.0) == "mixed" and hjb_state_dtype(cfg, 30.0, "float64") == "float64"
+    assert hjb_state_dtype(cfg, 20.0, "mixed") == "mixed"
     T = 30.0
     np.random.seed(3)
     with contextlib.redirect_stdout(io.StringIO()):
         sim = simulations.simulation("gold_a", T, config=cfg, noise="host", record=False)
-        assert sim.hjb_dtype == "float64"
+        assert sim.hjb_dtype == "mixed"         # float64 state, float32 direction field
         key = sim._key_names[0]
         sim.targets[key].compute_optimal_velocity(0.0, None)
     st = sim.targets[key].stats

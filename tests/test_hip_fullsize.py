@@ -211,17 +211,20 @@ def test_c4_value_grid_and_direction_field_vs_c_oracle(c4):
         assert flips <= 1e-3
 
 
-def test_c4_float64_mode_reproduces_the_oracle_at_full_size(c4):
-    """The same 2048 x 2048 solve in the library's float64 mode (same kernels, templated) against the C oracle on the
-    GPU's step sequence: phi within 1e-5 pointwise at t = 0 [8.4e-7: two float64 summation orders, amplified by the
-    marginally stable mode], direction within 1e-5 rad.  Ten output slices only (nt = 11 over the full T = 20), so the
-    float64 direction field stays small."""
+@pytest.mark.parametrize("dtype", ["float64", "mixed"])
+def test_c4_float64_mode_reproduces_the_oracle_at_full_size(c4, dtype):
+    """The same 2048 x 2048 solve on a float64 state (same kernels, templated) against the C oracle on the GPU's step
+    sequence: phi within 1e-5 pointwise at t = 0 [8.4e-7: two float64 roundings, amplified by the marginally stable
+    mode], direction within 1e-5 rad.  'float64' = state and field; 'mixed' = float64 state, float32 direction field (what
+    a user who needs the reference's field at this size would run: no float32 ripple, no doubled field memory).  Ten
+    output slices only (nt = 11 over the full T = 20)."""
+    import torch
     from oracle import oc_oracle_c as occ
     from optimal_crowds_amd.engine import Engine
     sim, cfg, stats = c4
     hp = cfg["hjb_params"]
     V = np.ascontiguousarray(sim.Vs[sim._key_names[0]])
-    eng = Engine(cfg, sim.room_length, sim.room_height, sim.Nx, sim.Ny, sim._X0, sim._Y0, 1, 16, dtype="float64")
+    eng = Engine(cfg, sim.room_length, sim.room_height, sim.Nx, sim.Ny, sim._X0, sim._Y0, 1, 16, dtype=dtype)
     eng.set_potential(0, V, np.zeros((0, 4)))
     nt = 11
     eng.alloc_field(0, nt - 1)
@@ -233,12 +236,13 @@ def test_c4_float64_mode_reproduces_the_oracle_at_full_size(c4):
     assert zst["n_accept"] == st["n_accept"]
     assert_steps_acceptable(zst["err"])
     vx, vy = eng.field_interior(0)
+    assert vx.dtype == (torch.float32 if dtype == "mixed" else torch.float64)
     for q, k in enumerate(keep):
         point, avg = phi_errors(got[q], want[q], V, sim.Ny, sim.Nx)
         assert point <= 1e-5, (k, point, avg)
         s = nt - 1 - k
         gx, gy = occ.vels(P, want[q])
-        a, flips = direction_errors(gx, gy, vx[s].cpu().numpy(), vy[s].cpu().numpy(),
+        a, flips = direction_errors(gx, gy, vx[s].double().cpu().numpy(), vy[s].double().cpu().numpy(),
                                     clear_cells(want[q], sim.Ny, sim.Nx, cfg["grid_step"], hp["mu"]))
         assert a.size > 1000 and a.max() <= 1e-5 and flips <= 1e-5
     eng.close()
