@@ -1532,7 +1532,14 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             for (long spin = 0;; ++spin) {
                 const double w = mb[0];
                 if (w >= 4294967296.0 || w >= (double)(enq - LAG)) break;
-                if ((spin & 4095) == 4095 && hipStreamQuery(s) == hipSuccess) break;
+                if ((spin & 4095) == 4095) {            // drained (mailbox not visible?) or failed: never spin on a dead stream
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) {
+                        oc_set_error("hjb_solve: %s", hipGetErrorString(q));
+                        return OC_ERR_HIP;
+                    }
+                }
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
