@@ -56,7 +56,7 @@ def csrc_hash():
     return hsh.hexdigest()[:16]
 
 
-def build_sim(workload, seed=20240807, wall_search_radius=-1.0, sharding=None):
+def build_sim(workload, seed=20240807, wall_search_radius=-1.0, sharding=None, dtype="float32"):
     import io
     import contextlib
     from optimal_crowds_amd import host, simulations
@@ -66,7 +66,7 @@ def build_sim(workload, seed=20240807, wall_search_radius=-1.0, sharding=None):
     np.random.seed(seed)
     with contextlib.redirect_stdout(io.StringIO()):
         sim = simulations.simulation(room, T, recompute, config=cfg, noise="device", seed=seed, record=False, history=False,
-                                     wall_search_radius=wall_search_radius, sharding=sharding)
+                                     wall_search_radius=wall_search_radius, sharding=sharding, dtype=dtype)
     return sim, cfg
 
 
@@ -307,6 +307,8 @@ def main():
                          "one independent simulation per GPU (aggregate replica throughput, weak scaling)")
     ap.add_argument("--no-ensemble-line", action="store_true", help="sharded mode: do not also measure the ensemble")
     ap.add_argument("--tune", default="", help="launch-shape knobs, e.g. pair_split=4 (oc_set_tuning)")
+    ap.add_argument("--hjb-dtype", default="float32", choices=["float32", "mixed", "float64"],
+                    help="HJB state: float32 (BASELINE's configs, default), mixed (float64 state, float32 field), float64")
     args = ap.parse_args()
 
     import torch
@@ -332,9 +334,10 @@ def main():
     sharded = mode == "sharded" and world > 1
     t_init = time.perf_counter()
     if sharded:     # one simulation on all ranks: same seed everywhere (replicated agents)
-        sim, cfg = build_sim(args.workload, wall_search_radius=args.wall_radius, sharding=parallel.dist_sharding())
+        sim, cfg = build_sim(args.workload, wall_search_radius=args.wall_radius, sharding=parallel.dist_sharding(),
+                             dtype=args.hjb_dtype)
     else:           # N = 1, or an ensemble: every rank simulates its own member (own placement and noise seed)
-        sim, cfg = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius)
+        sim, cfg = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius, dtype=args.hjb_dtype)
     t_init = time.perf_counter() - t_init
     eng = sim._engine
     for kv in filter(None, args.tune.split(",")):
@@ -377,12 +380,14 @@ def main():
         "value": (1 if sharded or world == 1 else world) * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K,
         "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
         "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if sim.hjb_dtype == "float32" else "f64", "data": "synthetic",
         "config": {"workload": "%s %dx%d grid, %d agents, %d keys, T=%g (nt=%d)"
                                % (args.workload, sim.Nx, sim.Ny, sim.N, keys_n, sim.T, nt)
                    + (", recompute=True" if sim.recompute else ""),
                    "parallelism": parallelism, "mode": "sharded" if sharded else ("ensemble" if world > 1 else "single"),
-                   "noise": "device Philox", "agent_state": "f64", "pair_math": "f32", "hjb_state": "f32"},
+                   "noise": "device Philox", "agent_state": "f64", "pair_math": "f32",
+                   "hjb_state": {"float32": "f32", "mixed": "f64", "float64": "f64"}[sim.hjb_dtype],
+                   "hjb_field": "f64" if sim.hjb_dtype == "float64" else "f32"},
         "roofline": roof,
         "breakdown": {"hjb_solve_s_total_this_rank": t_hjb, "hjb_solves_this_rank": len(mine),
                       "gcfm_kernel_ms_per_step": kernel_step_ms,
