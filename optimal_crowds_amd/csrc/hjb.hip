@@ -785,90 +785,112 @@ __global__ void __launch_bounds__(RWV * RH) k_stageV(Stage3Args<T> A) {
     const int gi = (logical / nbx) * TY - HY + ry, gj = (logical % nbx) * TX - HX + 4 * vx;
     const bool in = gi >= 0 && gi < Ny && gj >= 0 && gj < Nx;      // (Nx % 4 == 0: a vector is inside or outside as a whole)
     const int64_t idx = (int64_t)gi * Nx + gj;
-    V4<T> yv, cf, kv[NK], t;
+    // The thread's four cells as two PAIRS: float pairs are packed-math operands (v_pk_fma_f32 / v_pk_add_f32 /
+    // v_pk_mul_f32: one instruction for two cells -- the launch is bound by VALU issue, 71 % busy before this), double
+    // pairs compile to two scalar operations each.  Same IEEE operations per cell either way.
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    T2 yv[2], cf[2], al[2], kv[NK][2], t[2];
+    const T2 zero2 = {(T)0, (T)0};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        yv.v[c] = cf.v[c] = t.v[c] = (T)0;
-#pragma unroll
-        for (int j = 0; j < NK; ++j) kv[j].v[c] = (T)0;
+    for (int p = 0; p < 2; ++p) {
+        yv[p] = cf[p] = al[p] = t[p] = zero2;       // al: the wall mask (coef = NaN: optimals.py:162) folded into the two
+#pragma unroll                                      // coefficients once: a wall cell evaluates 0 * sum - 0 * C = 0 in every
+        for (int j = 0; j < NK; ++j) kv[j][p] = zero2;      // stage, without a compare and a select per stage
     }
-    V4<T> al;                                       // the wall mask (coef = NaN: optimals.py:162) folded into the two
-#pragma unroll                                      // coefficients once: a wall cell evaluates 0 * sum - 0 * C = 0 in
-    for (int c = 0; c < 4; ++c) al.v[c] = (T)0;     // every stage, without a compare and a select per stage
     if (in) {
-        yv = ld4(y + idx);
-        cf = ld4(A.coef + idx);
+        const V4<T> y4 = ld4(y + idx), c4 = ld4(A.coef + idx);
 #pragma unroll
-        for (int j = 0; j < S0; ++j) kv[j] = ld4(kin[j] + idx);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            yv.v[c] *= in_scale;                    // (1 unless the previous step ordered a rescale: exact)
-            kv[0].v[c] *= in_scale;
-            const bool wall = cf.v[c] != cf.v[c];
-            al.v[c] = wall ? (T)0 : A.a_lap;
-            cf.v[c] = wall ? (T)0 : cf.v[c];
+        for (int p = 0; p < 2; ++p) {
+            yv[p] = (T2){y4.v[2 * p], y4.v[2 * p + 1]} * (T2){in_scale, in_scale};      // (1 unless the previous step
+            const bool w0 = c4.v[2 * p] != c4.v[2 * p], w1 = c4.v[2 * p + 1] != c4.v[2 * p + 1];     // ordered a rescale)
+            al[p] = (T2){w0 ? (T)0 : A.a_lap, w1 ? (T)0 : A.a_lap};
+            cf[p] = (T2){w0 ? (T)0 : c4.v[2 * p], w1 ? (T)0 : c4.v[2 * p + 1]};
         }
+#pragma unroll
+        for (int j = 0; j < S0; ++j) {
+            const V4<T> k4 = ld4(kin[j] + idx);
+            kv[j][0] = (T2){k4.v[0], k4.v[1]};
+            kv[j][1] = (T2){k4.v[2], k4.v[3]};
+        }
+        kv[0][0] *= (T2){in_scale, in_scale};
+        kv[0][1] *= (T2){in_scale, in_scale};
     }
+    auto quad = [](const T2& a, const T2& b) {
+        V4<T> r;
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+        return r;
+    };
     T* const slot0 = &buf[0][ry + 1][4 + 4 * vx];
     constexpr int BUF = (RH + 2) * LS;              // elements between the two buffers
+    const T2 m4 = {(T)-4, (T)-4};
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         T* const slot = slot0 + (q & 1) * BUF;
+        T2 acc0 = zero2, acc1 = zero2;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            T acc = (T)0;
-#pragma unroll
-            for (int j = 0; j < S0 + q; ++j) acc = fma_t(cc[q][j], kv[j].v[c], acc);
-            t.v[c] = yv.v[c] + acc;
+        for (int j = 0; j < S0 + q; ++j) {
+            const T2 c2 = {cc[q][j], cc[q][j]};
+            acc0 = __builtin_elementwise_fma(c2, kv[j][0], acc0);
+            acc1 = __builtin_elementwise_fma(c2, kv[j][1], acc1);
         }
+        t[0] = yv[0] + acc0;
+        t[1] = yv[1] + acc1;
         if (in) {
-            st4(slot, t);
-            if (gi == 1 && ry >= 1) st4(slot - 2 * LS, t);                  // ghost row -1 = row 1
-            if (gi == Ny - 2 && ry + 2 <= RH - 1) st4(slot + 2 * LS, t);   // ghost row Ny = row Ny-2
+            const V4<T> t4 = quad(t[0], t[1]);
+            st4(slot, t4);
+            if (gi == 1 && ry >= 1) st4(slot - 2 * LS, t4);                  // ghost row -1 = row 1
+            if (gi == Ny - 2 && ry + 2 <= RH - 1) st4(slot + 2 * LS, t4);   // ghost row Ny = row Ny-2
         }
         // left / right neighbours of the vector: the adjacent lanes' cells (a region row is RWV consecutive lanes; what
         // crosses a row's end is region-edge garbage by construction), or the mirror cell at the room's border
-        const T lft_n = lane_prev(t.v[3]), rgt_n = lane_next(t.v[0]);
-        const T lft = (gj == 0) ? t.v[1] : lft_n, rgt = (gj + 3 == Nx - 1) ? t.v[2] : rgt_n;
+        const T lft_n = lane_prev(t[1].y), rgt_n = lane_next(t[0].x);
+        const T lft = (gj == 0) ? t[0].y : lft_n, rgt = (gj + 3 == Nx - 1) ? t[1].x : rgt_n;
         __syncthreads();
         const V4<T> up = ld4(slot - LS), dn = ld4(slot + LS);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const T C = t.v[c];
-            const T l = (c == 0) ? lft : t.v[c - 1], r = (c == 3) ? rgt : t.v[c + 1];
-            kv[S0 + q].v[c] = rhs_value(up.v[c], dn.v[c], l, r, C, al.v[c], cf.v[c]);
-        }
+        // hjb(t, phi, m) (rhs_value): a (N + S + W + E - 4 C) - coef C with the sum in the reference's order
+        const T2 mid = {t[0].y, t[1].x};            // right neighbours of cells 0, 1 = left neighbours of cells 2, 3
+        const T2 l0 = {lft, t[0].x}, r1 = {t[1].y, rgt};
+        T2 s0 = (((T2){up.v[0], up.v[1]} + (T2){dn.v[0], dn.v[1]}) + l0) + mid;
+        T2 s1 = (((T2){up.v[2], up.v[3]} + (T2){dn.v[2], dn.v[3]}) + mid) + r1;
+        s0 = __builtin_elementwise_fma(m4, t[0], s0);
+        s1 = __builtin_elementwise_fma(m4, t[1], s1);
+        kv[S0 + q][0] = al[0] * s0 - cf[0] * t[0];
+        kv[S0 + q][1] = al[1] * s1 - cf[1] * t[1];
     }
     const bool store = in && ry >= HY && ry < RH - HY && vx >= HX / 4 && vx < RWV - HX / 4;
     double esum = 0.0, ymax = 0.0;
     if (store) {
         if (NQ == 6) {                              // K2 .. K5, K6 (K1 is not needed again), y_new
-            st4(A.KM[1] + idx, kv[2]);
-            st4(A.KM[2] + idx, kv[3]);
-            st4(A.KM[3] + idx, kv[4]);
-            st4(A.KM[4] + idx, kv[5]);
-            st4(A.KX[par ^ 1] + idx, kv[6]);
+            st4(A.KM[1] + idx, quad(kv[2][0], kv[2][1]));
+            st4(A.KM[2] + idx, quad(kv[3][0], kv[3][1]));
+            st4(A.KM[3] + idx, quad(kv[4][0], kv[4][1]));
+            st4(A.KM[4] + idx, quad(kv[5][0], kv[5][1]));
+            st4(A.KX[par ^ 1] + idx, quad(kv[6][0], kv[6][1]));
         } else if (!FINAL) {
-            st4(A.KM[0] + idx, kv[S0]);
-            st4(A.KM[1] + idx, kv[S0 + 1]);
-            st4(A.KM[2] + idx, kv[S0 + 2]);
+            st4(A.KM[0] + idx, quad(kv[S0][0], kv[S0][1]));
+            st4(A.KM[1] + idx, quad(kv[S0 + 1][0], kv[S0 + 1][1]));
+            st4(A.KM[2] + idx, quad(kv[S0 + 2][0], kv[S0 + 2][1]));
         } else {
-            st4(A.KM[3] + idx, kv[S0]);
-            st4(A.KM[4] + idx, kv[S0 + 1]);
-            st4(A.KX[par ^ 1] + idx, kv[S0 + 2]);
+            st4(A.KM[3] + idx, quad(kv[S0][0], kv[S0][1]));
+            st4(A.KM[4] + idx, quad(kv[S0 + 1][0], kv[S0 + 1][1]));
+            st4(A.KX[par ^ 1] + idx, quad(kv[S0 + 2][0], kv[S0 + 2][1]));
         }
         if (FINAL) {
-            st4(ynew + idx, t);                     // the last stage's working value IS y_new
+            st4(ynew + idx, quad(t[0], t[1]));      // the last stage's working value IS y_new
             if (gi >= A.row_lo && gi < A.row_hi) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    T e = he[6] * kv[NK - 1].v[c];
+                for (int p = 0; p < 2; ++p) {
+                    T2 e = (T2){he[6], he[6]} * kv[NK - 1][p];
 #pragma unroll
-                    for (int j = 0; j < NK - 1; ++j) e = fma_t(he[j], kv[j].v[c], e);
-                    const T sc = atol_s + fmax(fabs(yv.v[c]), fabs(t.v[c])) * A.rtol;
-                    const T qq = e / sc;
-                    esum += (double)qq * (double)qq;
-                    ymax = fmax(ymax, (double)fabs(t.v[c]));
+                    for (int j = 0; j < NK - 1; ++j) e = __builtin_elementwise_fma((T2){he[j], he[j]}, kv[j][p], e);
+                    const T e2[2] = {e.x, e.y}, y2[2] = {yv[p].x, yv[p].y}, t2[2] = {t[p].x, t[p].y};
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const T sc = atol_s + fmax(fabs(y2[c]), fabs(t2[c])) * A.rtol;
+                        const T qq = e2[c] / sc;
+                        esum += (double)qq * (double)qq;
+                        ymax = fmax(ymax, (double)fabs(t2[c]));
+                    }
                 }
             }
         }
