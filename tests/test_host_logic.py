@@ -1,0 +1,37 @@
+"""Host-side logic that needs no GPU: the reference's import line, the choice of the HJB state type, bench.py's helpers."""
+import copy
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_import_line_resolves_to_this_package():
+    import optimal_crowds
+    from optimal_crowds import simulations, optimals, pedestrians          # noqa: F401  (reference README.md:31)
+    from optimal_crowds_amd import simulations as s2
+    assert simulations is s2 and optimal_crowds.optimals is optimals
+    assert hasattr(simulations, "simulation") and hasattr(pedestrians, "ped")
+    assert os.path.exists(os.path.join(REPO, "optimal_crowds", "config.json"))    # where the reference opens it (cwd-relative)
+
+
+def test_hjb_state_dtype_follows_the_float32_range():
+    from oracle import oc_oracle as oc
+    from optimal_crowds_amd.engine import hjb_state_dtype
+    cfg = copy.deepcopy(oc.DEFAULT_CONFIG)
+    assert [hjb_state_dtype(cfg, T) for T in (4.0, 20.0, 25.0, 26.0, 60.0)] == ["float32"] * 3 + ["mixed"] * 2
+    assert hjb_state_dtype(cfg, 20.0, "float64") == "float64" and hjb_state_dtype(cfg, 20.0, "mixed") == "mixed"
+    cfg["hjb_params"]["mu"] = 50.0                      # phi grows 10 x slower: float32 reaches 10 x farther
+    assert hjb_state_dtype(cfg, 200.0) == "float32" and hjb_state_dtype(cfg, 300.0) == "mixed"
+
+
+def test_bench_helpers():
+    sys.path.insert(0, REPO)
+    import bench
+    h = bench.csrc_hash()
+    assert len(h) == 16 and h == bench.csrc_hash()
+    cores, lim = bench.host_cores()
+    assert 1 <= cores <= lim["affinity"] and lim["host_cpus"] >= 1
+    assert set(bench.SHARDED_BY_DEFAULT) <= set(bench.WORKLOADS)
+    # a PMC summary taken with other kernel sources is never quoted
+    assert bench.pmc_file("no_such_pattern_*.json") is None

@@ -101,3 +101,23 @@ if os.path.exists(step_txt):
             step[kn] = {m.group(1): float(m.group(2)) for m in re.finditer(r"(\w+)\s+n=\d+\s+mean=([0-9.e+]+)", blk)}
     json.dump(step, open(os.path.join(P, tag + "_pmc_step.json"), "w"), indent=1)
 print("profiles:", sorted(os.listdir(P)))
+
+# bench lines of all BASELINE workloads (tools/run_workloads.sh): one compact JSON
+wl = {}
+for f in sorted(glob.glob(os.path.join(G, tag + "_wl_*.json"))):
+    try:
+        d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+    except Exception:
+        continue
+    name = os.path.basename(f)[len(tag) + 4:-5]
+    b, cb = d["breakdown"], d.get("cpu_baseline") or {}
+    wl[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
+                "config": d["config"], "roofline_frac": (d["roofline"] or {}).get("frac"),
+                "hjb_solve_s_mean": b["hjb_solve_s_total_this_rank"] / max(b["hjb_solves_this_rank"], 1),
+                "hjb_solves": b["hjb_solves_this_rank"], "rk_attempts": b["rk_attempts"],
+                "kernel_avg_ms": {k: v["avg_ms"] for k, v in b["kernels"].items()},
+                "cpu_baseline": {k: cb.get(k) for k in ("value", "cores", "kind", "t_hjb_solve_s", "t_step_s", "host_cpus",
+                                                         "cgroup_quota")} if cb else None,
+                "numpy_stack": cb.get("numpy_stack") if cb else None}
+if wl:
+    json.dump(wl, open(os.path.join(P, tag + "_workloads.json"), "w"), indent=1)
