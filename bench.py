@@ -113,14 +113,15 @@ def host_cores():
     return (min(aff, quota) if quota else aff), {"host_cpus": os.cpu_count(), "affinity": aff, "cgroup_quota": quota}
 
 
-def cpu_baseline(sim, cfg, workload, budget_s=25.0):
+def cpu_baseline(sim, cfg, workload, stt, budget_s=25.0):
     """The oracle's C restatement (oracle/liboc_oracle.so: float64, OpenMP, kind = "port": the reference itself is
     Python and cannot travel to this box) timed on this host's cores, all of those this process may use:
       HJB   one COMPLETE solve of key 0 up to the dense output (every RK attempt: occ_rk45_solve, the same algorithm
             as the GPU's) + the dense output and direction field of a sample of slices, scaled to nt - 1 slices;
       GCFM  one COMPLETE synchronous step of all agents (lookup, all pairs with the cutoff test, nearest wall cell,
-            integration) on the state the GPU run ended with -- or, if a probe says it would take longer than the
-            budget, a contiguous share of the agents against all, scaled.
+            integration) on the state the timed region STARTED from (after the warm-up steps: at the end of a run of a
+            small room most agents have left) -- or, if a probe says it would take longer than the budget, a contiguous
+            share of the agents against all, scaled.
     value = nt / (K t_solve + nt t_step): the same "one complete run" the GPU line times.  For the two small rooms the
     NumPy/SciPy-stack restatement (oracle/oc_oracle.py: the reference's own software stack, effectively one core) is
     timed beside it."""
@@ -146,8 +147,7 @@ def cpu_baseline(sim, cfg, workload, budget_s=25.0):
         occ.vels(P, phi[q])
     t_vels = (time.perf_counter() - t0) / len(keep)
     t_hjb = t_attempts + (nt - 1) * (t_dense + t_vels)
-    # ---- GCFM: complete step(s) on the current state
-    stt = sim._engine.get_state()
+    # ---- GCFM: complete step(s) on the state the timed region started from
     N = sim.N
     wms = [occ.WallMap(sim._X0, sim._Y0, sim.Vs[k]) for k in sim._key_names]
     rects = [[sim._room["targets"][t] for t in sim._possible[k]] for k in sim._key_names]
@@ -265,7 +265,7 @@ def pmc_step(workload):
     return d.get("k_forces")
 
 
-def measure(sim, args, nt, world, dist, red_dev):
+def measure(sim, args, nt, world, dist, red_dev, keep_state=False):
     """W warmup steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks."""
     import torch
     from optimal_crowds_amd import parallel
@@ -282,12 +282,13 @@ def measure(sim, args, nt, world, dist, red_dev):
     eng.set_profiling(1 | 4)        # HJB kernels on every 8th attempt, GCFM kernels on every 16th step (events cost gaps)
     eng.reset_kernel_stats()
     stats = []
+    state0 = eng.get_state() if keep_state else None        # the crowd the timed region starts from (CPU baseline's input)
     barrier()
     t0 = time.perf_counter()
     run_steps(sim, K, nt, stats)
     barrier()
     elapsed = time.perf_counter() - t0
-    return parallel.max_over_ranks(elapsed, device=red_dev), stats
+    return parallel.max_over_ranks(elapsed, device=red_dev), stats, state0
 
 
 def main():
@@ -345,7 +346,8 @@ def main():
         eng.set_tuning(name, int(val))
     nt = sim._nt0
     K, W = args.steps, args.warmup
-    elapsed, stats = measure(sim, args, nt, world, dist, red_dev)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    elapsed, stats, state0 = measure(sim, args, nt, world, dist, red_dev, keep_state=want_cpu)
 
     # ---- breakdown (untimed extras for the report)
     mine = [s for rnd in stats for s in rnd if s is not None]
@@ -433,8 +435,8 @@ def main():
                 "waves_per_launch": nw, "source": "SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAVES (profiles/)"}
     if rank == 0 and kf.get("avg_ms") and not args.no_work_count and not sharded:
         result["breakdown"]["gcfm_work"] = gcfm_work(sim, cfg, kf["avg_ms"] * 1e-3, (kernel_step_ms or 1.0) * 1e-3)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(sim, cfg, args.workload,
+    if want_cpu:
+        result["cpu_baseline"] = cpu_baseline(sim, cfg, args.workload, state0,
                                               budget_s=float(os.environ.get("OC_BENCH_CPU_BUDGET", "25")))
     if sharded and not args.no_ensemble_line:
         # the other way to use N GPUs, measured right after: one independent replica per GPU (no data-path collective)
@@ -442,7 +444,7 @@ def main():
         del sim, eng
         torch.cuda.empty_cache()
         sim2, _ = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius)
-        el2, _ = measure(sim2, args, nt, world, dist, red_dev)
+        el2, _, _ = measure(sim2, args, nt, world, dist, red_dev)
         result["ensemble"] = {"value": world * K / el2, "unit": "steps/s (aggregate over %d independent replicas)" % world,
                               "scaling": "weak", "ms_per_step_per_replica": 1e3 * el2 / K}
     if rank == 0:
