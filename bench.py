@@ -234,13 +234,14 @@ def gcfm_work(sim, cfg, t_forces_s, t_step_s):
             "state_bytes_frac_of_hbm_peak": 88.0 * na / t_step_s / (HBM_PEAK_GBS * 1e9)}
 
 
-def pmc_file(pattern):
-    """newest committed PMC summary whose kernels are the ones in this tree (stamped with csrc_hash), else None"""
+def pmc_file(pattern, workload="metro_station"):
+    """newest committed PMC summary of this workload whose kernels are the ones in this tree (stamped with csrc_hash),
+    else None"""
     import glob
     for f in reversed(sorted(glob.glob(os.path.join(REPO, "profiles", pattern)))):
         try:
             d = json.load(open(f))
-            if d.get("csrc_sha") == csrc_hash():
+            if d.get("csrc_sha") == csrc_hash() and d.get("workload", "metro_station") == workload:
                 return d
         except Exception:
             pass
@@ -252,17 +253,13 @@ def pmc_traffic(workload):
     --pmc FETCH_SIZE / WRITE_SIZE passes of this very command, gfx950 FETCH_SIZE x2 correction applied by
     tools/collect_profiles.py).  Counters cannot be collected from inside the timed run, hence the file; null if the
     file is absent, belongs to another workload or was taken with other kernel sources."""
-    d = pmc_file("r*_pmc_traffic*.json")
-    if not d or d.get("workload", "metro_station") != workload:
-        return None
-    return d.get("k_out_hbm_bytes_per_launch")
+    d = pmc_file("r*_pmc_traffic*.json", workload)
+    return d.get("k_out_hbm_bytes_per_launch") if d else None
 
 
 def pmc_step(workload):
-    d = pmc_file("r*_pmc_step*.json")
-    if not d or d.get("workload", "metro_station") != workload:
-        return None
-    return d.get("k_forces")
+    d = pmc_file("r*_pmc_step*.json", workload)
+    return d.get("k_forces") if d else None
 
 
 def measure(sim, args, nt, world, dist, red_dev, keep_state=False):
