@@ -9,7 +9,7 @@ for t in "$@"; do
 import json, sys
 t = sys.argv[1]
 d = json.loads([l for l in open('gpurun_out/ab_%s.log' % t) if l.startswith('{')][-1])
-print(t, 'steps/s %.0f' % d['value'], 'gcfm ms/step %.4f' % d['breakdown']['gcfm_ms_per_step'],
+print(t, 'steps/s %.0f' % d['value'], 'gcfm kernel ms/step %.4f' % (d['breakdown']['gcfm_kernel_ms_per_step'] or 0),
       {k: round(v['avg_ms'], 4) for k, v in d['breakdown']['kernels'].items() if v['avg_ms']})
 PY
 done
