@@ -108,3 +108,49 @@ def test_sequential_margin_violation_is_reported(golden):
     with pytest.raises(OcError, match="seq_margin"):
         eng.step_sequential(int(g["simu_step"]), g["perm"], noise=g["noise"])
     eng.close()
+
+
+def test_sequential_steps_at_config2_size_vs_oracle():
+    """BASELINE configs[1] (exit_opposite: 512 x 512 grid, 5 000 agents at 2.5 / m^2, two keys): eight steps in the
+    reference's update order -- permutation and noise drawn from np.random exactly as simulations.py:271,303 does -- on the
+    GPU and in the oracle's sequential mode.  A dense crowd: every agent has ~120 neighbours within the cutoff, the
+    permutation's dependency graph is tens of levels deep, and any agent advanced out of turn would show up as a
+    difference of millimetres (the synchronous step differs by 2.8e-3 m after one step, G7).  Positions agree to 1e-5 m
+    (float32 pair arithmetic and direction field against float64), the same agents are inside."""
+    import os
+    from optimal_crowds_amd import host, simulations
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = copy.deepcopy(host.load_config(os.path.join(REPO, "optimal_crowds_amd", "config.json")))
+    cfg["grid_step"] = 0.1
+    T = 1.0
+    room = room_library.ROOMS["exit_opposite"]()
+    np.random.seed(77)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim = simulations.simulation("exit_opposite", T, config=cfg, noise="host", update="sequential", record=False,
+                                     history=False, wall_search_radius=0.0)
+        sim._solve_all()
+    np.random.seed(77)
+    ref = oc.Simulation(room, T, cfg=cfg, mode="sequential")
+    assert np.array_equal(sim._x0, ref.x) and np.array_equal(sim._v_des, ref.v_des)         # same crowd
+    ref.solve_all()
+    # a crowd that already moves (k = 0 for a stationary agent, pedestrians.py:259-262): the same velocities on both sides
+    rng = np.random.RandomState(5)
+    v0 = rng.normal(0.0, 0.6, size=(sim.N, 2))
+    ref.vx[:], ref.vy[:] = v0[:, 0], v0[:, 1]
+    a = sim._engine.agents
+    import torch
+    a["vx"].copy_(torch.as_tensor(v0[:, 0])), a["vy"].copy_(torch.as_tensor(v0[:, 1]))
+    sim._engine.agents_changed()
+    for s in range(8):
+        state = np.random.get_state()
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim.step(sim.dt)
+        np.random.set_state(state)
+        ref.step()
+    st = sim._engine.get_state()
+    assert np.array_equal(st["status"].astype(bool), ref.status) and sim.inside == ref.inside
+    d = np.hypot(st["x"] - ref.x, st["y"] - ref.y)
+    assert d.max() <= 1e-5, d.max()
+    assert np.abs(st["vx"] - ref.vx).max() <= 5e-4 and np.abs(st["vy"] - ref.vy).max() <= 5e-4
+    assert min(sim.levels) >= 10            # a deep dependency graph: the schedule is doing real work
+    print("levels per step:", sim.levels)
