@@ -35,3 +35,25 @@ def test_bench_helpers():
     assert set(bench.SHARDED_BY_DEFAULT) <= set(bench.WORKLOADS)
     # a PMC summary taken with other kernel sources is never quoted
     assert bench.pmc_file("no_such_pattern_*.json") is None
+
+
+def test_the_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it"""
+    import re
+    offenders = []
+    for pkg in ("optimal_crowds_amd", "optimal_crowds", "examples"):
+        for root, _, files in os.walk(os.path.join(REPO, pkg)):
+            for f in files:
+                if f.endswith(".py"):
+                    txt = open(os.path.join(root, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b|oc_oracle|liboc_oracle", txt, re.M):
+                        offenders.append(os.path.join(root, f))
+    assert offenders == []
+    bench_src = open(os.path.join(REPO, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle import", bench_src)]
+    legs = [bench_src.rfind("\ndef ", 0, u) for u in uses]
+    names = {bench_src[l + 5:bench_src.index("(", l + 5)] for l in legs}
+    assert names <= {"cpu_baseline", "numpy_stack_baseline"}            # the baseline legs only
+    for src in ("csrc/oc_api.hip", "csrc/hjb.hip", "csrc/gcfm.hip", "csrc/density.hip", "csrc/raster.hip", "csrc/sort.hip"):
+        txt = open(os.path.join(REPO, "optimal_crowds_amd", src)).read()
+        assert not re.search(r'#include\s*[<"][^>"]*oracle|liboc_oracle|occ_', txt)      # (comments may cite the oracle)
