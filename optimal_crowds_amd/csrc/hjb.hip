@@ -1238,34 +1238,6 @@ struct Solver {
         if (mx) *mx = mb[1];
         return OC_OK;
     }
-    // after an accepted step: the `halo` owned rows next to each neighbour of y_new and K6 travel to that
-    // neighbour's halo rows (staged through the caller's contiguous buffers; rows are contiguous in memory)
-    int exchange_halo() {
-        if (!sh || !(sh->has_up || sh->has_dn)) return OC_OK;
-        const size_t hb = sizeof(T) * (size_t)sh->halo * Nx;
-        const size_t lo = (size_t)sh->own_lo * Nx, hi = (size_t)sh->own_hi * Nx, hn = (size_t)sh->halo * Nx;
-        if (sh->has_up) {
-            OC_HIP_CHECK(hipMemcpyAsync(sh->send_up, ynew + lo, hb, hipMemcpyDeviceToDevice, s));
-            OC_HIP_CHECK(hipMemcpyAsync((char*)sh->send_up + hb, K[6] + lo, hb, hipMemcpyDeviceToDevice, s));
-        }
-        if (sh->has_dn) {
-            OC_HIP_CHECK(hipMemcpyAsync(sh->send_dn, ynew + hi - hn, hb, hipMemcpyDeviceToDevice, s));
-            OC_HIP_CHECK(hipMemcpyAsync((char*)sh->send_dn + hb, K[6] + hi - hn, hb, hipMemcpyDeviceToDevice, s));
-        }
-        if (sh->exchange_halo(sh->user) != 0) {
-            oc_set_error("hjb_solve_rows: the exchange_halo callback failed");
-            return OC_ERR_STATE;
-        }
-        if (sh->has_up) {
-            OC_HIP_CHECK(hipMemcpyAsync(ynew + lo - hn, sh->recv_up, hb, hipMemcpyDeviceToDevice, s));
-            OC_HIP_CHECK(hipMemcpyAsync(K[6] + lo - hn, (char*)sh->recv_up + hb, hb, hipMemcpyDeviceToDevice, s));
-        }
-        if (sh->has_dn) {
-            OC_HIP_CHECK(hipMemcpyAsync(ynew + hi, sh->recv_dn, hb, hipMemcpyDeviceToDevice, s));
-            OC_HIP_CHECK(hipMemcpyAsync(K[6] + hi, (char*)sh->recv_dn + hb, hb, hipMemcpyDeviceToDevice, s));
-        }
-        return OC_OK;
-    }
 };
 
 template <typename T, int SG>
@@ -1804,8 +1776,6 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                 accepted = true;
                 stats.h_min = std::min(stats.h_min, std::fabs(hh));
                 stats.h_max = std::max(stats.h_max, std::fabs(hh));
-                // ---- row-block solve: refresh the halo rows of y_new and K6 (valid again `halo` rows deep)
-                if ((rc = S.exchange_halo())) return rc;
                 // ---- dense output for t_eval points in (t_new, t]  (scipy ivp.py:706-723)
                 if (use_fused) {
                     // the fused writer of the default path (k_out), its controller block filled in by the host: the
