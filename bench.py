@@ -319,9 +319,19 @@ def main():
     one_dev = os.environ.get("OC_BENCH_ONE_DEVICE") == "1"
     torch.cuda.set_device(0 if one_dev else local_rank)
     backend = "gloo" if one_dev else "nccl"
+    # OC_BENCH_FORCE_SHARDED=1 (rehearsal of the RCCL code path on a 1-GPU box): a process group of ONE rank over nccl and
+    # the sharded mode on it -- every collective of the design (the solve's all-gather, the step's all-reduce) is then
+    # issued through RCCL from the library's callbacks, on the launch stream, exactly as with N > 1
+    force_sharded = os.environ.get("OC_BENCH_FORCE_SHARDED") == "1"
+    if force_sharded and world == 1:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        tdist.init_process_group(backend, rank=0, world_size=1,
+                                 **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
     rank, world = parallel.init_distributed(backend)
     dist = None
-    if world > 1:
+    if world > 1 or force_sharded:
         import torch.distributed as dist
     red_dev = "cpu" if one_dev else "cuda"
 
@@ -329,7 +339,7 @@ def main():
     mode = args.mode
     if mode == "auto":
         mode = "sharded" if args.workload in SHARDED_BY_DEFAULT else "ensemble"
-    sharded = mode == "sharded" and world > 1
+    sharded = mode == "sharded" and (world > 1 or force_sharded)
     t_init = time.perf_counter()
     if sharded:     # one simulation on all ranks: same seed everywhere (replicated agents)
         sim, cfg = build_sim(args.workload, wall_search_radius=args.wall_radius, sharding=parallel.dist_sharding(),
@@ -397,7 +407,7 @@ def main():
                       "rk_accepted": first["n_accept"] if first else None, "kernels": kstats, "init_s": t_init,
                       "active_agents_end": int(eng.counters.cpu()[2]), "csrc_sha": csrc_hash()},
     }
-    if world > 1:
+    if world > 1 or sharded:
         sc = getattr(eng, "_step_comm", None)
         comms = [c for c in getattr(eng, "_halo_comms", {}).values() if c is not None] if sharded else []
         rowc = [c for c in comms if c.shard.world > 1]

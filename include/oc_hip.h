@@ -97,8 +97,10 @@ int oc_hjb_solve(oc_handle* h, int dtype, const void* coef, double T, int32_t nt
  * hold the rank's owned rows plus `halo` rows of each neighbour:
  *     local rows [0, own_lo)  upper halo (has_up)   [own_lo, own_hi)  owned   [own_hi, Ny_local)  lower halo (has_dn)
  * One RK step applies the 5-point stencil 6 times (5 stages + the FSAL derivative), so with y and K0 valid `halo`
- * rows deep at the start of a step, K1..K5, y_new, K6 are valid halo-1 .. halo-6 rows deep: halo >= 6 keeps the owned
- * rows exact, and the direction field is exact on the owned rows +- (halo - 6).  After every ACCEPTED step the rank
+ * rows deep at the start of a step, K1..K5, y_new, K6 are valid halo-1 .. halo-6 rows deep: that keeps the owned rows
+ * exact.  The dense output's coefficients Q = K^T P (scipy rk.py:178-180) are formed inside the stage launch, from the
+ * LOCAL K6, and the direction field of an owned row differentiates phi across the row beyond it: halo >= 7, and the
+ * direction field is exact on the owned rows +- (halo - 7).  After every ACCEPTED step the rank
  * sends its `halo` owned rows next to each neighbour of (y_new, K6) and receives the neighbour's: one message of
  * 2*halo*Nx elements per neighbour and step (instead of one row per RHS evaluation).  The error norm of an attempt
  * (scipy rk.py:146-147) is summed over owned rows and completed by an all-gather of (sum, max|y|) that every rank adds

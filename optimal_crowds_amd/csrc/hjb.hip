@@ -712,6 +712,7 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     T* KM[5];               // K1 .. K5
     const T* coef;
     T rtol, a_lap;
+    T p[6][3];              // rows 0, 2, 3, 4, 5, 6 / columns 1 .. 3 of P: the FINAL launch leaves Q1 .. Q3 for k_out
     double* partial;
     int Ny, Nx;
     int row_lo, row_hi;     // rows whose error / max|y| this launch accounts for
@@ -749,11 +750,11 @@ __device__ __forceinline__ double lane_next(double v) {
 // (halo NQ rows, and 4 ceil(NQ/4) columns so that vectors stay aligned).  The mirror ghosts of the room border
 // (optimals.py:149-152): rows -1 / Ny are extra LDS stores by the threads of rows 1 / Ny-2, columns -1 / Nx are the
 // vector's own cells 1 / 2.
-//   NQ = 3: two launches per attempt (A: K1..K3 from y, K0; B: K4, K5, y_new, K6 + error), region 128 x 32 -> tile 120 x 26
-//   NQ = 6: one launch (writes K2..K6, y_new), region 128 x 32 -> tile 112 x 20
+//   NQ = 3: two launches per attempt (A: K1..K3 from y, K0; B: Q1..Q3, y_new, K6 + error), region 128 x 32 -> tile 120 x 26
+//   NQ = 6: one launch (writes Q1..Q3, K6, y_new: 3 arrays read, 5 written), region 128 x 32 -> tile 112 x 20
 // Same arithmetic per cell as k_stage (one stage per launch, the cross-check variant): bit-identical results.
 template <typename T, int NQ, int S0, bool FINAL, int RWV, int RH>
-__global__ void __launch_bounds__(RWV * RH) k_stageV(Stage3Args<T> A) {
+__global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Stage3Args<T> A) {      // float: 64 VGPRs, two blocks per CU
     constexpr int HX = 4 * ((NQ + 3) / 4), HY = NQ, RW = 4 * RWV, NT = RWV * RH;
     constexpr int TX = RW - 2 * HX, TY = RH - 2 * HY, LS = RW + 8;
     constexpr int NK = S0 + NQ;                     // stage derivatives alive at the end of the launch
@@ -823,57 +824,79 @@ __global__ void __launch_bounds__(RWV * RH) k_stageV(Stage3Args<T> A) {
     T* const slot0 = &buf[0][ry + 1][4 + 4 * vx];
     constexpr int BUF = (RH + 2) * LS;              // elements between the two buffers
     const T2 m4 = {(T)-4, (T)-4};
+    // A wavefront holds 64 / RWV whole region rows.  Stage q's working value is only needed on rows at least q rows inside the
+    // region (the rest is edge garbage that nothing valid reads), its derivative only on rows q + 1 inside: a wavefront all of
+    // whose rows are nearer to the edge skips that part of the stage -- a wave-uniform branch; the barrier is outside it.
+    // With 2 rows per wavefront and six stages that is 18 of the 96 wavefront-stages of a block.
+    static_assert(64 % RWV == 0 && RH % (64 / RWV) == 0, "a wavefront holds whole region rows");
+    constexpr int RPW = 64 / RWV;
+    const int wr0 = (ry / RPW) * RPW;               // the wavefront's first row; its deepest row is wr0 + RPW - 1 or wr0
+    const int depth = __builtin_amdgcn_readfirstlane(max(min(wr0 + RPW - 1, RH - 1 - (wr0 + RPW - 1)), min(wr0, RH - 1 - wr0)));
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         T* const slot = slot0 + (q & 1) * BUF;
-        T2 acc0 = zero2, acc1 = zero2;
+        T lft_n = (T)0, rgt_n = (T)0;
+        if (depth >= q) {
+            T2 acc0 = zero2, acc1 = zero2;
 #pragma unroll
-        for (int j = 0; j < S0 + q; ++j) {
-            const T2 c2 = {cc[q][j], cc[q][j]};
-            acc0 = __builtin_elementwise_fma(c2, kv[j][0], acc0);
-            acc1 = __builtin_elementwise_fma(c2, kv[j][1], acc1);
+            for (int j = 0; j < S0 + q; ++j) {
+                const T2 c2 = {cc[q][j], cc[q][j]};
+                acc0 = __builtin_elementwise_fma(c2, kv[j][0], acc0);
+                acc1 = __builtin_elementwise_fma(c2, kv[j][1], acc1);
+            }
+            t[0] = yv[0] + acc0;
+            t[1] = yv[1] + acc1;
+            if (in) {
+                const V4<T> t4 = quad(t[0], t[1]);
+                st4(slot, t4);
+                if (gi == 1 && ry >= 1) st4(slot - 2 * LS, t4);                  // ghost row -1 = row 1
+                if (gi == Ny - 2 && ry + 2 <= RH - 1) st4(slot + 2 * LS, t4);   // ghost row Ny = row Ny-2
+            }
+            // left / right neighbours of the vector: the adjacent lanes' cells (a region row is RWV consecutive lanes; what
+            // crosses a row's end is region-edge garbage by construction), or the mirror cell at the room's border
+            lft_n = lane_prev(t[1].y);
+            rgt_n = lane_next(t[0].x);
         }
-        t[0] = yv[0] + acc0;
-        t[1] = yv[1] + acc1;
-        if (in) {
-            const V4<T> t4 = quad(t[0], t[1]);
-            st4(slot, t4);
-            if (gi == 1 && ry >= 1) st4(slot - 2 * LS, t4);                  // ghost row -1 = row 1
-            if (gi == Ny - 2 && ry + 2 <= RH - 1) st4(slot + 2 * LS, t4);   // ghost row Ny = row Ny-2
-        }
-        // left / right neighbours of the vector: the adjacent lanes' cells (a region row is RWV consecutive lanes; what
-        // crosses a row's end is region-edge garbage by construction), or the mirror cell at the room's border
-        const T lft_n = lane_prev(t[1].y), rgt_n = lane_next(t[0].x);
-        const T lft = (gj == 0) ? t[0].y : lft_n, rgt = (gj + 3 == Nx - 1) ? t[1].x : rgt_n;
         __syncthreads();
-        const V4<T> up = ld4(slot - LS), dn = ld4(slot + LS);
-        // hjb(t, phi, m) (rhs_value): a (N + S + W + E - 4 C) - coef C with the sum in the reference's order
-        const T2 mid = {t[0].y, t[1].x};            // right neighbours of cells 0, 1 = left neighbours of cells 2, 3
-        const T2 l0 = {lft, t[0].x}, r1 = {t[1].y, rgt};
-        T2 s0 = (((T2){up.v[0], up.v[1]} + (T2){dn.v[0], dn.v[1]}) + l0) + mid;
-        T2 s1 = (((T2){up.v[2], up.v[3]} + (T2){dn.v[2], dn.v[3]}) + mid) + r1;
-        s0 = __builtin_elementwise_fma(m4, t[0], s0);
-        s1 = __builtin_elementwise_fma(m4, t[1], s1);
-        kv[S0 + q][0] = al[0] * s0 - cf[0] * t[0];
-        kv[S0 + q][1] = al[1] * s1 - cf[1] * t[1];
+        if (depth >= q + 1) {
+            const T lft = (gj == 0) ? t[0].y : lft_n, rgt = (gj + 3 == Nx - 1) ? t[1].x : rgt_n;
+            const V4<T> up = ld4(slot - LS), dn = ld4(slot + LS);
+            // hjb(t, phi, m) (rhs_value): a (N + S + W + E - 4 C) - coef C with the sum in the reference's order
+            const T2 mid = {t[0].y, t[1].x};        // right neighbours of cells 0, 1 = left neighbours of cells 2, 3
+            const T2 l0 = {lft, t[0].x}, r1 = {t[1].y, rgt};
+            T2 s0 = (((T2){up.v[0], up.v[1]} + (T2){dn.v[0], dn.v[1]}) + l0) + mid;
+            T2 s1 = (((T2){up.v[2], up.v[3]} + (T2){dn.v[2], dn.v[3]}) + mid) + r1;
+            s0 = __builtin_elementwise_fma(m4, t[0], s0);
+            s1 = __builtin_elementwise_fma(m4, t[1], s1);
+            kv[S0 + q][0] = al[0] * s0 - cf[0] * t[0];
+            kv[S0 + q][1] = al[1] * s1 - cf[1] * t[1];
+        }
     }
     const bool store = in && ry >= HY && ry < RH - HY && vx >= HX / 4 && vx < RWV - HX / 4;
     double esum = 0.0, ymax = 0.0;
     if (store) {
-        if (NQ == 6) {                              // K2 .. K5, K6 (K1 is not needed again), y_new
-            st4(A.KM[1] + idx, quad(kv[2][0], kv[2][1]));
-            st4(A.KM[2] + idx, quad(kv[3][0], kv[3][1]));
-            st4(A.KM[3] + idx, quad(kv[4][0], kv[4][1]));
-            st4(A.KM[4] + idx, quad(kv[5][0], kv[5][1]));
-            st4(A.KX[par ^ 1] + idx, quad(kv[6][0], kv[6][1]));
-        } else if (!FINAL) {
+        if (FINAL) {
+            // What k_out needs of K0 .. K6 is the quartic interpolant's Q = K^T P (scipy rk.py:178-180).  Column 0 of P is
+            // e_0 (Q0 = K0, already in memory), row 1 is zero: the three columns Q1 .. Q3 are formed here, where every
+            // K_j of the cell is in a register, and take the place of K2 .. K5 in memory -- one array pass less for this
+            // launch, and k_out reads y + 4 arrays instead of y + 6.  (Same FMA chain as interp_coeffs: bit-identical.)
+            constexpr int rows[6] = {0, 2, 3, 4, 5, 6};
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+                T2 q0 = zero2, q1 = zero2;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const T2 p2 = {A.p[j][pp], A.p[j][pp]};
+                    q0 = __builtin_elementwise_fma(kv[rows[j]][0], p2, q0);
+                    q1 = __builtin_elementwise_fma(kv[rows[j]][1], p2, q1);
+                }
+                st4(A.KM[1 + pp] + idx, quad(q0, q1));
+            }
+            st4(A.KX[par ^ 1] + idx, quad(kv[NK - 1][0], kv[NK - 1][1]));     // K6 = the next step's K0 (FSAL)
+        } else {
             st4(A.KM[0] + idx, quad(kv[S0][0], kv[S0][1]));
             st4(A.KM[1] + idx, quad(kv[S0 + 1][0], kv[S0 + 1][1]));
             st4(A.KM[2] + idx, quad(kv[S0 + 2][0], kv[S0 + 2][1]));
-        } else {
-            st4(A.KM[3] + idx, quad(kv[S0][0], kv[S0][1]));
-            st4(A.KM[4] + idx, quad(kv[S0 + 1][0], kv[S0 + 1][1]));
-            st4(A.KX[par ^ 1] + idx, quad(kv[S0 + 2][0], kv[S0 + 2][1]));
         }
         if (FINAL) {
             st4(ynew + idx, quad(t[0], t[1]));      // the last stage's working value IS y_new
@@ -935,51 +958,56 @@ struct OutArgs {
     int Ny, Nx;
 };
 
-template <typename T>
+template <typename T, bool QIN>
 __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* const (&k)[6], const T (&P)[6][4],
-                                              T in_scale, int64_t idx, int n, T* yq, T (*Q)[4]) {
-    // n = 4: one vector of cells, n = 1: a single cell.  y and K0 (k[0]) carry the step's pending rescale (HjbCtl).
+                                              T in_scale, int64_t idx, int n, V4<T>& yq, V4<T> (&Q)[4]) {
+    // n = 4: one vector of cells, n = 1: a single cell (element 0).  y and K0 (k[0]) carry the step's pending rescale
+    // (HjbCtl).  Q[pp].v[q]: coefficient pp of cell q.
+    // QIN: k = {K0, Q1, Q2, Q3} -- the stage launch (k_stageV) already formed the columns of Q = K^T P (Q0 = K0);
+    // otherwise k = {K0, K2 .. K6} (the host-controlled cross-check variants) and Q is formed here, by the same FMAs.
+    constexpr int NA = QIN ? 4 : 6;
+    V4<T> kk[NA];
     if (n == 4) {
-        V4<T> yv = ld4(y + idx), kk[6];
+        yq = ld4(y + idx);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) kk[j] = ld4(k[j] + idx);
+        for (int j = 0; j < NA; ++j) kk[j] = ld4(k[j] + idx);
+    } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            yv.v[q] *= in_scale;
-            kk[0].v[q] *= in_scale;
+        for (int q = 0; q < 4; ++q) yq.v[q] = (T)0;
+        yq.v[0] = y[idx];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kk[j].v[q] = (T)0;
+            kk[j].v[0] = k[j][idx];
         }
+    }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            yq[q] = yv.v[q];
+    for (int q = 0; q < 4; ++q) {
+        yq.v[q] *= in_scale;
+        kk[0].v[q] *= in_scale;
+    }
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
+    for (int pp = 0; pp < 4; ++pp) {
+        if (QIN) {
+            Q[pp] = kk[pp];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
                 T acc = (T)0;
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc = fma_t(kk[j].v[q], P[j][pp], acc);
-                Q[q][pp] = acc;
+                Q[pp].v[q] = acc;
             }
-        }
-    } else {
-        yq[0] = y[idx] * in_scale;
-        T kk[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) kk[j] = k[j][idx];
-        kk[0] *= in_scale;
-#pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-            T acc = (T)0;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) acc = fma_t(kk[j], P[j][pp], acc);
-            Q[0][pp] = acc;
         }
     }
 }
 
 // Tile = OX x OY cells with OX * OY = 1024 (256 threads x 4 consecutive cells of a row): 64 x 16, 128 x 8 or 256 x 4.  A
 // wider tile writes longer contiguous runs per row and slice (1 KB at 256 instead of 256 B), which is what counts where
-// the seven input arrays no longer come out of the Infinity Cache (4096 x 4096).
-template <typename T, int OX, typename TO>
-__global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves per SIMD: at most 128 VGPRs
+// the input arrays no longer come out of the Infinity Cache (4096 x 4096).
+template <typename T, int OX, typename TO, bool QIN>
+__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> A) {      // float: 4 waves per SIMD (at most 128 VGPRs)
     constexpr int OY = 1024 / OX, VW = OX / 4, OLS = OX + 8;
     __shared__ alignas(16) T tile[2][OY + 2][OLS];
     const HjbCtl<T>* __restrict__ ctl = A.ctl;
@@ -990,7 +1018,8 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
     const T lim_s = ctl->out_lim_s, in_scale = ctl->out_in_scale;
     const int n_hx = ctl->n_hx;
     const T* __restrict__ y = A.Y[par];
-    const T* const kk[6] = {A.KX[par], A.KM[1], A.KM[2], A.KM[3], A.KM[4], A.KX[par ^ 1]};     // K0, K2 .. K5, K6
+    // K0, Q1 .. Q3 (left by k_stageV in the place of K2 .. K4)  /  K0, K2 .. K5, K6
+    const T* const kk[6] = {A.KX[par], A.KM[1], A.KM[2], A.KM[3], QIN ? nullptr : A.KM[4], QIN ? nullptr : A.KX[par ^ 1]};
     const int cx = (int)threadIdx.x % VW, ry = (int)threadIdx.x / VW;
     const int Ny = A.Ny, Nx = A.Nx;
     const int nbx = (Nx + OX - 1) / OX, nby = (Ny + OY - 1) / OY, nb = nbx * nby;
@@ -1002,8 +1031,8 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
     const bool valid = gi < Ny && gj < Nx;
     const int64_t idx = (int64_t)gi * Nx + gj;
     const int64_t ncell = (int64_t)Ny * Nx;
-    T yq[4], Q[4][4], hy[4], hQ[4][4];
-    if (valid) interp_coeffs<T>(y, kk, A.p, in_scale, idx, 4, yq, Q);
+    V4<T> yq, Q[4], hy, hQ[4];
+    if (valid) interp_coeffs<T, QIN>(y, kk, A.p, in_scale, idx, 4, yq, Q);
     // halo of the tile: threads 0 .. VW-1 the row above (a vector each), the next VW the row below, then OY threads the
     // column to the left and OY the column to the right (a cell each); cells outside the grid are never used
     HaloRole hr;
@@ -1018,7 +1047,7 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
         if (!(hr.gi >= 0 && hr.gi < Ny && hr.gj >= 0 && hr.gj < Nx)) hr.kind = 0;
     }
     const int hn = (hr.kind == 1 || hr.kind == 2) ? 4 : (hr.kind >= 3 ? 1 : 0);
-    if (hn) interp_coeffs<T>(y, kk, A.p, in_scale, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
+    if (hn) interp_coeffs<T, QIN>(y, kk, A.p, in_scale, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
     auto clip = [&](T v) { return (v > lim_s) ? v : ((v < lim_s) ? lim_s : (T)0); };
     // the controller's per-slice factors: fetched once (a load from the controller block inside the slice loop would
     // put a memory round trip into every slice)
@@ -1065,7 +1094,7 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
             V4<T> ph;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                ph.v[q] = yq[q] + fma_t(Q[q][3], h4, fma_t(Q[q][2], h3, fma_t(Q[q][1], h2, Q[q][0] * h1)));
+                ph.v[q] = yq.v[q] + fma_t(Q[3].v[q], h4, fma_t(Q[2].v[q], h3, fma_t(Q[1].v[q], h2, Q[0].v[q] * h1)));
                 pcl.v[q] = clip(ph.v[q]);
             }
             st4(&tile[buf][ry + 1][4 + 4 * cx], pcl);
@@ -1078,10 +1107,10 @@ __global__ void __launch_bounds__(256, 4) k_out(OutArgs<T> A) {      // 4 waves 
             V4<T> hp;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                hp.v[q] = clip(hy[q] + fma_t(hQ[q][3], h4, fma_t(hQ[q][2], h3, fma_t(hQ[q][1], h2, hQ[q][0] * h1))));
+                hp.v[q] = clip(hy.v[q] + fma_t(hQ[3].v[q], h4, fma_t(hQ[2].v[q], h3, fma_t(hQ[1].v[q], h2, hQ[0].v[q] * h1))));
             st4(&tile[buf][hr.li][hr.lj], hp);
         } else if (hn == 1) {
-            tile[buf][hr.li][hr.lj] = clip(hy[0] + fma_t(hQ[0][3], h4, fma_t(hQ[0][2], h3, fma_t(hQ[0][1], h2, hQ[0][0] * h1))));
+            tile[buf][hr.li][hr.lj] = clip(hy.v[0] + fma_t(hQ[3].v[0], h4, fma_t(hQ[2].v[0], h3, fma_t(hQ[1].v[0], h2, hQ[0].v[0] * h1))));
         }
         // left / right neighbours of the vector: the adjacent lanes (DPP wave shifts; as LDS scalars at a 16-byte stride
         // they were 4-way bank-conflicted), the tile's halo columns for the first and the last vector of a row
@@ -1136,18 +1165,18 @@ __global__ void k_halo_stage(const HjbCtl<T>* __restrict__ ctl, T* Y0, T* Y1, T*
 }
 
 // ------------------------------------------------------------------------------------------ host side
-// k_out's tile: 128 x 8 cells while the step's seven input arrays fit the 256 MB Infinity Cache (C4: 6.18 TB/s against 5.69
+// k_out's tile: 128 x 8 cells while the step's input arrays fit the 256 MB Infinity Cache (C4: 6.18 TB/s against 5.69
 // with 64 x 16 and 6.04 with 256 x 4), 256 x 4 beyond (C5, 4096 x 4096: 5.44 TB/s against 4.59 / 5.11) -- or the caller's
-// choice (oc_set_tuning "out_tile")
-template <typename T, typename TO>
+// choice (oc_set_tuning "out_tile").  QIN: the stage launch left Q1 .. Q3 (the product path); false: K2 .. K6.
+template <typename T, typename TO, bool QIN>
 void launch_out(int shape, int Nx, int Ny, hipStream_t s, const OutArgs<T>& OA) {
-    if (shape < 0) shape = (7.0 * sizeof(T) * (double)Nx * Ny > 256e6) ? 2 : 1;
+    if (shape < 0) shape = (5.0 * sizeof(T) * (double)Nx * Ny > 256e6) ? 2 : 1;
     const int ox = shape == 2 ? 256 : (shape == 1 ? 128 : 64), oy = 1024 / ox;
     const int nb = ((Nx + ox - 1) / ox) * ((Ny + oy - 1) / oy);
     const dim3 grid(8 * ((nb + 7) / 8));
-    if (shape == 2) hipLaunchKernelGGL((k_out<T, 256, TO>), grid, dim3(256), 0, s, OA);
-    else if (shape == 1) hipLaunchKernelGGL((k_out<T, 128, TO>), grid, dim3(256), 0, s, OA);
-    else hipLaunchKernelGGL((k_out<T, 64, TO>), grid, dim3(256), 0, s, OA);
+    if (shape == 2) hipLaunchKernelGGL((k_out<T, 256, TO, QIN>), grid, dim3(256), 0, s, OA);
+    else if (shape == 1) hipLaunchKernelGGL((k_out<T, 128, TO, QIN>), grid, dim3(256), 0, s, OA);
+    else hipLaunchKernelGGL((k_out<T, 64, TO, QIN>), grid, dim3(256), 0, s, OA);
 }
 
 template <typename T>
@@ -1410,6 +1439,11 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     SA.coef = S.coef;
     SA.rtol = (T)rtol;
     SA.a_lap = S.a_lap;
+    {
+        const int rows[6] = {0, 2, 3, 4, 5, 6};
+        for (int q = 0; q < 6; ++q)
+            for (int pp = 0; pp < 3; ++pp) SA.p[q][pp] = (T)RK_P[rows[q]][pp + 1];
+    }
     SA.partial = h->red_partial;
     SA.Ny = S.Ny;
     SA.Nx = S.Nx;
@@ -1504,7 +1538,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                                (T*)sh->recv_up, (T*)sh->recv_dn, lo, hi, hn, sh->has_up, sh->has_dn);
         }
         if (prof) event();
-        launch_out<T, TO>(h->out_tile, S.Nx, S.Ny, s, OA);
+        launch_out<T, TO, true>(h->out_tile, S.Nx, S.Ny, s, OA);
         if (prof) event();
         ++enq;
         return OC_OK;
@@ -1565,16 +1599,16 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             float e1 = 0.f, e2 = 0.f;
             (void)hipEventElapsedTime(&e1, ev[4 * g], ev[4 * g + 1]);
             (void)hipEventElapsedTime(&e2, ev[4 * g + 2], ev[4 * g + 3]);
-            if (log[a] & 1) {           // a real attempt: 9 array passes in one launch (two launches: 6 + 10)
+            if (log[a] & 1) {           // a real attempt: 8 array passes in one launch (two launches: 6 + 11)
                 ts.add_ms += e1;
                 ts.add_n += 1;
-                ts.bytes += (fuse == 0 ? 9.0 : 16.0) * sizeof(T) * (double)n;
+                ts.bytes += (fuse == 0 ? 8.0 : 17.0) * sizeof(T) * (double)n;
             }
-            if (log[a] & 2) {           // accepted: k_out read y + 6 stage arrays once, wrote 2 components per slice
+            if (log[a] & 2) {           // accepted: k_out read y, K0, Q1 .. Q3 once, wrote 2 components per slice
                 const int nv = log[a] >> 8;
                 to.add_ms += e2;
                 to.add_n += 1;
-                to.bytes += sizeof(T) * 7.0 * (double)n + sizeof(TO) * 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2);
+                to.bytes += sizeof(T) * 5.0 * (double)n + sizeof(TO) * 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2);
             }
         }
     }
@@ -1829,7 +1863,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                     OA.Ny = S.Ny;
                     OA.Nx = S.Nx;
                     oc_timer_begin(h, "hjb_out", s);
-                    launch_out<T, T>(h->out_tile, S.Nx, S.Ny, s, OA);
+                    launch_out<T, T, false>(h->out_tile, S.Nx, S.Ny, s, OA);
                     oc_timer_end(h, "hjb_out", s, sizeof(T) * (7.0 * (double)n + 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2)));
                     stats.n_slices_written += nv;
                     // (the pinned block is rewritten only after the next attempt's reduction has been read: copy done)
@@ -1991,7 +2025,7 @@ extern "C" int oc_hjb_solve_rows(oc_handle* h, int dtype, const void* coef_rows,
     OC_REQUIRE(nt <= 1 || (vx_out && vy_out), "null output field");
     OC_REQUIRE(n_keep == 0 || (keep_idx && phi_keep), "keep list without buffer");
     OC_REQUIRE(sh->world >= 1 && sh->world <= OC_MAX_WORLD, "bad world size");
-    OC_REQUIRE(sh->halo >= 6, "halo must cover the 6 stencil applications of one RK step");
+    OC_REQUIRE(sh->halo >= 7, "halo must cover the 6 stencil applications of one RK step + the row of K6 the output reads");
     OC_REQUIRE(sh->own_lo == (sh->has_up ? sh->halo : 0), "own_lo must equal the upper halo depth");
     OC_REQUIRE(sh->own_hi > sh->own_lo && sh->Ny_local == sh->own_hi + (sh->has_dn ? sh->halo : 0), "bad row window");
     OC_REQUIRE(!(sh->has_up || sh->has_dn) || sh->own_hi - sh->own_lo >= sh->halo, "owned block thinner than the halo");

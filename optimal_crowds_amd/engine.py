@@ -177,7 +177,7 @@ class Engine:
         comms = halo_comm if isinstance(halo_comm, dict) else {k: halo_comm for k in range(self.n_keys)}
         for c in comms.values():
             if c is not None and c.shard.world > 1 and c.shard.field_margin < 1:
-                raise ValueError("sharded lookups need halo >= 7")
+                raise ValueError("sharded lookups need halo >= 8")
         # per key: the communicator of the rank group that solves it (keys first, then row blocks: parallel
         # .key_row_plan), or None when this rank holds no part of that key's field
         self._halo_comms, self._step_comm = comms, step_comm
@@ -308,7 +308,7 @@ class Engine:
         this rank answers the lookups whose first cell lies in the rows it owns (oc_set_field_rows)."""
         if shard.world > 1 and shard.field_margin < 1:
             raise ValueError("a lookup's second cell may lie one row beyond the owned rows: the row block needs "
-                             "halo >= 7 (the field is exact halo - 6 rows beyond the block)")
+                             "halo >= 8 (the field is exact halo - 7 rows beyond the block)")
         nslice = int(vx.shape[0])
         self.fields[key] = [vx, vy, nslice, int(nt)]
         check(self.lib.oc_set_field_rows(self.h, key, self.field_dtype, _ptr(vx), _ptr(vy), nslice, int(nt), int(shard.row0),

@@ -79,11 +79,12 @@ def row_blocks(Ny, world):
 # ---------------------------------------------------------------------------------------------- row-block HJB solve
 class RowShard:
     """One rank's row block of the (Ny, Nx) grid plus `halo` rows of each neighbour (oc_hip.h: oc_hjb_shard).
-    halo >= 6 (one RK step applies the stencil 6 times); the direction field is exact on owned rows +- (halo - 6)."""
+    halo >= 7 (one RK step applies the stencil 6 times, and the interpolant's coefficients are formed from the LOCAL K6 one
+    row beyond the block); the direction field is exact on owned rows +- (halo - 7)."""
 
     def __init__(self, Ny, rank, world, halo=8):
         r0, r1 = row_blocks(Ny, world)[rank]
-        if world > 1 and (halo < 6 or Ny // world < halo):
+        if world > 1 and (halo < 7 or Ny // world < halo):
             raise ValueError("row blocks of %d rows cannot carry a halo of %d rows" % (Ny // world, halo))
         self.Ny, self.rank, self.world, self.halo = Ny, rank, world, halo
         self.has_up, self.has_dn = rank > 0, rank < world - 1
@@ -92,7 +93,7 @@ class RowShard:
         self.own_lo = halo if self.has_up else 0
         self.own_hi = self.own_lo + (r1 - r0)
         self.Ny_local = self.own_hi + (halo if self.has_dn else 0)
-        self.field_margin = halo - 6                                # rows beyond the block where the field is exact
+        self.field_margin = halo - 7                                # rows beyond the block where the field is exact
 
     def rows(self):
         """slice of the global grid rows held locally (owned + halo)"""

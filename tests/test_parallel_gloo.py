@@ -199,7 +199,7 @@ def _rows_worker(rank, world, port, q):
     m = rng.rand(Ny, Nx)
     hp = oc.DEFAULT_CONFIG["hjb_params"]
     T, nt = 1.0, 11
-    sh = parallel.RowShard(Ny, rank, world, halo=6)
+    sh = parallel.RowShard(Ny, rank, world, halo=7)
     comm = parallel.DistHaloComm(sh, Nx, torch.float64, "cpu")
     out, n_att, n_acc = _rows_model_solve(oc, comm, V[sh.rows()], m[sh.rows()], hp, dx, T, nt, Ny * Nx)
     ys, st = oc.rk45_solve(lambda t, y: oc.hjb_rhs(y, V, m, hp["sigma"], hp["mu"], hp["g"], dx, dx), T, 0.0,
@@ -234,7 +234,7 @@ def test_wide_halo_row_block_rk45_world2():
 def test_row_shard_geometry():
     from optimal_crowds_amd import parallel
     import pytest
-    for Ny, world, halo in ((2048, 8, 8), (4096, 8, 16), (100, 3, 6)):
+    for Ny, world, halo in ((2048, 8, 8), (4096, 8, 16), (100, 3, 7)):
         prev = None
         for r in range(world):
             s = parallel.RowShard(Ny, r, world, halo)
@@ -247,7 +247,9 @@ def test_row_shard_geometry():
             prev = s
         assert prev.g1 == Ny
     with pytest.raises(ValueError):
-        parallel.RowShard(40, 0, 8, 6)
+        parallel.RowShard(40, 0, 8, 7)              # blocks of 5 rows cannot carry the halo
+    with pytest.raises(ValueError):
+        parallel.RowShard(2048, 0, 8, 6)            # the output reads the local K6 one row beyond the block: halo >= 7
 
 
 # ------------------------------------------------------------------------------------------------ sharded-step plumbing
@@ -268,7 +270,7 @@ def _step_comm_worker(rank, world, port, q):
     other = torch.zeros(4, dtype=torch.float64)
     rc2 = comm._cb(None, other.data_ptr(), 4)
     refused = rc2 == -1 and isinstance(comm.error, AssertionError)
-    # row-block geometry the sharded lookup relies on: the owned rows tile the grid, halo >= 7 leaves a margin row
+    # row-block geometry the sharded lookup relies on: the owned rows tile the grid, halo >= 8 leaves a margin row
     sh = parallel.RowShard(64, rank, world, halo=8)
     q.put((rank, ok, refused, (sh.g0, sh.g1, sh.row0, sh.Ny_local, sh.field_margin)))
     dist.barrier()
@@ -286,4 +288,4 @@ def test_step_comm_and_row_shards_world2_gloo():
     assert all(r[1] and r[2] for r in res)
     (g0a, g1a, row0a, nla, mga), (g0b, g1b, row0b, nlb, mgb) = res[0][3], res[1][3]
     assert (g0a, g1a, g0b, g1b) == (0, 32, 32, 64)
-    assert (row0a, nla) == (0, 40) and (row0b, nlb) == (24, 40) and mga == mgb == 2
+    assert (row0a, nla) == (0, 40) and (row0b, nlb) == (24, 40) and mga == mgb == 1
