@@ -60,6 +60,7 @@ struct HjbCtl {
     double hh, t_new;                   // the attempt about to run: step and its end time
     double out_t, out_hh, out_unscale;  // the step just accepted (k_out): its start, length and 2^expo
     double h_min, h_max;
+    double act_sum;                     // stage tiles with a non-zero error share, summed over the attempts (active-set statistics)
     int32_t nt, k_next;                 // t_eval = linspace(T, 0, nt); next index to emit
     int32_t parity;                     // y = Y[parity], y_new = Y[1 - parity], K0 = KX[parity], K6 = KX[1 - parity]
     int32_t expo;                       // state = phi * 2^-expo
@@ -72,6 +73,8 @@ struct HjbCtl {
     // in memory as they are and the NEXT step multiplies them by `in_scale` (an exact power of two) as it loads them
     // -- as y and K0, in its stage launches and in its k_out -- so everything it writes is in the new scale.
     T in_scale, out_in_scale;
+    T u_bg;                             // active set: the far field's value of y in the current y buffer (a power of two)
+    int32_t work_count;                 // active set: tiles the next stage launch has to look at (work list, k_control)
     int32_t n_hx;                       // k_out's per-slice factors h x, h x^2, h x^3, h x^4 (0: more than HJB_MAXS slices,
     T hx[HJB_MAXS][4];                  // computed in the kernel)
 };
@@ -339,13 +342,16 @@ __global__ void __launch_bounds__(1024) k_reduce_final(const double* __restrict_
 // mailbox (pinned host memory): ONE word = ticks (control launches so far) + 2^32 * done -- a single store, so the host
 // never sees a torn pair and the kernel needs no system-scope fence.
 template <typename T>
-__global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, const double* __restrict__ parts,
+__global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, const double* parts,
                                                  int nparts, double* __restrict__ t_steps, int t_cap,
-                                                 int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox) {
+                                                 int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox,
+                                                 const int32_t* __restrict__ flags_cur = nullptr,
+                                                 int32_t* __restrict__ flags_next = nullptr, int32_t* __restrict__ work = nullptr,
+                                                 double* parts_rw = nullptr, int tnbx = 0, int tnby = 0) {
     // the controller block is worked on in LDS (one coalesced load, one coalesced store): thread 0's serial code would
     // otherwise pay a memory round trip for every field it touches
     __shared__ HjbCtl<T> c;
-    __shared__ double ls[4], lm[4];
+    __shared__ double ls[4], lm[4], la[4];
     constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
     static_assert(sizeof(HjbCtl<T>) % 4 == 0, "controller block must be a whole number of words");
     {
@@ -354,8 +360,8 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
         for (int i = threadIdx.x; i < NW32; i += blockDim.x) dst[i] = src[i];
     }
     // the attempt's error sums (issued together with the block's load; unused if the solve is over)
-    const double2* __restrict__ p2 = reinterpret_cast<const double2*>(parts);
-    double s = 0.0, m = 0.0;
+    const double2* p2 = reinterpret_cast<const double2*>(parts);
+    double s = 0.0, m = 0.0, na = 0.0;
     const int nth = blockDim.x;
     for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * nth) {
         double2 v[4];
@@ -365,13 +371,16 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
         for (int u = 0; u < 4; ++u) {
             s += v[u].x;
             m = fmax(m, v[u].y);
+            na += v[u].x > 0.0 ? 1.0 : 0.0;
         }
     }
     s = wave_sum(s);
     m = wave_max(m);
+    na = wave_sum(na);
     if ((threadIdx.x & 63) == 0) {
         ls[threadIdx.x >> 6] = s;
         lm[threadIdx.x >> 6] = m;
+        la[threadIdx.x >> 6] = na;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -381,9 +390,12 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
             c.do_scale = 0;
         } else {
             double esum = 0.0, ymax = 0.0;
+            // (active set: tiles off the work list took no part in the launch -- their share is 0 and the far field's u)
+            if (work != nullptr && c.work_count < nparts) ymax = fabs((double)c.u_bg * (double)c.in_scale);
             for (int q = 0; q < (nth + 63) / 64; ++q) {
                 esum += ls[q];
                 ymax = fmax(ymax, lm[q]);
+                c.act_sum += la[q];
             }
             const double err = sqrt(esum) / sqrt(c.n_rms);
             ++c.n_attempt;
@@ -416,6 +428,7 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
                 c.k_hi = c.k_next;
                 c.n_hx = (c.k_hi - c.k_lo <= HJB_MAXS) ? c.k_hi - c.k_lo : 0;      // (table: the lanes, below)
                 c.out_in_scale = c.in_scale;
+                c.u_bg *= c.in_scale;               // what the far field reads in the buffer that is y from now on
                 c.in_scale = (T)1;
                 c.t = c.t_new;
                 ++c.n_accept;
@@ -454,6 +467,70 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
             c.hx[q][pp] = (T)(c.out_hh * xp);
             xp *= x;
         }
+    }
+    // ---- active set: the next attempt's work list.  A tile that was trivial in the attempt just run, with all 8 neighbours,
+    // is trivial in the next one whatever the decision was; if the target buffers hold the trivial values already (the attempt
+    // was rejected, or no rescale lies between the buffers) it needs no block at all: flag and error share are set here.
+    if (work != nullptr && !c.done) {
+        constexpr int MAXT = 16384;                 // tiles whose flags fit the LDS copy (4096 x 4096: 7 585); more: list all
+        __shared__ uint8_t sflag[MAXT], srow[MAXT];
+        __shared__ int32_t wsum[4];
+        const int ntile = tnbx * tnby;
+        const bool skip_ok = (c.rejected != 0 || (c.in_scale == (T)1 && c.out_in_scale == (T)1)) && ntile <= MAXT;
+        // every thread owns a contiguous run of tiles (an ordered list keeps neighbouring tiles in neighbouring blocks)
+        const int per_thr = (ntile + nth - 1) / nth, t_lo = min((int)threadIdx.x * per_thr, ntile), t_hi = min(t_lo + per_thr, ntile);
+        uint32_t listed = 0xFFFFFFFFu;              // bit q: tile t_lo + q goes on the list (per_thr <= 32: MAXT / 256 = 64 -> two words)
+        uint32_t listed_hi = 0xFFFFFFFFu;
+        if (skip_ok) {
+            for (int t = threadIdx.x; t < ntile; t += nth) sflag[t] = flags_cur[t] != 0 ? 1 : 0;
+            __syncthreads();
+            // trivial with all 8 neighbours = AND over the row triple of the AND over the column triple (two passes)
+            int bj = t_lo % tnbx;
+            for (int t = t_lo; t < t_hi; ++t) {
+                const uint8_t l = bj > 0 ? sflag[t - 1] : (uint8_t)1, r = bj < tnbx - 1 ? sflag[t + 1] : (uint8_t)1;
+                srow[t] = sflag[t] & l & r;
+                bj = bj + 1 == tnbx ? 0 : bj + 1;
+            }
+            __syncthreads();
+            for (int t = t_lo; t < t_hi; ++t) {
+                const uint8_t u = t >= tnbx ? srow[t - tnbx] : (uint8_t)1, d = t + tnbx < ntile ? srow[t + tnbx] : (uint8_t)1;
+                const bool quiet = (srow[t] & u & d) != 0;
+                const int q = t - t_lo;
+                if (quiet) {
+                    if (q < 32) listed &= ~(1u << q);
+                    else listed_hi &= ~(1u << (q - 32));
+                }
+            }
+        }
+        const int nmine = t_hi - t_lo;
+        const uint32_t m_lo = nmine >= 32 ? 0xFFFFFFFFu : ((1u << max(nmine, 0)) - 1u);
+        const uint32_t m_hi = nmine >= 64 ? 0xFFFFFFFFu : (nmine > 32 ? ((1u << (nmine - 32)) - 1u) : 0u);
+        listed &= m_lo;
+        listed_hi &= m_hi;
+        const int mine = __popc(listed) + __popc(listed_hi);
+        int incl = mine;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int off = incl - mine;
+        for (int q = 0; q < wv; ++q) off += wsum[q];
+        for (int t = t_lo; t < t_hi; ++t) {
+            const int q = t - t_lo;
+            const bool on = q < 32 ? ((listed >> q) & 1u) != 0 : ((listed_hi >> (q - 32)) & 1u) != 0;
+            if (on) {
+                work[off++] = t;
+            } else {
+                flags_next[t] = 1;
+                parts_rw[2 * t] = 0.0;
+                parts_rw[2 * t + 1] = 0.0;
+            }
+        }
+        if (threadIdx.x == 0) c.work_count = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
     __syncthreads();
     {
@@ -716,6 +793,10 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     double* partial;
     int Ny, Nx;
     int row_lo, row_hi;     // rows whose error / max|y| this launch accounts for
+    // exact active set (k_stageV below): per tile 1 = trivial at that attempt, 0 = computed; NULL = every tile is computed
+    const int32_t* flags_prev;      // the previous attempt's flags (NULL at the first attempt)
+    int32_t* flags_cur;
+    const int32_t* work;            // the attempt's work list (ctl->work_count tiles, built by k_control), or NULL
 };
 
 // value of the previous / next lane of the wavefront (DPP wave shifts: no LDS traffic; lane 0 / 63 get 0)
@@ -736,6 +817,16 @@ __device__ __forceinline__ double lane_next(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xf, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xf, 0xf, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// a finite non-zero power of two (sums 2u, 3u, 4u of such a value are exact: the active-set argument of k_stageV)
+__device__ __forceinline__ bool is_pow2(float v) {
+    const uint32_t b = __float_as_uint(v), e = (b >> 23) & 0xFFu;
+    return (b & 0x007FFFFFu) == 0u && e != 0u && e != 0xFFu;
+}
+__device__ __forceinline__ bool is_pow2(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v), e = (b >> 52) & 0x7FFull;
+    return (b & 0x000FFFFFFFFFFFFFull) == 0ull && e != 0ull && e != 0x7FFull;
 }
 
 // ---- lean multi-stage kernel: four cells of a row per thread, no per-cell index arithmetic ------------------------
@@ -780,8 +871,12 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     const int Ny = A.Ny, Nx = A.Nx;
     const int nbx = (Nx + TX - 1) / TX, nby = (Ny + TY - 1) / TY, nb = nbx * nby;
     const int per = (nb + 7) / 8;
-    const int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);        // XCD-aware order (tile_of_block)
+    int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);              // XCD-aware order (tile_of_block)
     if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
+    if (NQ == 6 && A.work != nullptr) {             // active set: entry `logical` of the work list, or nothing to do
+        if (logical >= ctl->work_count) return;
+        logical = A.work[logical];
+    }
     const int vx = (int)threadIdx.x % RWV, ry = (int)threadIdx.x / RWV;
     const int gi = (logical / nbx) * TY - HY + ry, gj = (logical % nbx) * TX - HX + 4 * vx;
     const bool in = gi >= 0 && gi < Ny && gj >= 0 && gj < Nx;      // (Nx % 4 == 0: a vector is inside or outside as a whole)
@@ -798,8 +893,33 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
 #pragma unroll                                      // coefficients once: a wall cell evaluates 0 * sum - 0 * C = 0 in every
         for (int j = 0; j < NK; ++j) kv[j][p] = zero2;      // stage, without a compare and a select per stage
     }
+    // ---- the exact active set.  A tile is TRIVIAL when on its whole region (tile + halo) y is one and the same power of
+    // two u, K0 = 0 and coef = 0 or wall: then every stage evaluates a (4u - 4u) - 0 u = 0 exactly, so K1..K6 = 0, Q = 0,
+    // y_new = u, error share 0, max|y_new| = u -- the block writes that (or finds it already written) without computing
+    // anything.  With m = 0 that is the whole far field: phi stays exactly 1 until the stencil has carried the targets'
+    // influence there, 6 cells per step (C4: 4 % of the tiles are non-trivial on average over a solve, 10 % at its end).
+    // Results are bit-identical to computing every tile (tests/test_hip_active_set.py).
+    //   flags (per tile and attempt: 1 trivial, 0 computed).  A tile that was trivial together with its 8 neighbours is
+    //   trivial in the next attempt too (their outputs cover its region; a rejected attempt leaves the state as it was):
+    //   k_control leaves such tiles off the next attempt's WORK LIST, and the launch's blocks beyond the list exit at once;
+    //   a listed tile loads its region and tests it.  Its stores are skipped when the target buffers already hold the
+    //   trivial values: it was trivial at the previous attempt and no rescale separates the buffers' scales.
+    bool trivial = false, own_prev = false;
+    T u_raw = (T)0;
+    const bool track = (NQ == 6) && A.flags_cur != nullptr;
+    const int bi = logical / nbx, bj = logical % nbx;
+    if (track) {
+        u_raw = y[(int64_t)(bi * TY) * Nx + bj * TX];       // (uniform address: the tile's first cell)
+        own_prev = A.flags_prev != nullptr && A.flags_prev[logical] != 0;
+    }
+    bool cell_trivial = true;
     if (in) {
         const V4<T> y4 = ld4(y + idx), c4 = ld4(A.coef + idx);
+        if (track) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                cell_trivial = cell_trivial && y4.v[q] == u_raw && (c4.v[q] == (T)0 || c4.v[q] != c4.v[q]);
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             yv[p] = (T2){y4.v[2 * p], y4.v[2 * p + 1]} * (T2){in_scale, in_scale};      // (1 unless the previous step
@@ -812,6 +932,10 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             const V4<T> k4 = ld4(kin[j] + idx);
             kv[j][0] = (T2){k4.v[0], k4.v[1]};
             kv[j][1] = (T2){k4.v[2], k4.v[3]};
+            if (track && j == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cell_trivial = cell_trivial && k4.v[q] == (T)0;
+            }
         }
         kv[0][0] *= (T2){in_scale, in_scale};
         kv[0][1] *= (T2){in_scale, in_scale};
@@ -821,6 +945,34 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
         return r;
     };
+    if (track) {
+        trivial = __syncthreads_and((cell_trivial && is_pow2(u_raw)) ? 1 : 0) != 0;
+        if (trivial) {
+            const T un = u_raw * in_scale;
+            const bool can_skip = own_prev && (ctl->rejected != 0 || (in_scale == (T)1 && ctl->out_in_scale == (T)1));
+            if (!can_skip && in && ry >= HY && ry < RH - HY && vx >= HX / 4 && vx < RWV - HX / 4) {
+                V4<T> z, uu;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    z.v[q] = (T)0;
+                    uu.v[q] = un;
+                }
+                st4(A.KM[1] + idx, z);
+                st4(A.KM[2] + idx, z);
+                st4(A.KM[3] + idx, z);
+                st4(A.KX[par ^ 1] + idx, z);
+                st4(ynew + idx, uu);
+            }
+            if (threadIdx.x == 0) {
+                const int r_lo = bi * TY, r_hi = min(r_lo + TY, Ny);
+                A.partial[2 * logical] = 0.0;
+                A.partial[2 * logical + 1] = (r_hi > A.row_lo && r_lo < A.row_hi) ? (double)fabs(un) : 0.0;
+                A.flags_cur[logical] = 1;
+            }
+            return;
+        }
+        if (threadIdx.x == 0) A.flags_cur[logical] = 0;
+    }
     T* const slot0 = &buf[0][ry + 1][4 + 4 * vx];
     constexpr int BUF = (RH + 2) * LS;              // elements between the two buffers
     const T2 m4 = {(T)-4, (T)-4};
@@ -956,6 +1108,8 @@ struct OutArgs {
     const int32_t* keep_slot;
     T lim, mu, inv2dx, inv2dy;
     int Ny, Nx;
+    const int32_t* flags;   // the accepted attempt's stage-tile flags (stx x sty cells per tile), or NULL
+    int stx, sty;
 };
 
 template <typename T, bool QIN>
@@ -1031,6 +1185,29 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> 
     const bool valid = gi < Ny && gj < Nx;
     const int64_t idx = (int64_t)gi * Nx + gj;
     const int64_t ncell = (int64_t)Ny * Nx;
+    // the exact active set (k_stageV): where every stage tile under this tile and its one-cell ring was trivial in the
+    // accepted attempt, phi(t) is one constant there for every t of the step -- central differences 0, direction 0 -- and
+    // the slices are written as zeros without reading or computing anything (the audit output `keep` takes the full path)
+    if (A.flags != nullptr && A.keep_slot == nullptr) {
+        const int snbx = (Nx + A.stx - 1) / A.stx;
+        const int r0 = max(i0 - 1, 0) / A.sty, r1 = min(i0 + OY, Ny - 1) / A.sty;
+        const int c0 = max(j0 - 1, 0) / A.stx, c1 = min(j0 + OX, Nx - 1) / A.stx;
+        bool triv = true;
+        for (int r = r0; r <= r1; ++r)
+            for (int c = c0; c <= c1; ++c) triv = triv && A.flags[r * snbx + c] != 0;
+        if (triv) {
+            if (valid) {
+                V4<TO> z;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z.v[q] = (TO)0;
+                for (int k = max(k_lo, 1); k < k_hi; ++k) {
+                    st4_nt((TO*)A.vx_base + (size_t)(nt - 1 - k) * A.slice_elems + idx, z);
+                    st4_nt((TO*)A.vy_base + (size_t)(nt - 1 - k) * A.slice_elems + idx, z);
+                }
+            }
+            return;
+        }
+    }
     V4<T> yq, Q[4], hy, hQ[4];
     if (valid) interp_coeffs<T, QIN>(y, kk, A.p, in_scale, idx, 4, yq, Q);
     // halo of the tile: threads 0 .. VW-1 the row above (a vector each), the next VW the row below, then OY threads the
@@ -1421,6 +1598,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     hc.nt = nt;
     hc.is_f32 = sizeof(T) == 4 ? 1 : 0;
     hc.in_scale = hc.out_in_scale = (T)1;
+    hc.u_bg = (T)1;
+    hc.work_count = 1 << 30;            // (the first attempt looks at every tile)
     ctl_prepare_attempt(hc, true);
     OC_HIP_CHECK(hipMemcpyAsync(ctl, &hc, sizeof(hc), hipMemcpyHostToDevice, s));
     OC_HIP_CHECK(hipStreamSynchronize(s));          // (hc lives on this stack frame)
@@ -1449,6 +1628,9 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     SA.Nx = S.Nx;
     SA.row_lo = own_lo;
     SA.row_hi = own_hi;
+    SA.flags_prev = nullptr;
+    SA.flags_cur = nullptr;
+    SA.work = nullptr;
     // stage launches of an attempt (k_stageV): hjb_fuse 0 = all six stages in one launch (tile 112 x 20), 1 = two launches of
     // three stages (tile 120 x 26; measured slower, kept as a cross-check of the other)
     const int fuse = h->hjb_fuse;
@@ -1481,6 +1663,28 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     OA.inv2dy = (T)(1.0 / (2 * c.dy));
     OA.Ny = S.Ny;
     OA.Nx = S.Nx;
+    OA.flags = nullptr;
+    OA.stx = tx;
+    OA.sty = ty;
+    // the exact active set (k_stageV): two flag arrays, one per attempt parity.  Single-GPU, one-launch attempts only: in a
+    // row-block solve activity also arrives through the halo exchange, which the tile flags do not see.
+    // Below ~1000 tiles (grids under ~1500 x 1500) the bookkeeping costs more than the skipped tiles save (exit_opposite
+    // 512 x 512, where the front crosses the room: 3.9 against 3.5 ms per solve): hjb_active = 1 switches by size, 2 forces it.
+    const bool active_set = !sh && fuse == 0 && (h->hjb_active == 2 || (h->hjb_active == 1 && nb3 >= 1024));
+    if (active_set && h->hjb_flags_n < (size_t)3 * nb3) {     // flags of two attempts + the work list
+        if (h->hjb_flags) OC_HIP_CHECK(hipFree(h->hjb_flags));
+        h->hjb_flags = nullptr;
+        h->hjb_flags_n = 0;
+        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_flags, sizeof(int32_t) * 3 * (size_t)nb3));
+        h->hjb_flags_n = (size_t)3 * nb3;
+    }
+    int32_t* const work_list = active_set ? h->hjb_flags + 2 * (size_t)nb3 : nullptr;
+    if (active_set) {                               // the first attempt's list: every tile
+        std::vector<int32_t> ident((size_t)nb3);
+        for (int q = 0; q < nb3; ++q) ident[q] = q;
+        OC_HIP_CHECK(hipMemcpyAsync(work_list, ident.data(), sizeof(int32_t) * nb3, hipMemcpyHostToDevice, s));
+        OC_HIP_CHECK(hipStreamSynchronize(s));      // (ident lives on this stack frame)
+    }
     const size_t lo = (size_t)own_lo * S.Nx, hi = (size_t)own_hi * S.Nx, hn = sh ? (size_t)sh->halo * S.Nx : 0;
     const bool halos = sh && (sh->has_up || sh->has_dn);
 
@@ -1507,6 +1711,12 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         const bool prof = prof_on && (enq % PROF_EVERY == 0);
         if (prof) ev_attempt.push_back(enq);
         if (prof) event();
+        if (active_set) {
+            SA.flags_cur = h->hjb_flags + (size_t)(enq & 1) * nb3;
+            SA.flags_prev = enq > 0 ? h->hjb_flags + (size_t)((enq - 1) & 1) * nb3 : nullptr;
+            SA.work = work_list;
+            OA.flags = SA.flags_cur;
+        }
         if (fuse == 0) {
             hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32>), grid3, dim3(1024), 0, s, SA);
         } else {
@@ -1524,7 +1734,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                                h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev);
         } else {
             hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, ctl, (const double*)h->red_partial, nb3,
-                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev);
+                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev,
+                               (const int32_t*)SA.flags_cur,
+                               active_set ? h->hjb_flags + (size_t)((enq + 1) & 1) * nb3 : (int32_t*)nullptr, work_list,
+                               h->red_partial, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty);
         }
         if (halos) {
             const dim3 gh((unsigned)((4 * hn + 255) / 256));
@@ -1599,16 +1812,19 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             float e1 = 0.f, e2 = 0.f;
             (void)hipEventElapsedTime(&e1, ev[4 * g], ev[4 * g + 1]);
             (void)hipEventElapsedTime(&e2, ev[4 * g + 2], ev[4 * g + 3]);
+            // (active set: the state arrays are only moved on the non-trivial tiles -- priced with the solve's mean share
+            // of tiles that had an error contribution; the direction field is written in full either way)
+            const double share = active_set && n_real > 0 ? std::min(1.0, hc.act_sum / ((double)n_real * nb3)) : 1.0;
             if (log[a] & 1) {           // a real attempt: 8 array passes in one launch (two launches: 6 + 11)
                 ts.add_ms += e1;
                 ts.add_n += 1;
-                ts.bytes += (fuse == 0 ? 8.0 : 17.0) * sizeof(T) * (double)n;
+                ts.bytes += (fuse == 0 ? 8.0 : 17.0) * sizeof(T) * (double)n * share;
             }
             if (log[a] & 2) {           // accepted: k_out read y, K0, Q1 .. Q3 once, wrote 2 components per slice
                 const int nv = log[a] >> 8;
                 to.add_ms += e2;
                 to.add_n += 1;
-                to.bytes += sizeof(T) * 5.0 * (double)n + sizeof(TO) * 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2);
+                to.bytes += sizeof(T) * 5.0 * (double)n * share + sizeof(TO) * 2.0 * nv * (double)(S.Ny - 2) * (S.Nx - 2);
             }
         }
     }

@@ -62,6 +62,10 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
         const int v = atoi(e);
         if (v >= 0 && v <= 1) h->hjb_fuse = v;
     }
+    if (const char* e = getenv("OC_HJB_ACTIVE")) {      // 0: compute every tile of every attempt, 2: active set at any grid size
+        const int v = atoi(e);
+        if (v >= 0 && v <= 2) h->hjb_active = v;
+    }
     *out = h;
     return OC_OK;
 }
@@ -80,6 +84,7 @@ extern "C" int oc_destroy(oc_handle* h) {
     if (h->hjb_ctl_host) (void)hipHostFree(h->hjb_ctl_host);
     (void)hipFree(h->hjb_tsteps);
     (void)hipFree(h->hjb_log);
+    (void)hipFree(h->hjb_flags);
     for (hipEvent_t e : h->hjb_events) (void)hipEventDestroy(e);
     for (auto& w : h->wallmaps) {
         (void)hipFree(w.left);
@@ -237,6 +242,9 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     } else if (!strcmp(name, "out_tile")) {
         OC_REQUIRE(value >= -1 && value <= 2, "out_tile out of range");
         h->out_tile = value;
+    } else if (!strcmp(name, "hjb_active")) {
+        OC_REQUIRE(value >= 0 && value <= 2, "hjb_active out of range");
+        h->hjb_active = value;
     } else if (!strcmp(name, "hjb_fuse")) {
         OC_REQUIRE(value >= 0 && value <= 1, "hjb_fuse out of range");
         h->hjb_fuse = value;

@@ -85,6 +85,8 @@ struct oc_handle {
     double* hjb_tsteps = nullptr;
     int32_t* hjb_log = nullptr;
     std::vector<hipEvent_t> hjb_events;
+    int32_t* hjb_flags = nullptr;    // active-set flags of the stage tiles, two attempts (hjb.hip: k_stageV)
+    size_t hjb_flags_n = 0;
     // ---- per-key data
     std::vector<oc_field_desc> fields;
     std::vector<oc_wallmap> wallmaps;
@@ -122,6 +124,7 @@ struct oc_handle {
     int hjb_variant = 0;
     int out_tile = -1;              // tile of k_out: -1 = by grid size, 0 = 64 x 16, 1 = 128 x 8, 2 = 256 x 4 cells
     int hjb_fuse = 0;               // stage launches of an RK attempt: 0 = all six stages in one, 1 = 2 x three stages (hjb.hip)
+    int hjb_active = 1;             // exact active set (hjb.hip): 0 off, 1 on for grids of >= 1024 stage tiles, 2 on at any size
     std::map<std::string, oc_timer> timers;
 };
 
