@@ -304,6 +304,9 @@ def main():
                          "all-reduce per step; strong scaling) -- auto picks it for metro_station / open_room; ensemble = "
                          "one independent simulation per GPU (aggregate replica throughput, weak scaling)")
     ap.add_argument("--no-ensemble-line", action="store_true", help="sharded mode: do not also measure the ensemble")
+    ap.add_argument("--no-dense-line", action="store_true",
+                    help="do not also run the HJB solves with every tile computed (profiling passes: keeps the kernel "
+                         "averages to the product path)")
     ap.add_argument("--tune", default="", help="launch-shape knobs, e.g. pair_split=4 (oc_set_tuning)")
     ap.add_argument("--hjb-dtype", default="float32", choices=["float32", "mixed", "float64"],
                     help="HJB state: float32 (BASELINE's configs, default), mixed (float64 state, float32 field), float64")
@@ -353,6 +356,13 @@ def main():
         eng.set_tuning(name, int(val))
     nt = sim._nt0
     K, W = args.steps, args.warmup
+    # the exact active set of the HJB solve (csrc/hjb.hip): on by default from 1024 stage tiles (112 x 20 cells) on, single
+    # GPU / whole-key solves only; `--tune hjb_active=0` computes every tile of every attempt
+    tune_active = [kv.split("=")[1] for kv in args.tune.split(",") if kv.startswith("hjb_active=")]
+    active_knob = int(tune_active[-1]) if tune_active else int(os.environ.get("OC_HJB_ACTIVE", "1"))
+    n_stage_tiles = -(-sim.Nx // 112) * -(-sim.Ny // 20)
+    rows_split = sharded and any(len(p) > 1 for p in getattr(eng, "key_plan", []))
+    active_set = (active_knob == 2 or (active_knob == 1 and n_stage_tiles >= 1024)) and not rows_split
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     elapsed, stats, state0 = measure(sim, args, nt, world, dist, red_dev, keep_state=want_cpu)
 
@@ -396,7 +406,10 @@ def main():
                    "parallelism": parallelism, "mode": "sharded" if sharded else ("ensemble" if world > 1 else "single"),
                    "noise": "device Philox", "agent_state": "f64", "pair_math": "f32",
                    "hjb_state": {"float32": "f32", "mixed": "f64", "float64": "f64"}[sim.hjb_dtype],
-                   "hjb_field": "f64" if sim.hjb_dtype == "float64" else "f32"},
+                   "hjb_field": "f64" if sim.hjb_dtype == "float64" else "f32",
+                   "hjb_active_set": ("exact: tiles where phi is constant and K = 0 are not computed; every slice of the "
+                                      "direction field is written (bit-identical to the dense sweep)") if active_set
+                   else "off: every tile of every attempt is computed"},
         "roofline": roof,
         "breakdown": {"hjb_solve_s_total_this_rank": t_hjb, "hjb_solves_this_rank": len(mine),
                       "gcfm_kernel_ms_per_step": kernel_step_ms,
@@ -442,6 +455,27 @@ def main():
                 "waves_per_launch": nw, "source": "SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAVES (profiles/)"}
     if rank == 0 and kf.get("avg_ms") and not args.no_work_count and not sharded:
         result["breakdown"]["gcfm_work"] = gcfm_work(sim, cfg, kf["avg_ms"] * 1e-3, (kernel_step_ms or 1.0) * 1e-3)
+    if rank == 0 and world == 1 and active_set and roof is not None and not args.no_dense_line:
+        # the same solve with every tile computed (one untimed round, right after): the dense sweep's kernels beside it
+        eng.set_tuning("hjb_active", 0)
+        eng.reset_kernel_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dstat = [s_ for s_ in solve_round(sim) if s_ is not None]
+        torch.cuda.synchronize()
+        t_dense = time.perf_counter() - t0
+        dk = {}
+        for name in ("hjb_out", "hjb_stage"):
+            nl, ms, by = eng.kernel_stats(name)
+            dk[name] = {"launches_timed": nl, "avg_ms": (ms / nl if nl else None),
+                        "designed_GB_per_launch": (by / nl / 1e9 if nl else None),
+                        "achieved_GBps": (by / (ms * 1e-3) / 1e9 if ms > 0 and by > 0 else None)}
+        eng.set_tuning("hjb_active", active_knob)
+        result["dense_sweep"] = {
+            "what": "the same HJB solves with hjb_active=0 (every tile of every attempt computed), one untimed round",
+            "hjb_solve_s_per_key": t_dense / max(len(dstat), 1), "rk_attempts": dstat[0]["n_attempt"] if dstat else None,
+            "k_out": dict(dk["hjb_out"], frac_of_hbm_peak=(dk["hjb_out"]["achieved_GBps"] or 0) / HBM_PEAK_GBS),
+            "k_stageV": dk["hjb_stage"]}
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(sim, cfg, args.workload, state0,
                                               budget_s=float(os.environ.get("OC_BENCH_CPU_BUDGET", "25")))

@@ -253,7 +253,13 @@ int oc_set_hjb_variant(oc_handle* h, int variant);
  *   "out_tile"     tile of the dense-output / direction-field writer: -1 = by grid size (default), 0 = 64 x 16,
  *                  1 = 128 x 8, 2 = 256 x 4 cells
  *   "hjb_fuse"     stage launches of an RK attempt of the product path: 0 = one launch of six stages (default),
- *                  1 = two launches of three */
+ *                  1 = two launches of three
+ *   "hjb_active"   exact active set of oc_hjb_solve: tiles of the grid on which phi is one constant power of two, K0 = 0
+ *                  and coef = 0 -- the far field of a solve with m = 0, where optimals.py:144-164 evaluates to exactly 0
+ *                  -- are not computed; every slice of the direction field is still written, and fields, step sequence
+ *                  and statistics are bit-identical to computing every tile.  0 = off, 1 = on for grids of at least
+ *                  1024 stage tiles of 112 x 20 cells (default), 2 = on at any size.  Whole-key solves only
+ *                  (oc_hjb_solve_rows always computes every tile). */
 int oc_set_tuning(oc_handle* h, const char* name, int value);
 
 /* Opt-in corrections of reference quirks (SURVEY.md quirk register, section 8f-4).  Default 0: every entry point is

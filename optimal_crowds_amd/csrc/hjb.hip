@@ -75,6 +75,7 @@ struct HjbCtl {
     T in_scale, out_in_scale;
     T u_bg;                             // active set: the far field's value of y in the current y buffer (a power of two)
     int32_t work_count;                 // active set: tiles the next stage launch has to look at (work list, k_control)
+    int32_t dense_mode;                 // active set: every tile has become active -- the rest of the solve runs without flags and list
     int32_t n_hx;                       // k_out's per-slice factors h x, h x^2, h x^3, h x^4 (0: more than HJB_MAXS slices,
     T hx[HJB_MAXS][4];                  // computed in the kernel)
 };
@@ -352,6 +353,8 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
     // otherwise pay a memory round trip for every field it touches
     __shared__ HjbCtl<T> c;
     __shared__ double ls[4], lm[4], la[4];
+    __shared__ int all_active;          // every tile had an error share: all were computed, the next work list is every tile
+    if (threadIdx.x == 0) all_active = 0;
     constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
     static_assert(sizeof(HjbCtl<T>) % 4 == 0, "controller block must be a whole number of words");
     {
@@ -392,11 +395,14 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
             double esum = 0.0, ymax = 0.0;
             // (active set: tiles off the work list took no part in the launch -- their share is 0 and the far field's u)
             if (work != nullptr && c.work_count < nparts) ymax = fabs((double)c.u_bg * (double)c.in_scale);
+            double nact = 0.0;
             for (int q = 0; q < (nth + 63) / 64; ++q) {
                 esum += ls[q];
                 ymax = fmax(ymax, lm[q]);
-                c.act_sum += la[q];
+                nact += la[q];
             }
+            c.act_sum += nact;
+            all_active = (work != nullptr && nact == (double)nparts) ? 1 : 0;
             const double err = sqrt(esum) / sqrt(c.n_rms);
             ++c.n_attempt;
             c.accepted = 0;
@@ -471,7 +477,11 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
     // ---- active set: the next attempt's work list.  A tile that was trivial in the attempt just run, with all 8 neighbours,
     // is trivial in the next one whatever the decision was; if the target buffers hold the trivial values already (the attempt
     // was rejected, or no rescale lies between the buffers) it needs no block at all: flag and error share are set here.
-    if (work != nullptr && !c.done) {
+    if (work != nullptr && !c.done && (all_active || c.dense_mode)) {
+        // every tile is active (a density term under the whole crowd, or the front has reached every tile) and stays so:
+        // the rest of the solve runs without flags and list
+        if (threadIdx.x == 0) c.dense_mode = 1;
+    } else if (work != nullptr && !c.done) {
         constexpr int MAXT = 16384;                 // tiles whose flags fit the LDS copy (4096 x 4096: 7 585); more: list all
         __shared__ uint8_t sflag[MAXT], srow[MAXT];
         __shared__ int32_t wsum[4];
@@ -873,7 +883,8 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     const int per = (nb + 7) / 8;
     int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);              // XCD-aware order (tile_of_block)
     if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
-    if (NQ == 6 && A.work != nullptr) {             // active set: entry `logical` of the work list, or nothing to do
+    const bool sparse = NQ == 6 && A.flags_cur != nullptr && ctl->dense_mode == 0;
+    if (sparse && A.work != nullptr) {              // active set: entry `logical` of the work list, or nothing to do
         if (logical >= ctl->work_count) return;
         logical = A.work[logical];
     }
@@ -906,16 +917,19 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     //   trivial values: it was trivial at the previous attempt and no rescale separates the buffers' scales.
     bool trivial = false, own_prev = false;
     T u_raw = (T)0;
-    const bool track = (NQ == 6) && A.flags_cur != nullptr;
+    const bool track = sparse;
     const int bi = logical / nbx, bj = logical % nbx;
     if (track) {
         u_raw = y[(int64_t)(bi * TY) * Nx + bj * TX];       // (uniform address: the tile's first cell)
         own_prev = A.flags_prev != nullptr && A.flags_prev[logical] != 0;
     }
+    // a tile that was computed in the previous attempt is computed again without the test (the front only advances; were
+    // it ever trivial again, computing it is still right): the test's barrier is paid by the ring around the active region
+    const bool need_test = track && (A.flags_prev == nullptr || own_prev);
     bool cell_trivial = true;
     if (in) {
         const V4<T> y4 = ld4(y + idx), c4 = ld4(A.coef + idx);
-        if (track) {
+        if (need_test) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 cell_trivial = cell_trivial && y4.v[q] == u_raw && (c4.v[q] == (T)0 || c4.v[q] != c4.v[q]);
@@ -932,7 +946,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             const V4<T> k4 = ld4(kin[j] + idx);
             kv[j][0] = (T2){k4.v[0], k4.v[1]};
             kv[j][1] = (T2){k4.v[2], k4.v[3]};
-            if (track && j == 0) {
+            if (need_test && j == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) cell_trivial = cell_trivial && k4.v[q] == (T)0;
             }
@@ -946,7 +960,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         return r;
     };
     if (track) {
-        trivial = __syncthreads_and((cell_trivial && is_pow2(u_raw)) ? 1 : 0) != 0;
+        if (need_test) trivial = __syncthreads_and((cell_trivial && is_pow2(u_raw)) ? 1 : 0) != 0;
         if (trivial) {
             const T un = u_raw * in_scale;
             const bool can_skip = own_prev && (ctl->rejected != 0 || (in_scale == (T)1 && ctl->out_in_scale == (T)1));
@@ -1188,7 +1202,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> 
     // the exact active set (k_stageV): where every stage tile under this tile and its one-cell ring was trivial in the
     // accepted attempt, phi(t) is one constant there for every t of the step -- central differences 0, direction 0 -- and
     // the slices are written as zeros without reading or computing anything (the audit output `keep` takes the full path)
-    if (A.flags != nullptr && A.keep_slot == nullptr) {
+    if (A.flags != nullptr && A.keep_slot == nullptr && ctl->dense_mode == 0) {
         const int snbx = (Nx + A.stx - 1) / A.stx;
         const int r0 = max(i0 - 1, 0) / A.sty, r1 = min(i0 + OY, Ny - 1) / A.sty;
         const int c0 = max(j0 - 1, 0) / A.stx, c1 = min(j0 + OX, Nx - 1) / A.stx;

@@ -1,7 +1,7 @@
 # A/B of the HJB stage-launch shapes on the GPU box: bash tools/ab_hjb.sh [workload]
 wl=${1:-metro_station}
 for f in ${FUSE:-0 1}; do
-  python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-work-count --tune ${KNOB:-hjb_fuse}=$f > gpurun_out/ab_hjb_${wl}_$f.json 2> gpurun_out/ab_hjb_${wl}_$f.err || { echo "fuse $f failed"; tail -3 gpurun_out/ab_hjb_${wl}_$f.err; continue; }
+  python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-work-count --no-dense-line --tune ${KNOB:-hjb_fuse}=$f > gpurun_out/ab_hjb_${wl}_$f.json 2> gpurun_out/ab_hjb_${wl}_$f.err || { echo "fuse $f failed"; tail -3 gpurun_out/ab_hjb_${wl}_$f.err; continue; }
   python - $f gpurun_out/ab_hjb_${wl}_$f.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

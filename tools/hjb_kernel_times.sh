@@ -3,7 +3,7 @@ wl=${1:-metro_station}
 tune=${2:-hjb_active=1}
 root=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $root/gpurun_out/kt_${wl}_${tune} -o t -- python $root/bench.py --workload $wl --steps 20 --warmup 2 --no-cpu-baseline --no-work-count --tune $tune > $root/gpurun_out/kt_${wl}_${tune}.log 2>&1 || { echo failed; tail -3 $root/gpurun_out/kt_${wl}_${tune}.log; }
+rocprofv3 --kernel-trace --output-format csv -d $root/gpurun_out/kt_${wl}_${tune} -o t -- python $root/bench.py --workload $wl --steps 20 --warmup 2 --no-cpu-baseline --no-work-count --no-dense-line --tune $tune > $root/gpurun_out/kt_${wl}_${tune}.log 2>&1 || { echo failed; tail -3 $root/gpurun_out/kt_${wl}_${tune}.log; }
 python - $root/gpurun_out/kt_${wl}_${tune} <<'PY'
 import sys, glob, csv, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)

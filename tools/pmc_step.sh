@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM" \
            "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS SQ_LDS_ATOMIC_RETURN SQ_LDS_ADDR_CONFLICT"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --pmc $set --kernel-include-regex "$KERNELS" --output-format csv -d $out/p$i -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $out/p$i.log; }
+  timeout -k 10 400 rocprofv3 --pmc $set --kernel-include-regex "$KERNELS" --output-format csv -d $out/p$i -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-dense-line "$@" > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $out/p$i.log; }
 done
 python - $out <<'PY'
 import csv, glob, sys, collections
