@@ -387,6 +387,11 @@ def main():
                 "profiles/; null unless taken with these kernel sources)",
                 "launches_timed": ko["launches_timed"], "avg_launch_ms": ko["avg_ms"],
                 "algorithmic_GB_per_launch": ko["designed_GB_per_launch"]}
+        if active_set:
+            roof["note"] = ("product path = exact active set: the far field's slices are written as zeros without reads, so the "
+                            "launch is (almost) a pure write stream of the whole direction field -- bytes = the field written + "
+                            "the state arrays of the non-trivial tiles; the dense sweep's launch (5 arrays read + the same "
+                            "writes, in the same time) is in `dense_sweep.k_out`")
     keys_n = len(sim._key_names)
     parallelism = "single GPU"
     if world > 1:
