@@ -76,6 +76,7 @@ struct HjbCtl {
     T u_bg;                             // active set: the far field's value of y in the current y buffer (a power of two)
     int32_t work_count;                 // active set: tiles the next stage launch has to look at (work list, k_control)
     int32_t dense_mode;                 // active set: every tile has become active -- the rest of the solve runs without flags and list
+    int32_t list_todo;                  // active set: k_control's order for the list builder (block 0 of k_out): 1 = build, 2 = go dense
     int32_t n_hx;                       // k_out's per-slice factors h x, h x^2, h x^3, h x^4 (0: more than HJB_MAXS slices,
     T hx[HJB_MAXS][4];                  // computed in the kernel)
 };
@@ -474,74 +475,9 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
             xp *= x;
         }
     }
-    // ---- active set: the next attempt's work list.  A tile that was trivial in the attempt just run, with all 8 neighbours,
-    // is trivial in the next one whatever the decision was; if the target buffers hold the trivial values already (the attempt
-    // was rejected, or no rescale lies between the buffers) it needs no block at all: flag and error share are set here.
-    if (work != nullptr && !c.done && (all_active || c.dense_mode)) {
-        // every tile is active (a density term under the whole crowd, or the front has reached every tile) and stays so:
-        // the rest of the solve runs without flags and list
-        if (threadIdx.x == 0) c.dense_mode = 1;
-    } else if (work != nullptr && !c.done) {
-        constexpr int MAXT = 16384;                 // tiles whose flags fit the LDS copy (4096 x 4096: 7 585); more: list all
-        __shared__ uint8_t sflag[MAXT], srow[MAXT];
-        __shared__ int32_t wsum[4];
-        const int ntile = tnbx * tnby;
-        const bool skip_ok = (c.rejected != 0 || (c.in_scale == (T)1 && c.out_in_scale == (T)1)) && ntile <= MAXT;
-        // every thread owns a contiguous run of tiles (an ordered list keeps neighbouring tiles in neighbouring blocks)
-        const int per_thr = (ntile + nth - 1) / nth, t_lo = min((int)threadIdx.x * per_thr, ntile), t_hi = min(t_lo + per_thr, ntile);
-        uint32_t listed = 0xFFFFFFFFu;              // bit q: tile t_lo + q goes on the list (per_thr <= 32: MAXT / 256 = 64 -> two words)
-        uint32_t listed_hi = 0xFFFFFFFFu;
-        if (skip_ok) {
-            for (int t = threadIdx.x; t < ntile; t += nth) sflag[t] = flags_cur[t] != 0 ? 1 : 0;
-            __syncthreads();
-            // trivial with all 8 neighbours = AND over the row triple of the AND over the column triple (two passes)
-            int bj = t_lo % tnbx;
-            for (int t = t_lo; t < t_hi; ++t) {
-                const uint8_t l = bj > 0 ? sflag[t - 1] : (uint8_t)1, r = bj < tnbx - 1 ? sflag[t + 1] : (uint8_t)1;
-                srow[t] = sflag[t] & l & r;
-                bj = bj + 1 == tnbx ? 0 : bj + 1;
-            }
-            __syncthreads();
-            for (int t = t_lo; t < t_hi; ++t) {
-                const uint8_t u = t >= tnbx ? srow[t - tnbx] : (uint8_t)1, d = t + tnbx < ntile ? srow[t + tnbx] : (uint8_t)1;
-                const bool quiet = (srow[t] & u & d) != 0;
-                const int q = t - t_lo;
-                if (quiet) {
-                    if (q < 32) listed &= ~(1u << q);
-                    else listed_hi &= ~(1u << (q - 32));
-                }
-            }
-        }
-        const int nmine = t_hi - t_lo;
-        const uint32_t m_lo = nmine >= 32 ? 0xFFFFFFFFu : ((1u << max(nmine, 0)) - 1u);
-        const uint32_t m_hi = nmine >= 64 ? 0xFFFFFFFFu : (nmine > 32 ? ((1u << (nmine - 32)) - 1u) : 0u);
-        listed &= m_lo;
-        listed_hi &= m_hi;
-        const int mine = __popc(listed) + __popc(listed_hi);
-        int incl = mine;
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) wsum[wv] = incl;
-        __syncthreads();
-        int off = incl - mine;
-        for (int q = 0; q < wv; ++q) off += wsum[q];
-        for (int t = t_lo; t < t_hi; ++t) {
-            const int q = t - t_lo;
-            const bool on = q < 32 ? ((listed >> q) & 1u) != 0 : ((listed_hi >> (q - 32)) & 1u) != 0;
-            if (on) {
-                work[off++] = t;
-            } else {
-                flags_next[t] = 1;
-                parts_rw[2 * t] = 0.0;
-                parts_rw[2 * t + 1] = 0.0;
-            }
-        }
-        if (threadIdx.x == 0) c.work_count = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    }
+    // ---- active set: the next attempt's work list is built by block 0 of the k_out launch that follows (beside the output
+    // blocks, off the critical path): here only the order for it
+    if (threadIdx.x == 0) c.list_todo = (work != nullptr && !c.done) ? ((all_active || c.dense_mode) ? 2 : 1) : 0;
     __syncthreads();
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
@@ -1124,6 +1060,11 @@ struct OutArgs {
     int Ny, Nx;
     const int32_t* flags;   // the accepted attempt's stage-tile flags (stx x sty cells per tile), or NULL
     int stx, sty;
+    // block 0 builds the next attempt's work list (build_work_list) when `work` is set
+    HjbCtl<T>* ctl_rw;
+    int32_t* flags_next;
+    int32_t* work;
+    double* parts_rw;
 };
 
 template <typename T, bool QIN>
@@ -1171,6 +1112,82 @@ __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* 
     }
 }
 
+// The next attempt's work list (exact active set, k_stageV), built by block 0 of k_out beside the output blocks.  A tile that
+// was trivial in the attempt just run, with all 8 neighbours, is trivial in the next one whatever the decision was; if the
+// target buffers hold the trivial values already (the attempt was rejected, or no rescale lies between the buffers) it needs
+// no block at all: its flag and error share are set here.  sflag: the block's LDS (nbytes of it).
+template <typename T>
+__device__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __restrict__ flags_cur,
+                                int32_t* __restrict__ flags_next, int32_t* __restrict__ work, double* __restrict__ parts_rw,
+                                int tnbx, int tnby, uint8_t* sflag, int nbytes) {
+    __shared__ int32_t wsum[4];
+    const int todo = ctl->list_todo, nth = (int)blockDim.x;
+    if (todo == 0) return;
+    if (todo == 2) {                                // every tile is active and stays so: no flags, no list from now on
+        if (threadIdx.x == 0) ctl->dense_mode = 1;
+        return;
+    }
+    const int ntile = tnbx * tnby;
+    const bool skip_ok = (ctl->rejected != 0 || (ctl->in_scale == (T)1 && ctl->out_in_scale == (T)1)) && ntile <= nbytes;
+    // every thread owns a contiguous run of tiles (an ordered list keeps neighbouring tiles in neighbouring blocks)
+    const int per_thr = (ntile + nth - 1) / nth, t_lo = min((int)threadIdx.x * per_thr, ntile), t_hi = min(t_lo + per_thr, ntile);
+    uint32_t listed = 0xFFFFFFFFu, listed_hi = 0xFFFFFFFFu;     // bit q: tile t_lo + q goes on the list (per_thr <= 64)
+    if (skip_ok) {
+        for (int t = threadIdx.x; t < ntile; t += nth) sflag[t] = flags_cur[t] != 0 ? 1 : 0;
+        __syncthreads();
+        int bi = t_lo / tnbx, bj = t_lo % tnbx;
+        for (int t = t_lo; t < t_hi; ++t) {
+            uint32_t q9 = 1u;
+#pragma unroll
+            for (int di = -1; di <= 1; ++di)
+#pragma unroll
+                for (int dj = -1; dj <= 1; ++dj) {
+                    const int ni = bi + di, nj = bj + dj;
+                    const bool inside = ni >= 0 && ni < tnby && nj >= 0 && nj < tnbx;
+                    q9 &= inside ? (uint32_t)sflag[inside ? ni * tnbx + nj : t] : 1u;
+                }
+            const int q = t - t_lo;
+            if (q9) {
+                if (q < 32) listed &= ~(1u << q);
+                else listed_hi &= ~(1u << (q - 32));
+            }
+            if (++bj == tnbx) {
+                bj = 0;
+                ++bi;
+            }
+        }
+    }
+    const int nmine = t_hi - t_lo;
+    const uint32_t m_lo = nmine >= 32 ? 0xFFFFFFFFu : ((1u << max(nmine, 0)) - 1u);
+    const uint32_t m_hi = nmine >= 64 ? 0xFFFFFFFFu : (nmine > 32 ? ((1u << (nmine - 32)) - 1u) : 0u);
+    listed &= m_lo;
+    listed_hi &= m_hi;
+    const int mine = __popc(listed) + __popc(listed_hi);
+    int incl = mine;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int off = incl - mine;
+    for (int q = 0; q < wv; ++q) off += wsum[q];
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int q = t - t_lo;
+        const bool on = q < 32 ? ((listed >> q) & 1u) != 0 : ((listed_hi >> (q - 32)) & 1u) != 0;
+        if (on) {
+            work[off++] = t;
+        } else {
+            flags_next[t] = 1;
+            parts_rw[2 * t] = 0.0;
+            parts_rw[2 * t + 1] = 0.0;
+        }
+    }
+    if (threadIdx.x == 0) ctl->work_count = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
 // Tile = OX x OY cells with OX * OY = 1024 (256 threads x 4 consecutive cells of a row): 64 x 16, 128 x 8 or 256 x 4.  A
 // wider tile writes longer contiguous runs per row and slice (1 KB at 256 instead of 256 B), which is what counts where
 // the input arrays no longer come out of the Infinity Cache (4096 x 4096).
@@ -1179,6 +1196,12 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> 
     constexpr int OY = 1024 / OX, VW = OX / 4, OLS = OX + 8;
     __shared__ alignas(16) T tile[2][OY + 2][OLS];
     const HjbCtl<T>* __restrict__ ctl = A.ctl;
+    const int bshift = A.work != nullptr ? 1 : 0;
+    if (bshift && blockIdx.x == 0) {                // the list builder (also after a rejected attempt)
+        build_work_list<T>(A.ctl_rw, A.flags, A.flags_next, A.work, A.parts_rw, (A.Nx + A.stx - 1) / A.stx,
+                           (A.Ny + A.sty - 1) / A.sty, reinterpret_cast<uint8_t*>(&tile[0][0][0]), (int)sizeof(tile));
+        return;
+    }
     if (!ctl->accepted) return;                     // a rejected attempt (or one past the end) has nothing to emit
     const int par = ctl->out_parity;
     const int k_lo = ctl->k_lo, k_hi = ctl->k_hi, nt = ctl->nt;
