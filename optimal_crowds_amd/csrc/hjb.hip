@@ -1215,8 +1215,9 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> 
     const int Ny = A.Ny, Nx = A.Nx;
     const int nbx = (Nx + OX - 1) / OX, nby = (Ny + OY - 1) / OY, nb = nbx * nby;
     const int per = (nb + 7) / 8;
-    const int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);        // XCD-aware order (tile_of_block)
-    if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
+    const int bid = (int)blockIdx.x - bshift;
+    const int logical = (bid % 8) * per + bid / 8;              // XCD-aware order (tile_of_block)
+    if (bid / 8 >= per || logical >= nb) return;
     const int i0 = (logical / nbx) * OY, j0 = (logical % nbx) * OX;
     const int gi = i0 + ry, gj = j0 + 4 * cx;
     const bool valid = gi < Ny && gj < Nx;
@@ -1387,7 +1388,7 @@ void launch_out(int shape, int Nx, int Ny, hipStream_t s, const OutArgs<T>& OA) 
     if (shape < 0) shape = (5.0 * sizeof(T) * (double)Nx * Ny > 256e6) ? 2 : 1;
     const int ox = shape == 2 ? 256 : (shape == 1 ? 128 : 64), oy = 1024 / ox;
     const int nb = ((Nx + ox - 1) / ox) * ((Ny + oy - 1) / oy);
-    const dim3 grid(8 * ((nb + 7) / 8));
+    const dim3 grid(8 * ((nb + 7) / 8) + (OA.work != nullptr ? 1 : 0));     // (+ block 0: the work-list builder)
     if (shape == 2) hipLaunchKernelGGL((k_out<T, 256, TO, QIN>), grid, dim3(256), 0, s, OA);
     else if (shape == 1) hipLaunchKernelGGL((k_out<T, 128, TO, QIN>), grid, dim3(256), 0, s, OA);
     else hipLaunchKernelGGL((k_out<T, 64, TO, QIN>), grid, dim3(256), 0, s, OA);
@@ -1753,6 +1754,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             SA.flags_prev = enq > 0 ? h->hjb_flags + (size_t)((enq - 1) & 1) * nb3 : nullptr;
             SA.work = work_list;
             OA.flags = SA.flags_cur;
+            OA.ctl_rw = ctl;
+            OA.flags_next = h->hjb_flags + (size_t)((enq + 1) & 1) * nb3;
+            OA.work = work_list;
+            OA.parts_rw = h->red_partial;
         }
         if (fuse == 0) {
             hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32>), grid3, dim3(1024), 0, s, SA);
@@ -1775,6 +1780,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                                (const int32_t*)SA.flags_cur,
                                active_set ? h->hjb_flags + (size_t)((enq + 1) & 1) * nb3 : (int32_t*)nullptr, work_list,
                                h->red_partial, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty);
+            // (flags_next / parts_rw / tile counts: k_control no longer uses them -- the list is built in k_out's block 0)
         }
         if (halos) {
             const dim3 gh((unsigned)((4 * hn + 255) / 256));
