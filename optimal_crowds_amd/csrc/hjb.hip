@@ -74,7 +74,7 @@ struct HjbCtl {
     // -- as y and K0, in its stage launches and in its k_out -- so everything it writes is in the new scale.
     T in_scale, out_in_scale;
     T u_bg;                             // active set: the far field's value of y in the current y buffer (a power of two)
-    int32_t work_count;                 // active set: tiles the next stage launch has to look at (work list, k_control)
+    int32_t work_count;                 // active set: tiles the next stage launch has to look at (build_work_list)
     int32_t dense_mode;                 // active set: every tile has become active -- the rest of the solve runs without flags and list
     int32_t list_todo;                  // active set: k_control's order for the list builder (block 0 of k_out): 1 = build, 2 = go dense
     int32_t n_hx;                       // k_out's per-slice factors h x, h x^2, h x^3, h x^4 (0: more than HJB_MAXS slices,
@@ -347,9 +347,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, const double* parts,
                                                  int nparts, double* __restrict__ t_steps, int t_cap,
                                                  int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox,
-                                                 const int32_t* __restrict__ flags_cur = nullptr,
-                                                 int32_t* __restrict__ flags_next = nullptr, int32_t* __restrict__ work = nullptr,
-                                                 double* parts_rw = nullptr, int tnbx = 0, int tnby = 0) {
+                                                 int active_set = 0) {
     // the controller block is worked on in LDS (one coalesced load, one coalesced store): thread 0's serial code would
     // otherwise pay a memory round trip for every field it touches
     __shared__ HjbCtl<T> c;
@@ -395,7 +393,7 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
         } else {
             double esum = 0.0, ymax = 0.0;
             // (active set: tiles off the work list took no part in the launch -- their share is 0 and the far field's u)
-            if (work != nullptr && c.work_count < nparts) ymax = fabs((double)c.u_bg * (double)c.in_scale);
+            if (active_set != 0 && c.work_count < nparts) ymax = fabs((double)c.u_bg * (double)c.in_scale);
             double nact = 0.0;
             for (int q = 0; q < (nth + 63) / 64; ++q) {
                 esum += ls[q];
@@ -403,7 +401,7 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
                 nact += la[q];
             }
             c.act_sum += nact;
-            all_active = (work != nullptr && nact == (double)nparts) ? 1 : 0;
+            all_active = (active_set != 0 && nact == (double)nparts) ? 1 : 0;
             const double err = sqrt(esum) / sqrt(c.n_rms);
             ++c.n_attempt;
             c.accepted = 0;
@@ -477,7 +475,7 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
     }
     // ---- active set: the next attempt's work list is built by block 0 of the k_out launch that follows (beside the output
     // blocks, off the critical path): here only the order for it
-    if (threadIdx.x == 0) c.list_todo = (work != nullptr && !c.done) ? ((all_active || c.dense_mode) ? 2 : 1) : 0;
+    if (threadIdx.x == 0) c.list_todo = (active_set != 0 && !c.done) ? ((all_active || c.dense_mode) ? 2 : 1) : 0;
     __syncthreads();
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
@@ -742,7 +740,7 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     // exact active set (k_stageV below): per tile 1 = trivial at that attempt, 0 = computed; NULL = every tile is computed
     const int32_t* flags_prev;      // the previous attempt's flags (NULL at the first attempt)
     int32_t* flags_cur;
-    const int32_t* work;            // the attempt's work list (ctl->work_count tiles, built by k_control), or NULL
+    const int32_t* work;            // the attempt's work list (ctl->work_count tiles, build_work_list), or NULL: every tile
 };
 
 // value of the previous / next lane of the wavefront (DPP wave shifts: no LDS traffic; lane 0 / 63 get 0)
@@ -848,7 +846,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     // Results are bit-identical to computing every tile (tests/test_hip_active_set.py).
     //   flags (per tile and attempt: 1 trivial, 0 computed).  A tile that was trivial together with its 8 neighbours is
     //   trivial in the next attempt too (their outputs cover its region; a rejected attempt leaves the state as it was):
-    //   k_control leaves such tiles off the next attempt's WORK LIST, and the launch's blocks beyond the list exit at once;
+    //   build_work_list leaves such tiles off the next attempt's WORK LIST, and the launch's blocks beyond the list exit at once;
     //   a listed tile loads its region and tests it.  Its stores are skipped when the target buffers already hold the
     //   trivial values: it was trivial at the previous attempt and no rescale separates the buffers' scales.
     bool trivial = false, own_prev = false;
@@ -1717,12 +1715,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         h->hjb_flags_n = (size_t)3 * nb3;
     }
     int32_t* const work_list = active_set ? h->hjb_flags + 2 * (size_t)nb3 : nullptr;
-    if (active_set) {                               // the first attempt's list: every tile
-        std::vector<int32_t> ident((size_t)nb3);
-        for (int q = 0; q < nb3; ++q) ident[q] = q;
-        OC_HIP_CHECK(hipMemcpyAsync(work_list, ident.data(), sizeof(int32_t) * nb3, hipMemcpyHostToDevice, s));
-        OC_HIP_CHECK(hipStreamSynchronize(s));      // (ident lives on this stack frame)
-    }
+
     const size_t lo = (size_t)own_lo * S.Nx, hi = (size_t)own_hi * S.Nx, hn = sh ? (size_t)sh->halo * S.Nx : 0;
     const bool halos = sh && (sh->has_up || sh->has_dn);
 
@@ -1752,7 +1745,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         if (active_set) {
             SA.flags_cur = h->hjb_flags + (size_t)(enq & 1) * nb3;
             SA.flags_prev = enq > 0 ? h->hjb_flags + (size_t)((enq - 1) & 1) * nb3 : nullptr;
-            SA.work = work_list;
+            SA.work = enq > 0 ? work_list : nullptr;       // (the first attempt looks at every tile: no list yet)
             OA.flags = SA.flags_cur;
             OA.ctl_rw = ctl;
             OA.flags_next = h->hjb_flags + (size_t)((enq + 1) & 1) * nb3;
@@ -1776,11 +1769,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                                h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev);
         } else {
             hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, ctl, (const double*)h->red_partial, nb3,
-                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev,
-                               (const int32_t*)SA.flags_cur,
-                               active_set ? h->hjb_flags + (size_t)((enq + 1) & 1) * nb3 : (int32_t*)nullptr, work_list,
-                               h->red_partial, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty);
-            // (flags_next / parts_rw / tile counts: k_control no longer uses them -- the list is built in k_out's block 0)
+                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev, active_set ? 1 : 0);
         }
         if (halos) {
             const dim3 gh((unsigned)((4 * hn + 255) / 256));
