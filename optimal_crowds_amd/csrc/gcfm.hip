@@ -627,8 +627,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
             if (NROUND > 1) {
                 int all = 0;
 #pragma unroll
-                for (int h = 0; h < NW; ++h) all += __popc(mw[h]);
-                all = (all + 1) >> 1;
+                for (int h = 0; h < NW; ++h) all += (__popc(mw[h]) + 1) >> 1;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) all += __shfl_xor(all, o, 64);
                 if (all > PAIR_LIST_CAP) nround = NROUND;
@@ -639,10 +638,9 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
 #pragma unroll
                 for (int h = 0; h < NW; ++h) m[h] = (nround == 1 || rd == h) ? mw[h] : 0u;
                 // ---- compact, lane-major: exclusive prefix sum of the lanes' entry counts, every lane appends
-                int cntl = 0;
+                int cntl = 0;           // candidates are paired inside a mask word: ceil(popc / 2) entries per word
 #pragma unroll
-                for (int h = 0; h < NW; ++h) cntl += __popc(m[h]);
-                cntl = (cntl + 1) >> 1;
+                for (int h = 0; h < NW; ++h) cntl += (__popc(m[h]) + 1) >> 1;
                 int incl = cntl;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -652,24 +650,23 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 const int total = __builtin_amdgcn_readlane(incl, 63);
                 if (total == 0) continue;
                 work += total;
-                {   // entry: agent lane << 16 | B valid << 14 | jB << 7 | jA
+                {   // entry: agent lane << 16 | B valid << 14 | jB << 7 | jA.  Two candidates of the same mask word per loop
+                    // trip (an odd last one is paired with itself, B invalid): no carry between trips, 13 VALU per entry
+                    // instead of 22 for two single-bit trips; at most one entry more per lane than pairing across the words
                     int off = incl - cntl;
-                    int prev = -1;
+                    const uint32_t ebase = (uint32_t)lane << 16;
 #pragma unroll
                     for (int h = 0; h < NW; ++h) {
                         uint32_t mm = m[h];
                         while (mm) {
-                            const int q = __clz((int)mm);
-                            mm &= ~(0x80000000u >> q);
-                            const int j = 32 * h + q;
-                            if (prev < 0) prev = j;
-                            else {
-                                lst[off++] = ((uint32_t)lane << 16) | (1u << 14) | ((uint32_t)j << 7) | (uint32_t)prev;
-                                prev = -1;
-                            }
+                            const int q1 = __clz((int)mm);
+                            mm &= ~(0x80000000u >> q1);
+                            const bool two = mm != 0u;
+                            const int q2 = two ? __clz((int)mm) : q1;
+                            mm &= ~(0x80000000u >> q2);
+                            lst[off++] = ebase | (two ? (1u << 14) : 0u) | ((uint32_t)(32 * h + q2) << 7) | (uint32_t)(32 * h + q1);
                         }
                     }
-                    if (prev >= 0) lst[off] = ((uint32_t)lane << 16) | ((uint32_t)prev << 7) | (uint32_t)prev;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
