@@ -367,6 +367,18 @@ __global__ void __launch_bounds__(64) k_tile_lists(GcfmParams P, Scratch S, int 
 // ---------------------------------------------------------------------------------- pair forces
 #define COS_VISION (-0.58778525229247312917f)   // cos(0.7 pi), pedestrians.py:262
 
+// inclusive prefix sum over the 64 lanes by DPP row shifts and row broadcasts: six VALU-latency steps where six
+// ds_bpermute round trips (__shfl_up) sat in the middle of every virtual tile's chain
+__device__ __forceinline__ int wave_incl_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1  (a row = 16 lanes; out of row: 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 typedef float f2v __attribute__((ext_vector_type(2)));
 
 // force of j on i (pedestrians.py:242-280) in trig-free form: cos(alpha-beta) = e.h, sin = h x e.
@@ -623,15 +635,8 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
             }
             // list entries hold TWO candidates of one agent (an odd last one is paired with itself, masked).  Dense
             // tile pairs do not fit the list: rounds of 32 j each (64 agents x 16 entries = PAIR_LIST_CAP always fit)
+            // (whether the rounds are needed is known from the first pass's own prefix sum: no separate reduction)
             int nround = 1;
-            if (NROUND > 1) {
-                int all = 0;
-#pragma unroll
-                for (int h = 0; h < NW; ++h) all += (__popc(mw[h]) + 1) >> 1;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) all += __shfl_xor(all, o, 64);
-                if (all > PAIR_LIST_CAP) nround = NROUND;
-            }
             if (P.diag & 4u) nround = 0;
             for (int rd = 0; rd < nround; ++rd) {
                 uint32_t m[NW];
@@ -641,13 +646,13 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 int cntl = 0;           // candidates are paired inside a mask word: ceil(popc / 2) entries per word
 #pragma unroll
                 for (int h = 0; h < NW; ++h) cntl += (__popc(m[h]) + 1) >> 1;
-                int incl = cntl;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int v = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += v;
-                }
+                const int incl = wave_incl_scan(cntl);
                 const int total = __builtin_amdgcn_readlane(incl, 63);
+                if (NROUND > 1 && nround == 1 && total > PAIR_LIST_CAP) {       // a dense tile pair: again, in rounds
+                    nround = NROUND;
+                    rd = -1;
+                    continue;
+                }
                 if (total == 0) continue;
                 work += total;
                 {   // entry: agent lane << 16 | B valid << 14 | jB << 7 | jA.  Two candidates of the same mask word per loop
