@@ -513,6 +513,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
     const double2 pi = L.li_pos[tl][lane];
     const double4 bi = C.tile_box[it];
     const double ox = bi.x, oy = bi.y;             // origin of the box-relative float32 coordinates
+    const float ext_i = (float)((bi.z - bi.x) + (bi.w - bi.y) + 2.0 * P.cutoff);
     const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
     const f2v xi2 = {xi_f, xi_f}, yi2 = {yi_f, yi_f};
     const float my_speed = L.li_vel[tl][lane].z;
@@ -553,10 +554,12 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 if (tmask) {
                     jts[b] = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
                     tmask &= tmask - 1;
-                    // conservative float32 bound: rounding of the relative coordinates scales with the boxes' extent
+                    // conservative float32 bound: rounding of the relative coordinates scales with their size, and a staged
+                    // record lies within the cutoff of the i box, inside its tile's box: |x_j - ox| + |y_j - oy| is at most
+                    // the i box's extent + 2 cutoff + its own box's extent (3 float64 operations per tile; the exact extent
+                    // of the two boxes' union took 14)
                     const double4 bj = C.tile_box[jts[b]];
-                    ext = fmaxf(ext, (float)(fmax(fmax(bi.z, bj.z) - ox, ox - fmin(bi.x, bj.x)) +
-                                             fmax(fmax(bi.w, bj.w) - oy, oy - fmin(bi.y, bj.y))));
+                    ext = fmaxf(ext, (float)((bj.z - bj.x) + (bj.w - bj.y)));
                 }
                 if (lane / NJ == b) jt_l = jts[b];
             }
@@ -578,7 +581,8 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
             L.l_ry[w][lane] = (float)(cur.pos.y - oy);
             L.l_vel[w][lane] = cur.vel;
             L.l_head[w][lane] = cur.head;
-            const float c2f = (float)c2 * 1.00001f + 1e-6f * ext * (ext + (float)c);
+            const float extt = (ext + ext_i) * 1.0001f;
+            const float c2f = (float)c2 * 1.00001f + 1e-6f * extt * (extt + (float)c);
             const f2v nc2 = {-c2f, -c2f};
             int bself = -1;                                 // position of the i-tile itself in this virtual tile
             int nfill = 0;                                  // real tiles in it (the last one of a chunk is partly padding)
