@@ -3,7 +3,7 @@ import copy
 import sys
 import os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oc_oracle as oc, oc_oracle_c as occ
 from optimal_crowds_amd import room_library
 from optimal_crowds_amd.engine import Engine

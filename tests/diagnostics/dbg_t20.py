@@ -1,5 +1,7 @@
+"""Diagnostic (GPU): float32 against float64 HJB solves of room_test at T = 20 -- which cells differ and by how much.
+Lives under tests/ because it uses the oracle as a checker (only tests/, smoke() and bench.py's cpu_baseline may)."""
 import sys, os, copy
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import oc_oracle as oc
 from optimal_crowds_amd import room_library

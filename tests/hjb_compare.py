@@ -4,7 +4,7 @@ Why two phi metrics.  The reference integrates a diffusion equation with an EXPL
 controller pushes to the stability limit (h = 3.3 / (8 (sigma^2/2)/dx^2)); there the grid's highest
 mode -- the checkerboard (-1)^(i+j) -- is amplified a little in every step until it shows up in the error estimate.
 Rounding noise is its seed: two float64 implementations that differ only in summation order already disagree by
-1.7e-6 in that mode after a T = 20 solve (amplification 1e10, measured: tools/dbg_forced.py), and float32 seeds
+1.7e-6 in that mode after a T = 20 solve (amplification 1e10, measured: tests/diagnostics/dbg_forced.py), and float32 seeds
 (6e-8) saturate at whatever the controller tolerates, which is an RMS over ALL cells (scipy common.py:63-66): on a
 2048^2 grid a ripple of a few per cent confined to the thousand cells next to a door still has an error norm < 1.
 The ripple is invisible to what the path consumes: central differences (optimals.py:174-175) take both neighbours from

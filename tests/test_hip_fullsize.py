@@ -154,7 +154,7 @@ def test_t20_fp32_range_management_vs_oracle():
         # The fp32 solve takes slightly different adaptive steps (386 vs 383 accepted), so phi differs from the oracle
         # by up to ~1e-3 relative (the solver's own rtol; median 2e-6).  At the advancing front, where phi is only
         # 0.3 % above its far-field value, the direction is a difference of such values: errors of a few 1e-2 rad in
-        # a handful of cells are inherent to rtol = 1e-3, not to float32 (tools/dbg_t20.py prints the evidence).
+        # a handful of cells are inherent to rtol = 1e-3, not to float32 (tests/diagnostics/dbg_t20.py prints the evidence).
         a_clear = ang[both & clear]
         assert a_clear.size == 0 or (np.percentile(a_clear, 99) <= 1e-2 and a_clear.max() <= 6e-2)
         flip = (np.hypot(gx, gy) > 0.5) != (np.hypot(vx[s], vy[s]) > 0.5)
