@@ -362,7 +362,7 @@ def main():
     active_knob = int(tune_active[-1]) if tune_active else int(os.environ.get("OC_HJB_ACTIVE", "1"))
     n_stage_tiles = -(-sim.Nx // 112) * -(-sim.Ny // 20)
     rows_split = sharded and any(len(p) > 1 for p in getattr(eng, "key_plan", []))
-    active_set = (active_knob == 2 or (active_knob == 1 and n_stage_tiles >= 1024)) and not rows_split
+    active_set = (active_knob == 2 or (active_knob == 1 and n_stage_tiles >= 1024)) and n_stage_tiles <= 12000 and not rows_split
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     elapsed, stats, state0 = measure(sim, args, nt, world, dist, red_dev, keep_state=want_cpu)
 

@@ -1706,7 +1706,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // row-block solve activity also arrives through the halo exchange, which the tile flags do not see.
     // Below ~1000 tiles (grids under ~1500 x 1500) the bookkeeping costs more than the skipped tiles save (exit_opposite
     // 512 x 512, where the front crosses the room: 3.9 against 3.5 ms per solve): hjb_active = 1 switches by size, 2 forces it.
-    const bool active_set = !sh && fuse == 0 && (h->hjb_active == 2 || (h->hjb_active == 1 && nb3 >= 1024));
+    // Above 12 000 tiles (grids beyond ~5000 x 5000) the list builder's per-thread masks and its LDS copy of the flags no
+    // longer cover the grid: every tile is computed.
+    const bool active_set = !sh && fuse == 0 && nb3 <= 12000 &&
+                            (h->hjb_active == 2 || (h->hjb_active == 1 && nb3 >= 1024));
     if (active_set && h->hjb_flags_n < (size_t)3 * nb3) {     // flags of two attempts + the work list
         if (h->hjb_flags) OC_HIP_CHECK(hipFree(h->hjb_flags));
         h->hjb_flags = nullptr;
