@@ -34,23 +34,66 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 STAGE = "/tmp/oc_stage"
 REFERENCE = "/root/reference"
 
-sys.path.insert(0, REPO)
-from optimal_crowds_amd import room_library  # noqa: E402
 
 
-def stage():
-    os.makedirs(os.path.join(STAGE, "rooms"), exist_ok=True)
-    link = os.path.join(STAGE, "optimal_crowds")
+def _load_by_path(name, path):
+    """Load one source file as a stand-alone module WITHOUT putting its directory on sys.path.  The repository root
+    holds a regular package `optimal_crowds/` (the drop-in alias of the MI355X implementation); with the root on the
+    path that package would win over the staged reference (a namespace portion) and this script would record the
+    implementation's own outputs as "reference" fixtures."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+room_library = _load_by_path("_oc_room_library", os.path.join(REPO, "optimal_crowds_amd", "room_library.py"))
+
+
+def _under(path, root):
+    path, root = os.path.realpath(path), os.path.realpath(root)
+    return path == root or path.startswith(root + os.sep)
+
+
+def stage(stage_dir=STAGE, reference=REFERENCE):
+    """Stage the reference for import and return its three modules.  Refuses (RuntimeError) unless every one of them
+    was loaded from a file under `reference` (reference simulations.py:10-11 imports `from optimal_crowds import
+    pedestrians / optimals`, hence the directory name)."""
+    if not os.path.isdir(reference):
+        raise RuntimeError("%s is absent: fixtures can only be generated in the build container" % reference)
+    os.makedirs(os.path.join(stage_dir, "rooms"), exist_ok=True)
+    link = os.path.join(stage_dir, "optimal_crowds")
+    if os.path.islink(link) and os.path.realpath(link) != os.path.realpath(reference):
+        os.unlink(link)
     if not os.path.islink(link):
-        os.symlink(REFERENCE, link)
-    room_library.write_rooms(os.path.join(STAGE, "rooms"))
-    os.chdir(STAGE)
-    sys.path.insert(0, STAGE)
+        os.symlink(reference, link)
+    room_library.write_rooms(os.path.join(stage_dir, "rooms"))
+    os.chdir(stage_dir)
+    # nothing of the repository may answer to the name `optimal_crowds`: drop the repo root (and '' / '.' = a cwd that
+    # could be the repo root) from the path, forget modules a caller imported before
+    repo_real = os.path.realpath(REPO)
+    sys.path[:] = [p for p in sys.path
+                   if p not in ("", ".") and os.path.realpath(p) != repo_real]
+    for name in [m for m in sys.modules if m == "optimal_crowds" or m.startswith("optimal_crowds.")]:
+        del sys.modules[name]
+    import importlib
+    importlib.invalidate_caches()
+    sys.path.insert(0, stage_dir)
     sys.modules["seaborn"] = types.ModuleType("seaborn")
     import matplotlib
     matplotlib.use("Agg")
     from optimal_crowds import simulations, optimals, pedestrians
+    check_is_reference((simulations, optimals, pedestrians), reference)
     return simulations, optimals, pedestrians
+
+
+def check_is_reference(mods, reference=REFERENCE):
+    for m in mods:
+        f = getattr(m, "__file__", None)
+        if not f or not _under(f, reference):
+            raise RuntimeError("refusing to write fixtures: %s was loaded from %s, not from %s"
+                               % (m.__name__, f, reference))
 
 
 def versions():
@@ -58,8 +101,15 @@ def versions():
     return dict(numpy_version=np.__version__, scipy_version=scipy.__version__)
 
 
+OUT = HERE          # --out DIR writes elsewhere (e.g. to compare a regeneration with the committed fixtures)
+_MODS = ()
+
+
 def save(name, **arrs):
-    path = os.path.join(HERE, name)
+    check_is_reference(_MODS)          # again at every write: a fixture is only ever the reference's output
+    if not _MODS:
+        raise RuntimeError("refusing to write fixtures: stage() has not run")
+    path = os.path.join(OUT, name)
     np.savez_compressed(path, **arrs, **versions())
     print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024))
 
@@ -383,9 +433,48 @@ def g8(simulations, optimals, pedestrians):
 
 ALL = dict(G1=g1, G234=g234, G5=g5, G6=g6, G7=g7, G8=g8)
 
+
+def compare(dir_a, dir_b):
+    """Array-by-array comparison of two fixture directories; returns the list of differences (empty = bit-identical)."""
+    bad = []
+    for f in sorted(x for x in os.listdir(dir_a) if x.endswith(".npz")):
+        if not os.path.exists(os.path.join(dir_b, f)):
+            bad.append("%s: missing" % f)
+            continue
+        a, b = np.load(os.path.join(dir_a, f), allow_pickle=False), np.load(os.path.join(dir_b, f), allow_pickle=False)
+        if sorted(a.files) != sorted(b.files):
+            bad.append("%s: different arrays" % f)
+            continue
+        for k in a.files:
+            if a[k].dtype.kind in "fc":
+                same = a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True)
+            else:
+                same = a[k].shape == b[k].shape and np.array_equal(a[k], b[k])
+            if not same:
+                bad.append("%s[%s]" % (f, k))
+    return bad
+
+
 if __name__ == "__main__":
-    mods = stage()
-    which = sys.argv[1:] or list(ALL)
+    args = sys.argv[1:]
+    if "--out" in args:
+        i = args.index("--out")
+        OUT = os.path.abspath(args[i + 1])
+        os.makedirs(OUT, exist_ok=True)
+        del args[i:i + 2]
+    check = "--check" in args          # regenerate into --out (default: a scratch directory) and compare with tests/golden
+    if check:
+        args.remove("--check")
+        if OUT == HERE:
+            OUT = "/tmp/oc_goldens_regen"
+            os.makedirs(OUT, exist_ok=True)
+    _MODS = stage()
+    print("reference modules:", ", ".join(m.__file__ for m in _MODS))
+    which = args or list(ALL)
     for w in which:
         print("==", w)
-        ALL[w](*mods)
+        ALL[w](*_MODS)
+    if check:
+        bad = compare(OUT, HERE)
+        print("regenerated fixtures vs committed:", "bit-identical" if not bad else "DIFFERENT: " + ", ".join(bad))
+        sys.exit(1 if bad else 0)
