@@ -28,7 +28,7 @@ extern "C" {
 
 #define OC_ABI_VERSION 1
 
-typedef enum { OC_OK = 0, OC_ERR_ARG = -1, OC_ERR_HIP = -2, OC_ERR_STATE = -3, OC_ERR_SOLVER = -4 } oc_status;
+typedef enum { OC_OK = 0, OC_ERR_ARG = -1, OC_ERR_HIP = -2, OC_ERR_STATE = -3, OC_ERR_SOLVER = -4, OC_ERR_CAPACITY = -5 } oc_status;
 typedef enum { OC_F32 = 0, OC_F64 = 1, OC_F64_F32 = 2 } oc_dtype;
 
 typedef struct oc_handle oc_handle;
@@ -130,6 +130,43 @@ int oc_hjb_solve_rows(oc_handle* h, int dtype, const void* coef_rows, double T, 
                       const int32_t* keep_idx, int32_t n_keep, double* phi_keep,
                       oc_hjb_stats* stats, void* stream);
 
+/* ---- the interpolant ring: the direction field evaluated where it is looked up ---------------------------------------
+ * The reference fills every slice of vx_opt / vy_opt because NumPy has to (optimals.py:200-204), but step() reads ONE
+ * slice per step and only one or two cells of it per agent (optimals.py:231-248), and with recompute=True every re-solve
+ * overwrites ~950 slices of which 50 were looked up (simulations.py:432-435).  oc_hjb_solve_ring runs the same solve as
+ * oc_hjb_solve and keeps, instead of slices, what SciPy's dense output of each ACCEPTED step is made of (rk.py:178-180,
+ * 560-575): y_old, Q0 = K0, Q1 .. Q3 -- five values per cell and step (2048^2, T = 20: 93 steps x 5 arrays = 7.8 GB per
+ * key instead of 999 slices x 2 = 33.5 GB, and no extra array pass at all: the stage launch stores them in the place of
+ * Q1 .. Q3) -- plus a table slice -> (step, h x^1..4).  oc_set_field_ring registers it for the agent step, whose lookups
+ * then evaluate phi(t_eval) at the cell and its four neighbours and `vels` (optimals.py:168-186) on the spot, with the FMA
+ * chain of the slice writer: bit-identical to looking the value up in the slices oc_hjb_solve writes.
+ * oc_hjb_ring_slices materialises slices from a ring with the slice writer itself (for optimals.vx_opt / tests).
+ *   data : `dtype` state values, slots * oc_hjb_ring_slot_elems(rows) of them (OC_F64_F32: float64)
+ *   meta : oc_hjb_ring_meta_bytes(...) bytes (per-slot records, the slice table, tile flags of the exact active set)
+ *   slots: capacity in accepted steps (oc_hjb_ring_slots_hint); a solve that needs more returns OC_ERR_CAPACITY
+ *   nslice: slices the table covers (nt0 - 1);  rows: grid rows held (Ny, or Ny_local of a row block)
+ * Needs Nx % 4 == 0.  All three buffers are device memory owned by the caller. */
+typedef struct oc_hjb_ring {
+    void* data;
+    void* meta;
+    int32_t slots, nslice, rows, reserved;
+} oc_hjb_ring;
+int64_t oc_hjb_ring_slot_elems(const oc_handle* h, int32_t rows);
+int64_t oc_hjb_ring_meta_bytes(const oc_handle* h, int dtype, int32_t slots, int32_t nslice, int32_t rows);
+int32_t oc_hjb_ring_slots_hint(const oc_handle* h, double T);
+/* oc_hjb_solve / oc_hjb_solve_rows with a ring in the place of vx_out / vy_out (same arguments otherwise; phi_keep is
+ * produced from the ring after the solve). */
+int oc_hjb_solve_ring(oc_handle* h, int dtype, const void* coef, double T, int32_t nt, const oc_hjb_ring* ring,
+                      const int32_t* keep_idx, int32_t n_keep, double* phi_keep,
+                      double* t_steps, int32_t t_steps_cap, oc_hjb_stats* stats, void* stream);
+int oc_hjb_solve_rows_ring(oc_handle* h, int dtype, const void* coef_rows, double T, int32_t nt, const oc_hjb_ring* ring,
+                           const oc_hjb_shard* shard, const int32_t* keep_idx, int32_t n_keep, double* phi_keep,
+                           oc_hjb_stats* stats, void* stream);
+/* Slices [s_lo, s_hi) (s_hi <= nt - 1 of the ring's solve) as oc_hjb_solve would have written them: vx_out / vy_out are
+ * (s_hi - s_lo, rows, Nx) of the field type of `dtype` (OC_F32 / OC_F64_F32: float32, OC_F64: float64).  Synchronises. */
+int oc_hjb_ring_slices(oc_handle* h, int dtype, const oc_hjb_ring* ring, int32_t s_lo, int32_t s_hi, void* vx_out,
+                       void* vy_out, void* stream);
+
 /* Direction field of one phi (float64 input (Ny,Nx), dtype output padded (Ny,Nx)): replaces `vels`, optimals.py:168-186. */
 int oc_hjb_vels(oc_handle* h, int dtype, const void* phi, double scale, void* vx, void* vy, void* stream);
 
@@ -143,6 +180,12 @@ int oc_set_field(oc_handle* h, int key, int dtype, const void* vx, const void* v
  * oc_gcfm_step_sharded.  simulations.py:281 / optimals.py:212-250 on a domain-decomposed field. */
 int oc_set_field_rows(oc_handle* h, int key, int dtype, const void* vx, const void* vy, int32_t nslice_alloc,
                       int32_t nt_opt, int32_t row0, int32_t rows, int32_t own_lo, int32_t own_hi);
+/* The same with an interpolant ring (oc_hjb_solve_ring / oc_hjb_solve_rows_ring, `dtype` as passed there) in the place of
+ * the slices: optimals.py:231-248 reads slice simu_step -- here that slice's value is evaluated from the ring.  row0 < 0:
+ * the ring covers the whole grid; else it is the row block [row0, row0 + ring->rows) and this rank answers the lookups
+ * whose first cell lies in grid rows [own_lo, own_hi), as with oc_set_field_rows. */
+int oc_set_field_ring(oc_handle* h, int key, int dtype, const oc_hjb_ring* ring, int32_t nt_opt, int32_t row0,
+                      int32_t own_lo, int32_t own_hi);
 /* Exit rectangles (cx,cy,w,h) of a key's possible targets: pedestrians.py:132-136. rects: HOST (n,4) float64. */
 int oc_set_key_targets(oc_handle* h, int key, const double* rects, int32_t n);
 /* Room description -> potential on the grid: replaces simulation.create_potential (simulations.py:516-576) and, with
@@ -234,7 +277,8 @@ int oc_density(oc_handle* h, int dtype, const oc_agents* a, double sigma, const 
 /* With profiling enabled every launch of a named kernel class is bracketed by HIP events on its own stream.
  * oc_kernel_stats returns, since the last reset: number of launches, summed event time (ms) and summed
  * bytes the launch is DESIGNED to move (DESIGN.md section "Rooflines").  Classes: "hjb_stage" (the stage launch(es) of
- * one RK attempt: 9 array passes), "hjb_out" (dense output + direction-field writer), "gcfm_forces", "gcfm_finish" (the
+ * one RK attempt: 8 array passes -- 3 read, 5 written; with the interpolant ring 10 -- 3 read, 7 written), "hjb_list" (ring solves:
+ * the work-list builder's launch), "hjb_out" (dense output + direction-field writer), "gcfm_forces", "gcfm_finish" (the
  * two launches of a step), "density".  The HJB classes are sampled (every 8th attempt).  Synchronises. */
 /* mode bits: 1 = HJB kernels, 2 = GCFM kernels every step, 4 = GCFM kernels every 16th step; 0 = off */
 int oc_set_profiling(oc_handle* h, int mode);

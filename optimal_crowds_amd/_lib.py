@@ -60,6 +60,15 @@ class OcHjbShard(C.Structure):
     ]
 
 
+class OcHjbRing(C.Structure):
+    """oc_hip.h: oc_hjb_ring -- the interpolant ring of one key (device buffers owned by the caller)"""
+    _fields_ = [("data", C.c_void_p), ("meta", C.c_void_p),
+                ("slots", C.c_int32), ("nslice", C.c_int32), ("rows", C.c_int32), ("reserved", C.c_int32)]
+
+
+OC_ERR_CAPACITY = -5
+
+
 class OcAgents(C.Structure):
     _fields_ = [
         ("N", C.c_int32),
@@ -82,6 +91,19 @@ SIGNATURES = {
     "oc_hjb_solve_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.POINTER(OcHjbShard), C.c_void_p, C.c_int32, C.c_void_p,
                                     C.POINTER(OcHjbStats), C.c_void_p]),
+    "oc_hjb_ring_slot_elems": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "oc_hjb_ring_meta_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_int32]),
+    "oc_hjb_ring_slots_hint": (C.c_int32, [C.c_void_p, C.c_double]),
+    "oc_hjb_solve_ring": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int32, C.POINTER(OcHjbRing),
+                                    C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                    C.POINTER(OcHjbStats), C.c_void_p]),
+    "oc_hjb_solve_rows_ring": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int32, C.POINTER(OcHjbRing),
+                                         C.POINTER(OcHjbShard), C.c_void_p, C.c_int32, C.c_void_p,
+                                         C.POINTER(OcHjbStats), C.c_void_p]),
+    "oc_hjb_ring_slices": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(OcHjbRing), C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "oc_set_field_ring": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(OcHjbRing), C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32]),
     "oc_hjb_vels": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "oc_set_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "oc_set_field_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

@@ -37,6 +37,13 @@ struct KeyDev {
     double edt_cap;
     int32_t dtype, nslice_alloc, nt_opt, nrect;
     int32_t row0, rows, own_lo, own_hi;     // row block of the field held here / grid rows whose lookups are answered here
+    // interpolant ring in the place of the slices (oc_set_field_ring; layout: oc_internal.h)
+    const void* ring_data;                  // NULL: slices (vx, vy)
+    const void* ring_slots;                 // OcRingSlot<T> [slots]
+    const void* ring_slices;                // OcRingSlice<T> [nslice]
+    const uint8_t* ring_flags;              // [slots][ring_ntile]
+    int64_t ring_slot_elems;
+    int32_t ring_state_dtype, ring_ntile, ring_tnbx, ring_pad;
     double rect[OC_MAX_TARGET_RECTS][4];
 };
 
@@ -49,6 +56,7 @@ struct GcfmParams {
     double cell;        // coarse cell size for ordering
     double drift;       // D: how far a tile box may grow beyond its sort-time box before the lists are invalid
     int32_t ncx, ncy, horder;
+    double mu, lim;     // hjb mu and the clip level lim (optimals.py:95): `vels` evaluated from the interpolant ring
     uint32_t fix;       // OC_FIX_* bits (oc_set_fix_flags); 0 = the reference's behaviour
     uint32_t diag;      // diagnostic builds of k_forces (oc_set_tuning "diag"): 1 = no phase 2, 2 = no prep work, 4 = no compaction either
 };
@@ -1019,6 +1027,92 @@ __device__ __forceinline__ double2 field_fetch(const KeyDev& kd, int step, int i
     return make_double2((ax + bx) / 2, (ay + by) / 2);
 }
 
+// ---- the same values from the interpolant ring (oc_set_field_ring) -----------------------------------------------------
+// Slice `step` of the direction field is not in memory; what is: for the accepted RK step that contains the slice's time,
+// y_old, K0 and Q1 .. Q3 of every cell (OcRingSlot / blocks of 20 values per four cells) and the slice's four factors
+// h x^1..4 (OcRingSlice).  ring_dir evaluates phi at the cell and its four neighbours (scipy rk.py:560-575), clips it and
+// forms `vels` (optimals.py:168-186) exactly as the slice writer k_out does -- same operations in the same order on the
+// same inputs, so the result is the bit pattern a slice would hold.  A stage tile that was trivial in the accepted attempt
+// (exact active set: phi one constant u on the tile, every derivative zero) stored nothing: its cells read (u, 0, 0, 0, 0).
+template <typename T>
+struct RingCtx {
+    const T* slot;              // the slot's data
+    const uint8_t* flags;       // its tile flags, or NULL (every tile holds data)
+    T h1, h2, h3, h4, lim_s, u;
+    T lim, mu, inv2dx, inv2dy;
+    int rows, row0, Nx, tnbx;
+};
+
+template <typename T>
+__device__ __forceinline__ RingCtx<T> ring_open(const GcfmParams& P, const KeyDev& kd, int step) {
+    RingCtx<T> c;
+    const OcRingSlice<T> sl = ((const OcRingSlice<T>*)kd.ring_slices)[step];
+    const OcRingSlot<T> rs = ((const OcRingSlot<T>*)kd.ring_slots)[sl.slot];
+    c.slot = (const T*)kd.ring_data + (size_t)sl.slot * (size_t)kd.ring_slot_elems;
+    c.flags = rs.dense ? nullptr : kd.ring_flags + (size_t)sl.slot * kd.ring_ntile;
+    c.h1 = sl.h[0]; c.h2 = sl.h[1]; c.h3 = sl.h[2]; c.h4 = sl.h[3];
+    c.lim_s = rs.lim_s;
+    c.u = rs.u;
+    c.mu = (T)P.mu;
+    c.lim = (T)P.lim;
+    c.inv2dx = (T)(1.0 / (2 * P.dx));
+    c.inv2dy = (T)(1.0 / (2 * P.dy));
+    c.rows = kd.rows < 0 ? P.Ny : kd.rows;
+    c.row0 = kd.row0;
+    c.Nx = P.Nx;
+    c.tnbx = kd.ring_tnbx;
+    return c;
+}
+
+// clipped phi(t_eval) at LOCAL row r, column c (optimals.py:172)
+template <typename T>
+__device__ __forceinline__ T ring_phi(const RingCtx<T>& c, int r, int cc) {
+    T ph;
+    if (c.flags != nullptr && c.flags[(r / OC_RING_STY) * c.tnbx + cc / OC_RING_STX] != 0) {
+        ph = c.u;                       // (u + h (0 x + 0 x^2 + ...) = u)
+    } else {
+        const T* b = c.slot + ((size_t)r * c.Nx + cc >> 2) * (4 * OC_RING_VALS) + (cc & 3);
+        const T y = b[0], q0 = b[4], q1 = b[8], q2 = b[12], q3 = b[16];
+        ph = y + fma_t(q3, c.h4, fma_t(q2, c.h3, fma_t(q1, c.h2, q0 * c.h1)));
+    }
+    return (ph > c.lim_s) ? ph : ((ph < c.lim_s) ? c.lim_s : (T)0);
+}
+
+// the direction field's value at padded grid cell (global row gr, column gc), as float64 of what a slice of type TO holds
+template <typename T, typename TO>
+__device__ __forceinline__ double2 ring_dir(const RingCtx<T>& c, int Ny, int gr, int gc) {
+    const int r = gr - c.row0;
+    if (r < 1 || r >= c.rows - 1 || gc < 1 || gc >= c.Nx - 1) return make_double2(0.0, 0.0);   // the slices' border ring
+    const T pw = ring_phi(c, r, gc - 1), pe = ring_phi(c, r, gc + 1);
+    const T ps = ring_phi(c, r - 1, gc), pn = ring_phi(c, r + 1, gc);
+    const T p0 = ring_phi(c, r, gc);
+    const T pc = (p0 > c.lim_s) ? p0 : ((p0 < c.lim_s) ? c.lim_s : (T)0);     // the reference clips the centre twice (:177)
+    const T gx = (pe - pw) * c.inv2dx, gy = (pn - ps) * c.inv2dy;
+    T ox, oy;
+    direction_of<T>(gx, gy, c.mu * pc, c.lim, ox, oy);
+    return make_double2((double)(TO)ox, (double)(TO)oy);
+}
+
+template <typename T, typename TO>
+__device__ __forceinline__ double2 ring_fetch(const GcfmParams& P, const KeyDev& kd, int step, int i0, int i1, int j0,
+                                              int j1) {
+    // interior index i of the reference's (Ny-2, Nx-2) array is grid row i + 1 (field_fetch)
+    const RingCtx<T> c = ring_open<T>(P, kd, step);
+    const double2 a = ring_dir<T, TO>(c, P.Ny, i0 + 1, j0 + 1), b = ring_dir<T, TO>(c, P.Ny, i1 + 1, j1 + 1);
+    return make_double2((a.x + b.x) / 2, (a.y + b.y) / 2);
+}
+
+template <typename T, typename TO>
+__device__ __forceinline__ double2 ring_bilinear(const GcfmParams& P, const KeyDev& kd, int step, int r0, int r1, int c0,
+                                                 int c1, double fy, double fx) {
+    const RingCtx<T> c = ring_open<T>(P, kd, step);
+    const double2 g00 = ring_dir<T, TO>(c, P.Ny, r0, c0), g01 = ring_dir<T, TO>(c, P.Ny, r0, c1);
+    const double2 g10 = ring_dir<T, TO>(c, P.Ny, r1, c0), g11 = ring_dir<T, TO>(c, P.Ny, r1, c1);
+    const double w00 = (1.0 - fy) * (1.0 - fx), w01 = (1.0 - fy) * fx, w10 = fy * (1.0 - fx), w11 = fy * fx;
+    return make_double2(w00 * g00.x + w01 * g01.x + w10 * g10.x + w11 * g11.x,
+                        w00 * g00.y + w01 * g01.y + w10 * g10.y + w11 * g11.y);
+}
+
 // OC_FIX_LOOKUP: the four grid nodes (r0|r1, c0|c1) around the position, weights (1-fy|fy) x (1-fx|fx); the padded
 // slices are indexed by grid row and column directly
 template <typename T>
@@ -1054,8 +1148,15 @@ __device__ __forceinline__ double2 lookup_bilinear(const GcfmParams& P, const Ke
     split(y / (P.H / (Ny - 1)), Ny, r0, r1, fy);
     if (r0 < kd.own_lo || r0 >= kd.own_hi) return make_double2(0.0, 0.0);       // another rank's rows
     if (kd.rows >= 0 && (r1 < kd.row0 || r1 >= kd.row0 + kd.rows)) r1 = r0;
-    const double2 d = (kd.dtype == OC_F32) ? field_bilinear<float>(kd, step, r0, r1, c0, c1, fy, fx, Nx, Ny)
-                                           : field_bilinear<double>(kd, step, r0, r1, c0, c1, fy, fx, Nx, Ny);
+    double2 d;
+    if (kd.ring_data != nullptr) {
+        if (kd.ring_state_dtype == OC_F32) d = ring_bilinear<float, float>(P, kd, step, r0, r1, c0, c1, fy, fx);
+        else if (kd.dtype == OC_F32) d = ring_bilinear<double, float>(P, kd, step, r0, r1, c0, c1, fy, fx);
+        else d = ring_bilinear<double, double>(P, kd, step, r0, r1, c0, c1, fy, fx);
+    } else {
+        d = (kd.dtype == OC_F32) ? field_bilinear<float>(kd, step, r0, r1, c0, c1, fy, fx, Nx, Ny)
+                                 : field_bilinear<double>(kd, step, r0, r1, c0, c1, fy, fx, Nx, Ny);
+    }
     return make_double2(vdes * d.x, vdes * d.y);
 }
 
@@ -1097,8 +1198,15 @@ __device__ __forceinline__ double2 lookup(const GcfmParams& P, const KeyDev& kd,
     if (i0 + 1 < kd.own_lo || i0 + 1 >= kd.own_hi) return make_double2(0.0, 0.0);
     if (kd.rows >= 0 && (i1 + 1 < kd.row0 || i1 + 1 >= kd.row0 + kd.rows)) i1 = i0;   // (a wrapped negative index of an
                                                                                       // agent outside the room)
-    double2 d = (kd.dtype == OC_F32) ? field_fetch<float>(kd, step, i0, i1, j0, j1, Nx, Ny)
-                                     : field_fetch<double>(kd, step, i0, i1, j0, j1, Nx, Ny);
+    double2 d;
+    if (kd.ring_data != nullptr) {
+        if (kd.ring_state_dtype == OC_F32) d = ring_fetch<float, float>(P, kd, step, i0, i1, j0, j1);
+        else if (kd.dtype == OC_F32) d = ring_fetch<double, float>(P, kd, step, i0, i1, j0, j1);
+        else d = ring_fetch<double, double>(P, kd, step, i0, i1, j0, j1);
+    } else {
+        d = (kd.dtype == OC_F32) ? field_fetch<float>(kd, step, i0, i1, j0, j1, Nx, Ny)
+                                 : field_fetch<double>(kd, step, i0, i1, j0, j1, Nx, Ny);
+    }
     return make_double2(vdes * d.x, vdes * d.y);
 }
 
@@ -1549,6 +1657,8 @@ GcfmParams make_params(const oc_handle* h) {
         P.ncx = (int)(c.room_length / P.cell) + 1;
         P.ncy = (int)(c.room_height / P.cell) + 1;
     }
+    P.mu = c.mu;
+    P.lim = c.lim;
     P.fix = h->fix_flags;
     P.diag = (uint32_t)h->diag;
     P.horder = 1;
@@ -1631,7 +1741,21 @@ int upload_keys(oc_handle* h, hipStream_t s) {
         d.vy = h->fields[k].vy;
         d.dtype = h->fields[k].dtype;
         d.nslice_alloc = h->fields[k].nslice_alloc;
-        d.nt_opt = h->fields[k].vx ? h->fields[k].nt_opt : 0;
+        d.nt_opt = (h->fields[k].vx || h->fields[k].ring_data) ? h->fields[k].nt_opt : 0;
+        if (h->fields[k].ring_data) {
+            const oc_field_desc& f = h->fields[k];
+            const size_t ts = f.ring_state_dtype == OC_F32 ? 4 : 8;
+            const int rows = f.rows < 0 ? h->cfg.Ny : f.rows;
+            const char* m = (const char*)f.ring_meta;
+            d.ring_data = f.ring_data;
+            d.ring_slots = m + oc_ring_slots_off();
+            d.ring_slices = m + oc_ring_slices_off(ts, f.ring_slots);
+            d.ring_flags = (const uint8_t*)(m + oc_ring_flags_off(ts, f.ring_slots, f.nslice_alloc));
+            d.ring_slot_elems = (int64_t)OC_RING_VALS * rows * h->cfg.Nx;
+            d.ring_state_dtype = f.ring_state_dtype;
+            d.ring_ntile = oc_ring_ntile(rows, h->cfg.Nx);
+            d.ring_tnbx = (h->cfg.Nx + OC_RING_STX - 1) / OC_RING_STX;
+        }
         d.row0 = h->fields[k].row0;
         d.rows = h->fields[k].rows;
         d.own_lo = h->fields[k].own_lo;
@@ -2037,7 +2161,7 @@ extern "C" int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t si
     // some key -- every rank walks all tiles and the holder of the field rows answers; with every field whole on every
     // rank the tile's owner does
     bool rows = false;
-    for (const auto& f : h->fields) rows = rows || f.rows >= 0 || f.vx == nullptr;
+    for (const auto& f : h->fields) rows = rows || f.rows >= 0 || (f.vx == nullptr && f.ring_data == nullptr);
     const TileShare mine = {(int32_t)((int64_t)S.ntiles * rank / world), (int32_t)((int64_t)S.ntiles * (rank + 1) / world), 0,
                             rows ? 1 : 0};
     return launch_step(h, a, S, P, simu_step, noise, seed, counters, mine, allreduce_sum, user, xchg, rank, s);

@@ -142,12 +142,6 @@ __host__ __device__ inline double ctl_te(const HjbCtl<T>& c, int k) {      // np
     return (k == c.nt - 1) ? 0.0 : (double)k * c.te_step + c.Tfinal;
 }
 
-// Fused multiply-add, written out: the library is compiled with -ffp-contract=off (the float64 index decisions of the
-// agent step must round like NumPy), so the HJB kernels ask for their FMAs explicitly -- ALL variants in the same
-// places, so that they stay bit-identical to each other: a_0 k_0 + a_1 k_1 + ... is one rounding per term instead of two.
-__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
-
 template <typename T>
 struct Lin8 {   // out = base + sum_j c[j] * K[j]
     const T* k[8];
@@ -347,7 +341,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, const double* parts,
                                                  int nparts, double* __restrict__ t_steps, int t_cap,
                                                  int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox,
-                                                 int active_set = 0) {
+                                                 int active_set = 0, OcRingSlot<T>* __restrict__ rslots = nullptr,
+                                                 OcRingSlice<T>* __restrict__ rslices = nullptr, int ring_cap = 0) {
     // the controller block is worked on in LDS (one coalesced load, one coalesced store): thread 0's serial code would
     // otherwise pay a memory round trip for every field it touches
     __shared__ HjbCtl<T> c;
@@ -447,7 +442,30 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
                 }
                 c.rejected = 0;
                 logw |= 2 | (nv << 8);
-                if (-(c.t - c.tf) >= 0) c.done = 1; // direction = -1
+                bool ring_full = false;
+                if (rslots != nullptr) {            // interpolant ring: what the step's dense output is made of stays in slot
+                    const int slot = c.n_accept - 1;            // n_accept - 1 (the stage launch wrote y, K0, Q1 .. Q3 there)
+                    if (slot >= ring_cap) {
+                        ring_full = true;
+                    } else {
+                        OcRingSlot<T> rs;
+                        rs.out_t = c.out_t;
+                        rs.out_hh = c.out_hh;
+                        rs.out_unscale = c.out_unscale;
+                        rs.k_lo = c.k_lo;
+                        rs.k_hi = c.k_hi;
+                        rs.dense = (active_set == 0 || c.dense_mode != 0) ? 1 : 0;
+                        rs.pad = 0;
+                        rs.lim_s = c.out_lim_s;
+                        rs.u = c.u_bg;              // the far field's y in the step's own scale (in_scale applied above)
+                        rslots[slot] = rs;
+                    }
+                }
+                if (ring_full) {
+                    c.status = OC_ERR_SOLVER - 200; // more accepted steps than ring slots: the caller retries with a larger ring
+                    c.accepted = 0;
+                    c.done = 1;
+                } else if (-(c.t - c.tf) >= 0) c.done = 1; // direction = -1
                 else ctl_prepare_step(c, true);
             } else {
                 c.h_abs *= fmax(0.2, 0.9 * pow(err, -0.2));
@@ -471,6 +489,25 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
         for (int pp = 0; pp < 4; ++pp) {
             c.hx[q][pp] = (T)(c.out_hh * xp);
             xp *= x;
+        }
+    }
+    // interpolant ring: the slice table -- for every t_eval point of the accepted step its slot and the same four factors
+    // (slice nt - 1 - k <-> t_eval[k], optimals.py:200-204; k = 0 is never looked up)
+    if (rslices != nullptr && c.accepted && threadIdx.x >= 64) {
+        const int slot = c.n_accept - 1;
+        for (int q = (int)threadIdx.x - 64; q < c.k_hi - c.k_lo; q += (int)blockDim.x - 64) {
+            const int k = c.k_lo + q;
+            if (k < 1) continue;
+            const double x = (ctl_te(c, k) - c.out_t) / c.out_hh;
+            double xp = x;
+            OcRingSlice<T> e;
+            e.slot = slot;
+            e.pad = 0;
+            for (int pp = 0; pp < 4; ++pp) {
+                e.h[pp] = (T)(c.out_hh * xp);
+                xp *= x;
+            }
+            rslices[c.nt - 1 - k] = e;
         }
     }
     // ---- active set: the next attempt's work list is built by block 0 of the k_out launch that follows (beside the output
@@ -497,35 +534,6 @@ __global__ void k_dense(const T* __restrict__ yold, Lin8<T> W /* c_j = h * sum_p
     T v = yold[i] + acc;
     if (out) out[i] = v;
     if (keep) keep[i] = (double)v * unscale;
-}
-
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
-__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ double fast_rsq(double x) { return 1.0 / sqrt(x); }
-
-// Unit-or-zero direction of v = grad/(mu*phi_c) (optimals.py:179-186) without forming v: in float32 the ratio
-// overflows next to walls late in the solve (|grad| ~ 2^64 against phi_c = lim*2^-e), although its direction and
-// the decision |v| > lim are perfectly representable.  |v| > lim  <=>  m*nn > lim*mu*phi_c with m = max(|gx|,|gy|),
-// nn = |(gx,gy)/m| in [1, sqrt 2].  (|v| == lim, 0/0 in the reference, is treated as "not greater": zero.)
-template <typename T>
-__device__ __forceinline__ void direction_of(T gx, T gy, T mupc, T lim, T& ox, T& oy) {
-    const T m = fmax(fabs(gx), fabs(gy));
-    ox = (T)0;
-    oy = (T)0;
-    if (m > (T)0) {
-        const T im = fast_rcp(m);
-        const T ax = gx * im, ay = gy * im;
-        const T n2 = ax * ax + ay * ay;          // in [1, 2]
-        const T inn = fast_rsq(n2);
-        if (m * (n2 * inn) > lim * mupc) {
-            ox = ax * inn;
-            oy = ay * inn;
-        }
-    } else if (m != m) {                 // NaN input stays visible
-        ox = m;
-        oy = m;
-    }
 }
 
 // vels (optimals.py:168-186) on a phi carried as phi*scale: lim -> lim*scale; everything else is a ratio.
@@ -741,6 +749,12 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     const int32_t* flags_prev;      // the previous attempt's flags (NULL at the first attempt)
     int32_t* flags_cur;
     const int32_t* work;            // the attempt's work list (ctl->work_count tiles, build_work_list), or NULL: every tile
+    // interpolant ring (RING kernels): y, K0, Q1 .. Q3 of the step go to slot ctl->n_accept (blocks of 20 values per four
+    // cells, oc_internal.h) instead of Q1 .. Q3 to KM -- an attempt that is rejected is overwritten by the next one
+    T* ring;
+    size_t ring_slot_elems;         // 5 * rows * Nx
+    uint8_t* ring_flags;            // [cap][ntile]: 1 = the tile was trivial in the slot's attempt (nothing stored for it)
+    int32_t ring_cap, ring_ntile;
 };
 
 // value of the previous / next lane of the wavefront (DPP wave shifts: no LDS traffic; lane 0 / 63 get 0)
@@ -788,8 +802,9 @@ __device__ __forceinline__ bool is_pow2(double v) {
 //   NQ = 3: two launches per attempt (A: K1..K3 from y, K0; B: Q1..Q3, y_new, K6 + error), region 128 x 32 -> tile 120 x 26
 //   NQ = 6: one launch (writes Q1..Q3, K6, y_new: 3 arrays read, 5 written), region 128 x 32 -> tile 112 x 20
 // Same arithmetic per cell as k_stage (one stage per launch, the cross-check variant): bit-identical results.
-template <typename T, int NQ, int S0, bool FINAL, int RWV, int RH>
+template <typename T, int NQ, int S0, bool FINAL, int RWV, int RH, bool RING = false>
 __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Stage3Args<T> A) {      // float: 64 VGPRs, two blocks per CU
+    static_assert(!RING || (NQ == 6 && FINAL), "the ring is written by the one-launch attempt");
     constexpr int HX = 4 * ((NQ + 3) / 4), HY = NQ, RW = 4 * RWV, NT = RWV * RH;
     constexpr int TX = RW - 2 * HX, TY = RH - 2 * HY, LS = RW + 8;
     constexpr int NK = S0 + NQ;                     // stage derivatives alive at the end of the launch
@@ -826,6 +841,8 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     const int gi = (logical / nbx) * TY - HY + ry, gj = (logical % nbx) * TX - HX + 4 * vx;
     const bool in = gi >= 0 && gi < Ny && gj >= 0 && gj < Nx;      // (Nx % 4 == 0: a vector is inside or outside as a whole)
     const int64_t idx = (int64_t)gi * Nx + gj;
+    const int rslot = RING ? ctl->n_accept : 0;                     // the ring slot of the step this attempt tries
+    const bool ring_ok = RING && rslot < A.ring_cap;                // (beyond the capacity k_control ends the solve)
     // The thread's four cells as two PAIRS: float pairs are packed-math operands (v_pk_fma_f32 / v_pk_add_f32 /
     // v_pk_mul_f32: one instruction for two cells -- the launch is bound by VALU issue, 71 % busy before this), double
     // pairs compile to two scalar operations each.  Same IEEE operations per cell either way.
@@ -905,9 +922,11 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                     z.v[q] = (T)0;
                     uu.v[q] = un;
                 }
-                st4(A.KM[1] + idx, z);
-                st4(A.KM[2] + idx, z);
-                st4(A.KM[3] + idx, z);
+                if (!RING) {                    // (Q1 .. Q3 of a trivial tile: with the ring its flag says "all zero")
+                    st4(A.KM[1] + idx, z);
+                    st4(A.KM[2] + idx, z);
+                    st4(A.KM[3] + idx, z);
+                }
                 st4(A.KX[par ^ 1] + idx, z);
                 st4(ynew + idx, uu);
             }
@@ -916,10 +935,14 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                 A.partial[2 * logical] = 0.0;
                 A.partial[2 * logical + 1] = (r_hi > A.row_lo && r_lo < A.row_hi) ? (double)fabs(un) : 0.0;
                 A.flags_cur[logical] = 1;
+                if (ring_ok) A.ring_flags[(size_t)rslot * A.ring_ntile + logical] = 1;
             }
             return;
         }
-        if (threadIdx.x == 0) A.flags_cur[logical] = 0;
+        if (threadIdx.x == 0) {
+            A.flags_cur[logical] = 0;
+            if (ring_ok) A.ring_flags[(size_t)rslot * A.ring_ntile + logical] = 0;
+        }
     }
     T* const slot0 = &buf[0][ry + 1][4 + 4 * vx];
     constexpr int BUF = (RH + 2) * LS;              // elements between the two buffers
@@ -980,7 +1003,14 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             // e_0 (Q0 = K0, already in memory), row 1 is zero: the three columns Q1 .. Q3 are formed here, where every
             // K_j of the cell is in a register, and take the place of K2 .. K5 in memory -- one array pass less for this
             // launch, and k_out reads y + 4 arrays instead of y + 6.  (Same FMA chain as interp_coeffs: bit-identical.)
+            // RING: y (its pending rescale applied, as k_out applies it), K0 and Q1 .. Q3 go to the step's ring slot instead
+            // -- 20 consecutive values per thread -- and nothing reads them before a lookup or the slice writer does.
             constexpr int rows[6] = {0, 2, 3, 4, 5, 6};
+            T* const rb = RING ? A.ring + (size_t)rslot * A.ring_slot_elems + (size_t)idx * OC_RING_VALS : nullptr;
+            if (RING && ring_ok) {
+                st4_nt(rb, quad(yv[0], yv[1]));
+                st4_nt(rb + 4, quad(kv[0][0], kv[0][1]));
+            }
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp) {
                 T2 q0 = zero2, q1 = zero2;
@@ -990,7 +1020,8 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                     q0 = __builtin_elementwise_fma(kv[rows[j]][0], p2, q0);
                     q1 = __builtin_elementwise_fma(kv[rows[j]][1], p2, q1);
                 }
-                st4(A.KM[1 + pp] + idx, quad(q0, q1));
+                if (!RING) st4(A.KM[1 + pp] + idx, quad(q0, q1));
+                else if (ring_ok) st4_nt(rb + 8 + 4 * pp, quad(q0, q1));
             }
             st4(A.KX[par ^ 1] + idx, quad(kv[NK - 1][0], kv[NK - 1][1]));     // K6 = the next step's K0 (FSAL)
         } else {
@@ -1063,11 +1094,34 @@ struct OutArgs {
     int32_t* flags_next;
     int32_t* work;
     double* parts_rw;
+    const T* ring_slot;     // RING: the slot's data (k_ring_ctl filled ctl from its record)
 };
 
-template <typename T, bool QIN>
+template <typename T, bool QIN, bool RING = false>
 __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* const (&k)[6], const T (&P)[6][4],
                                               T in_scale, int64_t idx, int n, V4<T>& yq, V4<T> (&Q)[4]) {
+    if (RING) {
+        // y = a ring slot (blocks of y[4], K0[4], Q1[4], Q2[4], Q3[4] per four cells, oc_internal.h): the values k_stageV
+        // stored, the rescale already applied -- what the other branch holds after its loads and multiplications
+        if (n == 4) {
+            const T* b = y + idx * OC_RING_VALS;
+            yq = ld4(b);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) Q[pp] = ld4(b + 4 + 4 * pp);
+        } else {
+            const T* b = y + (idx >> 2) * (4 * OC_RING_VALS) + (idx & 3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) yq.v[q] = (T)0;
+            yq.v[0] = b[0];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Q[pp].v[q] = (T)0;
+                Q[pp].v[0] = b[4 + 4 * pp];
+            }
+        }
+        return;
+    }
     // n = 4: one vector of cells, n = 1: a single cell (element 0).  y and K0 (k[0]) carry the step's pending rescale
     // (HjbCtl).  Q[pp].v[q]: coefficient pp of cell q.
     // QIN: k = {K0, Q1, Q2, Q3} -- the stage launch (k_stageV) already formed the columns of Q = K^T P (Q0 = K0);
@@ -1117,7 +1171,8 @@ __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* 
 template <typename T>
 __device__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __restrict__ flags_cur,
                                 int32_t* __restrict__ flags_next, int32_t* __restrict__ work, double* __restrict__ parts_rw,
-                                int tnbx, int tnby, uint8_t* sflag, int nbytes) {
+                                int tnbx, int tnby, uint8_t* sflag, int nbytes, uint8_t* __restrict__ ring_flags = nullptr,
+                                int ring_cap = 0) {
     __shared__ int32_t wsum[4];
     const int todo = ctl->list_todo, nth = (int)blockDim.x;
     if (todo == 0) return;
@@ -1126,6 +1181,9 @@ __device__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __re
         return;
     }
     const int ntile = tnbx * tnby;
+    // (interpolant ring: a tile left off the list is trivial in the next attempt -- flagged in that attempt's slot here,
+    // since no block will look at it)
+    uint8_t* const rf = (ring_flags != nullptr && ctl->n_accept < ring_cap) ? ring_flags + (size_t)ctl->n_accept * ntile : nullptr;
     const bool skip_ok = (ctl->rejected != 0 || (ctl->in_scale == (T)1 && ctl->out_in_scale == (T)1)) && ntile <= nbytes;
     // every thread owns a contiguous run of tiles (an ordered list keeps neighbouring tiles in neighbouring blocks)
     const int per_thr = (ntile + nth - 1) / nth, t_lo = min((int)threadIdx.x * per_thr, ntile), t_hi = min(t_lo + per_thr, ntile);
@@ -1181,15 +1239,86 @@ __device__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __re
             flags_next[t] = 1;
             parts_rw[2 * t] = 0.0;
             parts_rw[2 * t + 1] = 0.0;
+            if (rf) rf[t] = 1;
         }
     }
     if (threadIdx.x == 0) ctl->work_count = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// With the interpolant ring no k_out launch follows an attempt: the list builder is a launch of its own (one block).
+template <typename T>
+__global__ void __launch_bounds__(256) k_list(HjbCtl<T>* ctl, const int32_t* __restrict__ flags_cur,
+                                              int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
+                                              double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* ring_flags,
+                                              int ring_cap) {
+    __shared__ uint8_t sflag[16384];
+    build_work_list<T>(ctl, flags_cur, flags_next, work, parts_rw, tnbx, tnby, sflag, (int)sizeof(sflag), ring_flags, ring_cap);
+}
+
+// ---- slices from the ring (oc_hjb_ring_slices; the audit output phi_keep of a ring solve) ---------------------------
+// One slot at a time: k_ring_ctl turns the slot's record into the controller block k_out reads (the t_eval range clamped
+// to the slices [s_lo, s_hi) that were asked for), k_ring_fill writes (u, 0, 0, 0, 0) into the slot's stage tiles that
+// were trivial in the accepted attempt -- what k_stageV leaves in the state arrays of such a tile, and what a lookup
+// substitutes for it -- and k_out<.., RING> then runs exactly the arithmetic of the slice-writing solve.
+template <typename T>
+__global__ void k_ring_ctl(const OcRingHead* __restrict__ rh, const OcRingSlot<T>* __restrict__ rslots, int slot, int s_lo,
+                           int s_hi, HjbCtl<T>* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const OcRingSlot<T> rs = rslots[slot];
+    const int nt = rh->nt;
+    out->accepted = 0;
+    out->done = 0;
+    out->dense_mode = 1;
+    out->out_parity = 0;
+    out->nt = nt;
+    out->te_step = rh->te_step;
+    out->Tfinal = rh->Tfinal;
+    out->out_t = rs.out_t;
+    out->out_hh = rs.out_hh;
+    out->out_unscale = rs.out_unscale;
+    out->out_lim_s = rs.lim_s;
+    out->out_in_scale = (T)1;
+    out->u_bg = rs.u;
+    out->n_hx = 0;                                  // (k_out computes the slice factors itself: the same expression)
+    out->list_todo = 0;
+    // slice s <-> t_eval index k = nt - 1 - s: s in [s_lo, s_hi)  <=>  k in [nt - s_hi, nt - s_lo)
+    const int k_lo = max(rs.k_lo, nt - s_hi), k_hi = min(rs.k_hi, nt - s_lo);
+    out->k_lo = k_lo;
+    out->k_hi = k_hi;
+    out->work_count = rs.dense;                     // (borrowed: 1 = the slot has no trivial tiles to fill)
+    if (slot < rh->n_slots && k_lo < k_hi) out->accepted = 1;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_ring_fill(const HjbCtl<T>* __restrict__ ctl, T* __restrict__ slot_data,
+                                                   const uint8_t* __restrict__ slot_flags, int Ny, int Nx) {
+    if (!ctl->accepted || ctl->work_count != 0) return;
+    const int t = blockIdx.x;
+    if (slot_flags[t] == 0) return;
+    const int tnbx = (Nx + OC_RING_STX - 1) / OC_RING_STX;
+    const int r0 = (t / tnbx) * OC_RING_STY, c0 = (t % tnbx) * OC_RING_STX;
+    const T u = ctl->u_bg;
+    constexpr int VPR = OC_RING_STX / 4;            // vectors of four cells per tile row
+    for (int q = threadIdx.x; q < VPR * OC_RING_STY; q += blockDim.x) {
+        const int r = r0 + q / VPR, c = c0 + 4 * (q % VPR);
+        if (r >= Ny || c >= Nx) continue;
+        T* b = slot_data + ((size_t)r * Nx + c) * OC_RING_VALS;
+        V4<T> uu, z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uu.v[e] = u;
+            z.v[e] = (T)0;
+        }
+        st4(b, uu);
+#pragma unroll
+        for (int a = 1; a < OC_RING_VALS; ++a) st4(b + 4 * a, z);
+    }
+}
+
 // Tile = OX x OY cells with OX * OY = 1024 (256 threads x 4 consecutive cells of a row): 64 x 16, 128 x 8 or 256 x 4.  A
 // wider tile writes longer contiguous runs per row and slice (1 KB at 256 instead of 256 B), which is what counts where
 // the input arrays no longer come out of the Infinity Cache (4096 x 4096).
-template <typename T, int OX, typename TO, bool QIN>
+template <typename T, int OX, typename TO, bool QIN, bool RING = false>
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> A) {      // float: 4 waves per SIMD (at most 128 VGPRs)
     constexpr int OY = 1024 / OX, VW = OX / 4, OLS = OX + 8;
     __shared__ alignas(16) T tile[2][OY + 2][OLS];
@@ -1206,7 +1335,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> 
     const double t0 = ctl->out_t, hh = ctl->out_hh, unscale = ctl->out_unscale, te_step = ctl->te_step, Tf = ctl->Tfinal;
     const T lim_s = ctl->out_lim_s, in_scale = ctl->out_in_scale;
     const int n_hx = ctl->n_hx;
-    const T* __restrict__ y = A.Y[par];
+    const T* __restrict__ y = RING ? A.ring_slot : A.Y[par];       // (RING: everything comes from the slot's blocks)
     // K0, Q1 .. Q3 (left by k_stageV in the place of K2 .. K4)  /  K0, K2 .. K5, K6
     const T* const kk[6] = {A.KX[par], A.KM[1], A.KM[2], A.KM[3], QIN ? nullptr : A.KM[4], QIN ? nullptr : A.KX[par ^ 1]};
     const int cx = (int)threadIdx.x % VW, ry = (int)threadIdx.x / VW;
@@ -1245,7 +1374,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> 
         }
     }
     V4<T> yq, Q[4], hy, hQ[4];
-    if (valid) interp_coeffs<T, QIN>(y, kk, A.p, in_scale, idx, 4, yq, Q);
+    if (valid) interp_coeffs<T, QIN, RING>(y, kk, A.p, in_scale, idx, 4, yq, Q);
     // halo of the tile: threads 0 .. VW-1 the row above (a vector each), the next VW the row below, then OY threads the
     // column to the left and OY the column to the right (a cell each); cells outside the grid are never used
     HaloRole hr;
@@ -1260,7 +1389,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> 
         if (!(hr.gi >= 0 && hr.gi < Ny && hr.gj >= 0 && hr.gj < Nx)) hr.kind = 0;
     }
     const int hn = (hr.kind == 1 || hr.kind == 2) ? 4 : (hr.kind >= 3 ? 1 : 0);
-    if (hn) interp_coeffs<T, QIN>(y, kk, A.p, in_scale, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
+    if (hn) interp_coeffs<T, QIN, RING>(y, kk, A.p, in_scale, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
     auto clip = [&](T v) { return (v > lim_s) ? v : ((v < lim_s) ? lim_s : (T)0); };
     // the controller's per-slice factors: fetched once (a load from the controller block inside the slice loop would
     // put a memory round trip into every slice)
@@ -1273,7 +1402,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> 
     int it = 0;
     for (int k = k_lo; k < k_hi; ++k) {
         // t_eval[k] <-> slice nt - 1 - k of the field; k = 0 (phi = 1 at t = T) is never used (optimals.py:200-204)
-        const bool want_v = k >= 1;
+        const bool want_v = k >= 1 && A.vx_base != nullptr;
         double* keep = (A.keep_slot && A.keep_slot[k] >= 0) ? A.keep_base + (size_t)A.keep_slot[k] * ncell : nullptr;
         if (!want_v && !keep) continue;
         T h1, h2, h3, h4;
@@ -1381,15 +1510,83 @@ __global__ void k_halo_stage(const HjbCtl<T>* __restrict__ ctl, T* Y0, T* Y1, T*
 // k_out's tile: 128 x 8 cells while the step's input arrays fit the 256 MB Infinity Cache (C4: 6.18 TB/s against 5.69
 // with 64 x 16 and 6.04 with 256 x 4), 256 x 4 beyond (C5, 4096 x 4096: 5.44 TB/s against 4.59 / 5.11) -- or the caller's
 // choice (oc_set_tuning "out_tile").  QIN: the stage launch left Q1 .. Q3 (the product path); false: K2 .. K6.
-template <typename T, typename TO, bool QIN>
+template <typename T, typename TO, bool QIN, bool RING = false>
 void launch_out(int shape, int Nx, int Ny, hipStream_t s, const OutArgs<T>& OA) {
     if (shape < 0) shape = (5.0 * sizeof(T) * (double)Nx * Ny > 256e6) ? 2 : 1;
     const int ox = shape == 2 ? 256 : (shape == 1 ? 128 : 64), oy = 1024 / ox;
     const int nb = ((Nx + ox - 1) / ox) * ((Ny + oy - 1) / oy);
     const dim3 grid(8 * ((nb + 7) / 8) + (OA.work != nullptr ? 1 : 0));     // (+ block 0: the work-list builder)
-    if (shape == 2) hipLaunchKernelGGL((k_out<T, 256, TO, QIN>), grid, dim3(256), 0, s, OA);
-    else if (shape == 1) hipLaunchKernelGGL((k_out<T, 128, TO, QIN>), grid, dim3(256), 0, s, OA);
-    else hipLaunchKernelGGL((k_out<T, 64, TO, QIN>), grid, dim3(256), 0, s, OA);
+    if (shape == 2) hipLaunchKernelGGL((k_out<T, 256, TO, QIN, RING>), grid, dim3(256), 0, s, OA);
+    else if (shape == 1) hipLaunchKernelGGL((k_out<T, 128, TO, QIN, RING>), grid, dim3(256), 0, s, OA);
+    else hipLaunchKernelGGL((k_out<T, 64, TO, QIN, RING>), grid, dim3(256), 0, s, OA);
+}
+
+// typed views of a caller's ring (oc_hip.h: oc_hjb_ring; layout: oc_internal.h)
+template <typename T>
+struct RingView {
+    T* data;
+    OcRingHead* head;
+    OcRingSlot<T>* slots;
+    OcRingSlice<T>* slices;
+    uint8_t* flags;
+    size_t slot_elems;
+    int cap, nslice, rows, ntile;
+};
+template <typename T>
+RingView<T> ring_view(const oc_hjb_ring* r, int Nx) {
+    RingView<T> v;
+    char* m = (char*)r->meta;
+    v.data = (T*)r->data;
+    v.head = (OcRingHead*)m;
+    v.slots = (OcRingSlot<T>*)(m + oc_ring_slots_off());
+    v.slices = (OcRingSlice<T>*)(m + oc_ring_slices_off(sizeof(T), r->slots));
+    v.flags = (uint8_t*)(m + oc_ring_flags_off(sizeof(T), r->slots, r->nslice));
+    v.slot_elems = (size_t)OC_RING_VALS * r->rows * Nx;
+    v.cap = r->slots;
+    v.nslice = r->nslice;
+    v.rows = r->rows;
+    v.ntile = oc_ring_ntile(r->rows, Nx);
+    return v;
+}
+
+// slices [s_lo, s_hi) of the direction field (and / or the audit output phi at kept t_eval points) from a ring: slice s
+// goes to vx_out[s - s_lo].  n_slots: the solve's accepted steps (the caller read the ring's head).
+template <typename T, typename TO>
+int ring_emit(oc_handle* h, const RingView<T>& R, int n_slots, int s_lo, int s_hi, void* vx_out, void* vy_out,
+              double* keep_base, const int32_t* keep_slot_dev, hipStream_t s) {
+    const oc_config& c = h->cfg;
+    const int Ny = R.rows, Nx = c.Nx;
+    if (!h->hjb_ctl) OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 4096));
+    HjbCtl<T>* ctl = (HjbCtl<T>*)((char*)h->hjb_ctl + 2048);       // (the second half: the first is a solve's controller)
+    static_assert(sizeof(HjbCtl<T>) <= 2048, "controller block too large");
+    OutArgs<T> OA;
+    memset(&OA, 0, sizeof(OA));
+    OA.ctl = ctl;
+    OA.slice_elems = (size_t)Ny * Nx;
+    // slice s lands at index s - s_lo of the caller's arrays (only addresses of asked-for slices are ever formed)
+    OA.vx_base = vx_out ? (void*)((TO*)vx_out - (ptrdiff_t)s_lo * (ptrdiff_t)OA.slice_elems) : nullptr;
+    OA.vy_base = vy_out ? (void*)((TO*)vy_out - (ptrdiff_t)s_lo * (ptrdiff_t)OA.slice_elems) : nullptr;
+    OA.keep_base = keep_base;
+    OA.keep_slot = keep_slot_dev;
+    OA.lim = (T)c.lim;
+    OA.mu = (T)c.mu;
+    OA.inv2dx = (T)(1.0 / (2 * c.dx));
+    OA.inv2dy = (T)(1.0 / (2 * c.dy));
+    OA.Ny = Ny;
+    OA.Nx = Nx;
+    OA.stx = OC_RING_STX;
+    OA.sty = OC_RING_STY;
+    for (int slot = 0; slot < n_slots; ++slot) {
+        T* sd = R.data + (size_t)slot * R.slot_elems;
+        hipLaunchKernelGGL(k_ring_ctl<T>, dim3(1), dim3(1), 0, s, (const OcRingHead*)R.head, (const OcRingSlot<T>*)R.slots, slot,
+                           s_lo, s_hi, ctl);
+        hipLaunchKernelGGL(k_ring_fill<T>, dim3(R.ntile), dim3(256), 0, s, (const HjbCtl<T>*)ctl, sd,
+                           (const uint8_t*)(R.flags + (size_t)slot * R.ntile), Ny, Nx);
+        OA.ring_slot = sd;
+        launch_out<T, TO, true, true>(h->out_tile, Nx, Ny, s, OA);
+    }
+    OC_HIP_CHECK(hipGetLastError());
+    return OC_OK;
 }
 
 template <typename T>
@@ -1538,7 +1735,7 @@ void launch_stages_fused(Solver<T>& S, double hh, T atol_s, T rtol) {
 template <typename T, typename TO>
 int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, void* vx_out, void* vy_out,
                   const int32_t* keep_idx, int32_t n_keep, double* phi_keep, double* t_steps, int32_t t_steps_cap,
-                  oc_hjb_stats* st, hipStream_t s, const oc_hjb_shard* sh) {
+                  oc_hjb_stats* st, hipStream_t s, const oc_hjb_shard* sh, const oc_hjb_ring* ring = nullptr) {
     const oc_config& c = h->cfg;
     Solver<T> S;
     S.h = h;
@@ -1669,8 +1866,22 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     SA.work = nullptr;
     // stage launches of an attempt (k_stageV): hjb_fuse 0 = all six stages in one launch (tile 112 x 20), 1 = two launches of
     // three stages (tile 120 x 26; measured slower, kept as a cross-check of the other)
-    const int fuse = h->hjb_fuse;
+    const int fuse = ring ? 0 : h->hjb_fuse;        // (the ring is written by the one-launch attempt)
     const int tx = fuse == 0 ? 112 : 120, ty = fuse == 0 ? 20 : 26;
+    static_assert(OC_RING_STX == 112 && OC_RING_STY == 20, "the ring's tile flags are those of k_stageV<T, 6, 1, true, 32, 32>");
+    RingView<T> R;
+    memset(&R, 0, sizeof(R));
+    if (ring) {
+        OC_REQUIRE(ring->data && ring->meta && ring->slots >= 1, "empty ring");
+        OC_REQUIRE(ring->rows == S.Ny, "the ring's row count differs from the solve's");
+        OC_REQUIRE(ring->nslice >= nt - 1, "horizon exceeds the ring's slice table");
+        R = ring_view<T>(ring, S.Nx);
+        SA.ring = R.data;
+        SA.ring_slot_elems = R.slot_elems;
+        SA.ring_flags = R.flags;
+        SA.ring_cap = R.cap;
+        SA.ring_ntile = R.ntile;
+    }
     const int nb3 = ((S.Nx + tx - 1) / tx) * ((S.Ny + ty - 1) / ty);
     const dim3 grid3(8 * ((nb3 + 7) / 8));
     if (nb3 > h->red_blocks) {
@@ -1755,7 +1966,9 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             OA.work = work_list;
             OA.parts_rw = h->red_partial;
         }
-        if (fuse == 0) {
+        if (ring) {
+            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32, true>), grid3, dim3(1024), 0, s, SA);
+        } else if (fuse == 0) {
             hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32>), grid3, dim3(1024), 0, s, SA);
         } else {
             hipLaunchKernelGGL((k_stageV<T, 3, 1, false, 32, 32>), grid3, dim3(1024), 0, s, SA);
@@ -1769,10 +1982,12 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                 return OC_ERR_STATE;
             }
             hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, ctl, (const double*)sh->red_all, sh->world,
-                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev);
+                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev, 0, R.slots, R.slices,
+                               R.cap);
         } else {
             hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, ctl, (const double*)h->red_partial, nb3,
-                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev, active_set ? 1 : 0);
+                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev, active_set ? 1 : 0,
+                               R.slots, R.slices, R.cap);
         }
         if (halos) {
             const dim3 gh((unsigned)((4 * hn + 255) / 256));
@@ -1786,7 +2001,12 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                                (T*)sh->recv_up, (T*)sh->recv_dn, lo, hi, hn, sh->has_up, sh->has_dn);
         }
         if (prof) event();
-        launch_out<T, TO, true>(h->out_tile, S.Nx, S.Ny, s, OA);
+        if (!ring) {
+            launch_out<T, TO, true>(h->out_tile, S.Nx, S.Ny, s, OA);
+        } else if (active_set) {        // no slice writer beside which the list could be built: its own (one-block) launch
+            hipLaunchKernelGGL(k_list<T>, dim3(1), dim3(256), 0, s, ctl, (const int32_t*)OA.flags, OA.flags_next, OA.work,
+                               OA.parts_rw, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty, R.flags, R.cap);
+        }
         if (prof) event();
         ++enq;
         return OC_OK;
@@ -1829,9 +2049,29 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     OC_HIP_CHECK(hipStreamSynchronize(s));
     OC_HIP_CHECK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
     if (hc.status != 0) {
+        if (hc.status == OC_ERR_SOLVER - 200) {
+            oc_set_error("hjb_solve_ring: more than %d accepted steps (t = %g reached): the ring is too small", R.cap, hc.t);
+            return OC_ERR_CAPACITY;
+        }
         if (hc.status == OC_ERR_SOLVER) oc_set_error("RK45: step size too small at t=%g", hc.t);
         else oc_set_error("RK45: NaN error norm at t=%g (state overflow?)", hc.t);
         return OC_ERR_SOLVER;
+    }
+    if (ring) {
+        OcRingHead rh;
+        memset(&rh, 0, sizeof(rh));
+        rh.n_slots = hc.n_accept;
+        rh.nt = nt;
+        rh.cap = R.cap;
+        rh.nslice = R.nslice;
+        rh.te_step = hc.te_step;
+        rh.Tfinal = hc.Tfinal;
+        OC_HIP_CHECK(hipMemcpy(R.head, &rh, sizeof(rh), hipMemcpyHostToDevice));
+        if (n_keep > 0) {               // the audit output: phi at the kept t_eval points, from the ring
+            int rc2 = ring_emit<T, TO>(h, R, hc.n_accept, 0, nt, nullptr, nullptr, phi_keep, keep_slot_dev, s);
+            if (rc2) return rc2;
+            OC_HIP_CHECK(hipStreamSynchronize(s));
+        }
     }
     const int n_real = hc.n_attempt;
     std::vector<int32_t> log((size_t)std::min(enq, LOG_CAP));
@@ -1853,9 +2093,15 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             if (log[a] & 1) {           // a real attempt: 8 array passes in one launch (two launches: 6 + 11)
                 ts.add_ms += e1;
                 ts.add_n += 1;
-                ts.bytes += (fuse == 0 ? 8.0 : 17.0) * sizeof(T) * (double)n * share;
+                ts.bytes += (ring ? 10.0 : (fuse == 0 ? 8.0 : 17.0)) * sizeof(T) * (double)n * share;    // ring: 3 read, 7 written
             }
-            if (log[a] & 2) {           // accepted: k_out read y, K0, Q1 .. Q3 once, wrote 2 components per slice
+            if (ring) {                 // (the second interval is the list builder's launch)
+                if (log[a] & 1) {
+                    oc_timer& tl = h->timers["hjb_list"];
+                    tl.add_ms += e2;
+                    tl.add_n += 1;
+                }
+            } else if (log[a] & 2) {           // accepted: k_out read y, K0, Q1 .. Q3 once, wrote 2 components per slice
                 const int nv = log[a] >> 8;
                 to.add_ms += e2;
                 to.add_n += 1;
@@ -1882,7 +2128,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
 template <typename T, typename TO = T>
 int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, void* vx_out, void* vy_out,
                 const int32_t* keep_idx, int32_t n_keep, double* phi_keep, double* t_steps, int32_t t_steps_cap,
-                oc_hjb_stats* st, hipStream_t s, const oc_hjb_shard* sh = nullptr) {
+                oc_hjb_stats* st, hipStream_t s, const oc_hjb_shard* sh = nullptr, const oc_hjb_ring* ring = nullptr) {
     const oc_config& c = h->cfg;
     Solver<T> S;
     S.h = h;
@@ -1907,7 +2153,11 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
     const bool use_fused = (h->hjb_variant != 1) && (c.Nx % 4 == 0);   // vector kernels need 16-byte rows
     if (h->hjb_variant == 0 && use_fused)        // the default: three stages per launch, controller on the device
         return hjb_solve_dev<T, TO>(h, coef_v, Tfinal, nt, vx_out, vy_out, keep_idx, n_keep, phi_keep, t_steps, t_steps_cap,
-                                    st, s, sh);
+                                    st, s, sh, ring);
+    if (ring) {
+        oc_set_error("the interpolant ring needs the product path (Nx %% 4 == 0, hjb variant 0)");
+        return OC_ERR_ARG;
+    }
     if (sizeof(TO) != sizeof(T)) {
         oc_set_error("the float64-state / float32-field mode needs the product path (Nx %% 4 == 0, hjb variant 0)");
         return OC_ERR_ARG;
@@ -2311,3 +2561,127 @@ extern "C" int oc_hjb_solve_rows(oc_handle* h, int dtype, const void* coef_rows,
     }
     return rc;
 }
+
+// ------------------------------------------------------------------------------------------ the interpolant ring
+static int ring_check(const oc_handle* h, int dtype, const oc_hjb_ring* ring) {
+    OC_REQUIRE(h && ring, "null argument");
+    OC_REQUIRE(dtype == OC_F32 || dtype == OC_F64 || dtype == OC_F64_F32, "bad dtype");
+    OC_REQUIRE(ring->data && ring->meta, "null ring buffers");
+    OC_REQUIRE(ring->slots >= 1 && ring->nslice >= 0 && ring->rows >= 3 && ring->rows <= h->cfg.Ny, "bad ring dimensions");
+    OC_REQUIRE(h->cfg.Nx % 4 == 0, "the interpolant ring needs Nx % 4 == 0 (16-byte rows)");
+    return OC_OK;
+}
+
+extern "C" int64_t oc_hjb_ring_slot_elems(const oc_handle* h, int32_t rows) {
+    return h ? (int64_t)OC_RING_VALS * rows * h->cfg.Nx : 0;
+}
+
+extern "C" int64_t oc_hjb_ring_meta_bytes(const oc_handle* h, int dtype, int32_t slots, int32_t nslice, int32_t rows) {
+    if (!h || slots < 1 || rows < 1) return 0;
+    return (int64_t)oc_ring_meta_size(dtype == OC_F32 ? 4 : 8, slots, nslice, rows, h->cfg.Nx);
+}
+
+// Accepted steps a solve over [T, 0] will take: the controller drives the explicit pair to its stability limit on this
+// equation (h ~ 3.3 / (8 (sigma^2/2) / dx^2), measured 383 steps at dx = 0.05 and 93 at dx = 0.1 for T = 20),
+// so T / h_stab plus a third and a constant covers it; a ring that turns out too small is reported (OC_ERR_CAPACITY).
+extern "C" int32_t oc_hjb_ring_slots_hint(const oc_handle* h, double T) {
+    if (!h) return 0;
+    const oc_config& c = h->cfg;
+    const double h_stab = 3.3 / (4.0 * c.sigma * c.sigma / (c.dx * c.dy));
+    const double n = std::fabs(T) / h_stab;
+    return (int32_t)std::min(1.35 * n + 40.0, 1e6);
+}
+
+extern "C" int oc_hjb_solve_ring(oc_handle* h, int dtype, const void* coef, double T, int32_t nt, const oc_hjb_ring* ring,
+                                 const int32_t* keep_idx, int32_t n_keep, double* phi_keep, double* t_steps,
+                                 int32_t t_steps_cap, oc_hjb_stats* stats, void* stream) {
+    OC_REQUIRE(h && coef, "null argument");
+    int rc = ring_check(h, dtype, ring);
+    if (rc) return rc;
+    OC_REQUIRE(ring->rows == h->cfg.Ny, "a whole-grid solve needs a ring of Ny rows");
+    OC_REQUIRE(n_keep == 0 || (keep_idx && phi_keep), "keep list without buffer");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    auto t0 = std::chrono::steady_clock::now();
+    if (dtype == OC_F32)
+        rc = hjb_solve_t<float>(h, coef, T, nt, nullptr, nullptr, keep_idx, n_keep, phi_keep, t_steps, t_steps_cap, stats, s,
+                                nullptr, ring);
+    else if (dtype == OC_F64)
+        rc = hjb_solve_t<double>(h, coef, T, nt, nullptr, nullptr, keep_idx, n_keep, phi_keep, t_steps, t_steps_cap, stats, s,
+                                 nullptr, ring);
+    else
+        rc = hjb_solve_t<double, float>(h, coef, T, nt, nullptr, nullptr, keep_idx, n_keep, phi_keep, t_steps, t_steps_cap,
+                                        stats, s, nullptr, ring);
+    if (rc == OC_OK) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            oc_set_error("hjb_solve_ring: %s", hipGetErrorString(e));
+            return OC_ERR_HIP;
+        }
+        if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return rc;
+}
+
+extern "C" int oc_hjb_solve_rows_ring(oc_handle* h, int dtype, const void* coef_rows, double T, int32_t nt,
+                                      const oc_hjb_ring* ring, const oc_hjb_shard* sh, const int32_t* keep_idx,
+                                      int32_t n_keep, double* phi_keep, oc_hjb_stats* stats, void* stream) {
+    OC_REQUIRE(h && coef_rows && sh, "null argument");
+    int rc = ring_check(h, dtype, ring);
+    if (rc) return rc;
+    OC_REQUIRE(ring->rows == sh->Ny_local, "the ring must hold the row block's Ny_local rows");
+    OC_REQUIRE(n_keep == 0 || (keep_idx && phi_keep), "keep list without buffer");
+    OC_REQUIRE(sh->world >= 1 && sh->world <= OC_MAX_WORLD, "bad world size");
+    OC_REQUIRE(sh->halo >= 7, "halo must cover the 6 stencil applications of one RK step + the row of K6 the output reads");
+    OC_REQUIRE(sh->own_lo == (sh->has_up ? sh->halo : 0), "own_lo must equal the upper halo depth");
+    OC_REQUIRE(sh->own_hi > sh->own_lo && sh->Ny_local == sh->own_hi + (sh->has_dn ? sh->halo : 0), "bad row window");
+    OC_REQUIRE(!(sh->has_up || sh->has_dn) || sh->own_hi - sh->own_lo >= sh->halo, "owned block thinner than the halo");
+    OC_REQUIRE(sh->Ny_local >= 3 && sh->Ny_local <= sh->Ny_global && sh->Ny_global <= h->cfg.Ny, "bad row counts");
+    OC_REQUIRE(sh->red_local && sh->red_all && sh->allgather_red, "missing reduction buffers / callback");
+    OC_REQUIRE(!(sh->has_up || sh->has_dn) || sh->exchange_halo, "missing halo callback");
+    OC_REQUIRE(!sh->has_up || (sh->send_up && sh->recv_up), "missing upper staging buffers");
+    OC_REQUIRE(!sh->has_dn || (sh->send_dn && sh->recv_dn), "missing lower staging buffers");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    auto t0 = std::chrono::steady_clock::now();
+    if (dtype == OC_F32)
+        rc = hjb_solve_t<float>(h, coef_rows, T, nt, nullptr, nullptr, keep_idx, n_keep, phi_keep, nullptr, 0, stats, s, sh, ring);
+    else if (dtype == OC_F64)
+        rc = hjb_solve_t<double>(h, coef_rows, T, nt, nullptr, nullptr, keep_idx, n_keep, phi_keep, nullptr, 0, stats, s, sh,
+                                 ring);
+    else
+        rc = hjb_solve_t<double, float>(h, coef_rows, T, nt, nullptr, nullptr, keep_idx, n_keep, phi_keep, nullptr, 0, stats, s,
+                                        sh, ring);
+    if (rc == OC_OK) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            oc_set_error("hjb_solve_rows_ring: %s", hipGetErrorString(e));
+            return OC_ERR_HIP;
+        }
+        if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return rc;
+}
+
+// Slices [s_lo, s_hi) of the direction field from a ring, by the slice writer of oc_hjb_solve (k_out) itself: the arrays a
+// slice-writing solve would have left, bit for bit.  vx_out / vy_out: (s_hi - s_lo, rows, Nx) of the field's type.
+extern "C" int oc_hjb_ring_slices(oc_handle* h, int dtype, const oc_hjb_ring* ring, int32_t s_lo, int32_t s_hi, void* vx_out,
+                                  void* vy_out, void* stream) {
+    int rc = ring_check(h, dtype, ring);
+    if (rc) return rc;
+    OC_REQUIRE(vx_out && vy_out, "null output");
+    OC_REQUIRE(s_lo >= 0 && s_lo <= s_hi, "bad slice range");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    OcRingHead rh;
+    OC_HIP_CHECK(hipStreamSynchronize(s));
+    OC_HIP_CHECK(hipMemcpy(&rh, ring->meta, sizeof(rh), hipMemcpyDeviceToHost));
+    OC_REQUIRE(rh.cap == ring->slots && rh.nslice == ring->nslice && rh.n_slots >= 0 && rh.n_slots <= rh.cap,
+               "the ring holds no finished solve (or was made with other dimensions)");
+    OC_REQUIRE(s_hi <= rh.nt - 1 || s_hi == s_lo, "slices beyond the solve's horizon (nt - 1) do not exist in the ring");
+    if (s_hi == s_lo) return OC_OK;
+    if (dtype == OC_F32) return ring_emit<float, float>(h, ring_view<float>(ring, h->cfg.Nx), rh.n_slots, s_lo, s_hi, vx_out, vy_out, nullptr, nullptr, s);
+    if (dtype == OC_F64) return ring_emit<double, double>(h, ring_view<double>(ring, h->cfg.Nx), rh.n_slots, s_lo, s_hi, vx_out, vy_out, nullptr, nullptr, s);
+    return ring_emit<double, float>(h, ring_view<double>(ring, h->cfg.Nx), rh.n_slots, s_lo, s_hi, vx_out, vy_out, nullptr, nullptr, s);
+}
+

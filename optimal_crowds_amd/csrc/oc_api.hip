@@ -197,6 +197,43 @@ extern "C" int oc_set_field(oc_handle* h, int key, int dtype, const void* vx, co
     f.rows = -1;
     f.own_lo = 0;
     f.own_hi = 1 << 30;
+    f.ring_data = f.ring_meta = nullptr;
+    f.ring_state_dtype = -1;
+    f.ring_slots = 0;
+    h->key_tables_dirty = true;
+    return OC_OK;
+}
+
+// The interpolant ring of a key in the place of its slices: lookups evaluate the direction from it (gcfm.hip: ring_dir).
+extern "C" int oc_set_field_ring(oc_handle* h, int key, int dtype, const oc_hjb_ring* ring, int32_t nt_opt, int32_t row0,
+                                 int32_t own_lo, int32_t own_hi) {
+    OC_REQUIRE(h && key >= 0 && key < (int)h->fields.size(), "bad key");
+    OC_REQUIRE(dtype == OC_F32 || dtype == OC_F64 || dtype == OC_F64_F32, "bad dtype");
+    OC_REQUIRE(ring && ring->data && ring->meta && ring->slots >= 1 && ring->rows >= 3, "bad ring");
+    OC_REQUIRE(h->cfg.Nx % 4 == 0, "the interpolant ring needs Nx % 4 == 0");
+    oc_field_desc& f = h->fields[key];
+    f.dtype = dtype == OC_F64 ? OC_F64 : OC_F32;        // what a slice would hold: float32 unless the audit mode
+    f.vx = f.vy = nullptr;
+    f.nslice_alloc = ring->nslice;
+    f.nt_opt = nt_opt;
+    f.ring_data = ring->data;
+    f.ring_meta = ring->meta;
+    f.ring_state_dtype = dtype == OC_F32 ? OC_F32 : OC_F64;
+    f.ring_slots = ring->slots;
+    if (row0 < 0) {                 // the whole grid
+        OC_REQUIRE(ring->rows == h->cfg.Ny, "a whole-grid ring has Ny rows");
+        f.row0 = 0;
+        f.rows = -1;
+        f.own_lo = 0;
+        f.own_hi = 1 << 30;
+    } else {
+        OC_REQUIRE(row0 + ring->rows <= h->cfg.Ny, "row block outside the grid");
+        OC_REQUIRE(own_lo >= row0 && own_hi <= row0 + ring->rows && own_lo < own_hi, "owned rows outside the row block");
+        f.row0 = row0;
+        f.rows = ring->rows;
+        f.own_lo = own_lo;
+        f.own_hi = own_hi;
+    }
     h->key_tables_dirty = true;
     return OC_OK;
 }

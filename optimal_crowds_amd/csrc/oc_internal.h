@@ -30,10 +30,63 @@ void oc_set_error(const char* fmt, ...);
         }                                                                  \
     } while (0)
 
+// ---- the interpolant ring (hjb.hip writes it, gcfm.hip's lookup and the slice writer read it) -------------------------
+// Instead of every slice of the direction field, a solve can keep what the dense output of each ACCEPTED step is made of
+// (scipy rk.py:178-180, 560-575): y_old, K0 = Q0 and Q1 .. Q3 -- five values per cell and step instead of two per cell and
+// t_eval point (C4: 93 steps x 5 arrays against 999 slices x 2) -- and the direction (optimals.py:168-186) is evaluated
+// where it is looked up, with the same FMA chain as the slice writer k_out.
+//   data   per slot (= accepted step) rows x Nx/4 blocks of 20 values: y[4], K0[4], Q1[4], Q2[4], Q3[4] of four
+//          consecutive cells of a row (one lookup cell's five values share one or two cache lines; the stage kernel
+//          stores five natural 16-byte vectors per thread).  Only the stage tiles that were COMPUTED in the accepted
+//          attempt are written (exact active set); the others are flagged and read as (u, 0, 0, 0, 0).
+//   meta   OcRingHead | OcRingSlot<T> x slots | OcRingSlice<T> x nslice | uint8 flags [slots][stage tiles]
+#define OC_RING_VALS 5
+#define OC_RING_STX 112          // stage tile of the product path (k_stageV<T, 6, 1, true, 32, 32>): 112 x 20 cells
+#define OC_RING_STY 20
+struct OcRingHead {
+    int32_t n_slots;             // accepted steps of the last solve
+    int32_t nt;                  // its horizon: slices 0 .. nt - 2 are covered by the slice table
+    int32_t cap, nslice;
+    double te_step, Tfinal;      // t_eval[k] = k * te_step + Tfinal  (np.linspace(T, 0, nt))
+    int32_t pad[8];
+};
+template <typename T>
+struct OcRingSlot {
+    double out_t, out_hh, out_unscale;      // the step: start time, signed length, 2^expo of its scale
+    int32_t k_lo, k_hi;                     // t_eval indices [k_lo, k_hi) lie in the step
+    int32_t dense, pad;                     // 1: every stage tile of the slot holds data (no flags)
+    T lim_s, u;                             // the clip level in the slot's scale; the far field's constant value of y
+};
+template <typename T>
+struct OcRingSlice {
+    int32_t slot, pad;
+    T h[4];                                 // h x, h x^2, h x^3, h x^4 of the slice's t_eval point in its step
+};
+inline size_t oc_ring_align(size_t v) { return (v + 255) & ~(size_t)255; }
+inline int oc_ring_ntile(int rows, int Nx) {
+    return ((Nx + OC_RING_STX - 1) / OC_RING_STX) * ((rows + OC_RING_STY - 1) / OC_RING_STY);
+}
+inline size_t oc_ring_slots_off() { return oc_ring_align(sizeof(OcRingHead)); }
+inline size_t oc_ring_slices_off(size_t tsize, int slots) {
+    return oc_ring_slots_off() + oc_ring_align((tsize == 4 ? sizeof(OcRingSlot<float>) : sizeof(OcRingSlot<double>)) * (size_t)slots);
+}
+inline size_t oc_ring_flags_off(size_t tsize, int slots, int nslice) {
+    return oc_ring_slices_off(tsize, slots) +
+           oc_ring_align((tsize == 4 ? sizeof(OcRingSlice<float>) : sizeof(OcRingSlice<double>)) * (size_t)std::max(nslice, 1));
+}
+inline size_t oc_ring_meta_size(size_t tsize, int slots, int nslice, int rows, int Nx) {
+    return oc_ring_flags_off(tsize, slots, nslice) + oc_ring_align((size_t)slots * oc_ring_ntile(rows, Nx));
+}
+
 struct oc_field_desc {
     int dtype = -1;
     const void* vx = nullptr;
     const void* vy = nullptr;
+    // interpolant ring instead of slices (oc_set_field_ring): dtype above = the FIELD's type (what a slice would hold)
+    const void* ring_data = nullptr;
+    const void* ring_meta = nullptr;
+    int ring_state_dtype = -1;              // OC_F32 / OC_F64: type of the ring's values
+    int32_t ring_slots = 0;
     int32_t nslice_alloc = 0;
     int32_t nt_opt = 0;
     int32_t row0 = 0, rows = -1;            // row block held locally (rows < 0: the whole grid)
@@ -127,6 +180,42 @@ struct oc_handle {
     int hjb_active = 1;             // exact active set (hjb.hip): 0 off, 1 on for grids of >= 1024 stage tiles, 2 on at any size
     std::map<std::string, oc_timer> timers;
 };
+
+// ---- device arithmetic shared by the slice writer (hjb.hip) and the lookup that evaluates the ring (gcfm.hip)
+// Fused multiply-add, written out: the library is compiled with -ffp-contract=off (the float64 index decisions of the
+// agent step must round like NumPy), so the HJB kernels ask for their FMAs explicitly -- ALL variants in the same
+// places, so that they stay bit-identical to each other: a_0 k_0 + a_1 k_1 + ... is one rounding per term instead of two.
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double fast_rsq(double x) { return 1.0 / sqrt(x); }
+
+// Unit-or-zero direction of v = grad/(mu*phi_c) (optimals.py:179-186) without forming v: in float32 the ratio
+// overflows next to walls late in the solve (|grad| ~ 2^64 against phi_c = lim*2^-e), although its direction and
+// the decision |v| > lim are perfectly representable.  |v| > lim  <=>  m*nn > lim*mu*phi_c with m = max(|gx|,|gy|),
+// nn = |(gx,gy)/m| in [1, sqrt 2].  (|v| == lim, 0/0 in the reference, is treated as "not greater": zero.)
+template <typename T>
+__device__ __forceinline__ void direction_of(T gx, T gy, T mupc, T lim, T& ox, T& oy) {
+    const T m = fmax(fabs(gx), fabs(gy));
+    ox = (T)0;
+    oy = (T)0;
+    if (m > (T)0) {
+        const T im = fast_rcp(m);
+        const T ax = gx * im, ay = gy * im;
+        const T n2 = ax * ax + ay * ay;          // in [1, 2]
+        const T inn = fast_rsq(n2);
+        if (m * (n2 * inn) > lim * mupc) {
+            ox = ax * inn;
+            oy = ay * inn;
+        }
+    } else if (m != m) {                 // NaN input stays visible
+        ox = m;
+        oy = m;
+    }
+}
 
 // timers (oc_api.hip)
 void oc_timer_begin(oc_handle* h, const char* name, hipStream_t s);

@@ -14,7 +14,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FIX_BITS, OC_F32, OC_F64, OC_F64_F32, OcAgents, OcConfig, OcHjbStats, check
+from ._lib import (FIX_BITS, OC_ERR_CAPACITY, OC_F32, OC_F64, OC_F64_F32, OcAgents, OcConfig, OcHjbRing, OcHjbStats,
+                   check)
 
 LIM = 10e-3          # reference optimals.py:95
 
@@ -36,9 +37,49 @@ def hjb_state_dtype(cfg, T, requested="float32"):
     return "float32" if bits - 64.0 <= 118.0 else "mixed"
 
 
+class _Field:
+    """Direction field of one key, indexed like the list it replaces: [0], [1] = vx, vy as (nslice, rows, Nx) device
+    tensors, [2] = allocated slices, [3] = current horizon nt_opt.  In 'ring' mode the key holds an interpolant ring
+    (oc_hjb_solve_ring) and the tensors are MATERIALISED from it on first access (oc_hjb_ring_slices: the slice writer's
+    own arithmetic) and dropped at the next solve; the agent step never needs them."""
+
+    def __init__(self, eng, key, nslice, rows, held=True):
+        self.eng, self.key, self.nslice, self.rows, self.held = eng, key, nslice, rows, held
+        self.nt = 0
+        self.vx = self.vy = None        # slices (mode 'slices'), or the materialised cache of a ring
+        self.ring = None                # dict(data, meta, slots, struct) once a ring solve has run
+        self.is_ring = False
+
+    def __getitem__(self, i):
+        if i == 2:
+            return self.nslice
+        if i == 3:
+            return self.nt
+        if i not in (0, 1):
+            raise IndexError(i)
+        if not self.held:
+            return None
+        if self.is_ring and self.vx is None:
+            self.vx, self.vy = self.eng.ring_slices(self.key, 0, max(self.nt - 1, 0), full=True)
+        return self.vx if i == 0 else self.vy
+
+    def __setitem__(self, i, v):
+        if i == 3:
+            self.nt = v
+        elif i == 0:
+            self.vx = v
+        elif i == 1:
+            self.vy = v
+        else:
+            raise IndexError(i)
+
+    def __iter__(self):
+        return iter((self[0], self[1], self.nslice, self.nt))
+
+
 class Engine:
     def __init__(self, cfg, room_length, room_height, Nx, Ny, X0, Y0, n_keys, max_agents,
-                 device="cuda:0", dtype="float32", wall_search_radius=0.0):
+                 device="cuda:0", dtype="float32", wall_search_radius=0.0, field_mode="ring"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.OcError("no HIP device visible: optimal_crowds_amd needs an MI355X (there is no CPU path)")
@@ -53,6 +94,13 @@ class Engine:
         self.field_tdtype = torch.float32 if self.field_dtype == OC_F32 else torch.float64
         self.solve_dtype = OC_F64_F32 if self.mixed else self.dtype
         self.Nx, self.Ny, self.n_keys = Nx, Ny, n_keys
+        # field_mode: 'ring' (default) -- a solve keeps the accepted steps' interpolants (oc_hjb_solve_ring) and lookups
+        # evaluate the direction from them: the slices nobody reads are never written (reference optimals.py:200-204
+        # fills all of them, step() reads one, :231-248); 'slices' -- every slice is written (oc_hjb_solve), as the
+        # reference does.  The ring needs the vector kernels (Nx % 4 == 0); other grids use slices.
+        if field_mode not in ("ring", "slices"):
+            raise ValueError("field_mode must be 'ring' or 'slices'")
+        self.field_mode = field_mode if Nx % 4 == 0 else "slices"
         hp = cfg["hjb_params"]
         c = OcConfig()
         c.Ny, c.Nx = Ny, Nx
@@ -120,6 +168,8 @@ class Engine:
 
     def set_hjb_variant(self, variant):
         check(self.lib.oc_set_hjb_variant(self.h, int(variant)))
+        if int(variant) != 0:               # the cross-check variants write slices
+            self.field_mode = "slices"
 
     def set_tuning(self, name, value):
         """Launch-shape knobs of the step kernels (oc_hip.h: oc_set_tuning)."""
@@ -198,15 +248,80 @@ class Engine:
         # slices are stored padded as (Ny, Nx) so that every row is 16-byte aligned for the vector kernels;
         # the reference's (Ny-2, Nx-2) array is the interior block [1:-1, 1:-1] (see field_interior)
         if not self.holds_key(key):             # another rank group solves and answers this key
-            self.fields[key] = [None, None, nslice, 0]
+            self.fields[key] = _Field(self, key, nslice, 0, held=False)
             return None, None
         rc = self._key_rows(key)
         rows = rc.shard.Ny_local if rc is not None else self.Ny                  # row-sharded: this rank's block
+        f = self.fields[key] = _Field(self, key, nslice, rows)
+        if self.field_mode == "ring":           # (the ring itself is allocated by the first solve, which knows T)
+            f.is_ring = True
+            return None, None
         shape = (max(nslice, 0), rows, self.Nx)
-        vx = torch.zeros(shape, dtype=self.field_tdtype, device=self.device)
-        vy = torch.zeros(shape, dtype=self.field_tdtype, device=self.device)
-        self.fields[key] = [vx, vy, nslice, 0]
+        f.vx = torch.zeros(shape, dtype=self.field_tdtype, device=self.device)
+        f.vy = torch.zeros(shape, dtype=self.field_tdtype, device=self.device)
+        return f.vx, f.vy
+
+    # ------------------------------------------------------------------ the interpolant ring
+    def _ring(self, key, T, grow=False):
+        """the key's ring, allocated for horizon T (oc_hjb_ring_slots_hint) or doubled after OC_ERR_CAPACITY"""
+        f = self.fields[key]
+        if f.ring is not None and not grow:
+            return f.ring
+        slots = int(self.lib.oc_hjb_ring_slots_hint(self.h, float(T))) if f.ring is None else 2 * f.ring["slots"]
+        return self.make_ring(key, slots)
+
+    def make_ring(self, key, slots):
+        """(re)allocate the key's ring with room for `slots` accepted steps"""
+        f = self.fields[key]
+        f.ring = None                                   # (frees the old buffers before the larger ones are made)
+        f.vx = f.vy = None
+        slots = max(int(slots), 1)
+        per = int(self.lib.oc_hjb_ring_slot_elems(self.h, int(f.rows)))
+        nmeta = int(self.lib.oc_hjb_ring_meta_bytes(self.h, self.solve_dtype, slots, int(f.nslice), int(f.rows)))
+        data = torch.empty((slots, per), dtype=self.tdtype, device=self.device)
+        meta = torch.zeros(nmeta, dtype=torch.uint8, device=self.device)
+        st = OcHjbRing()
+        st.data, st.meta = data.data_ptr(), meta.data_ptr()
+        st.slots, st.nslice, st.rows, st.reserved = slots, int(f.nslice), int(f.rows), 0
+        f.ring = dict(data=data, meta=meta, slots=slots, struct=st)
+        return f.ring
+
+    def ring_slices(self, key, s_lo, s_hi, full=False):
+        """slices [s_lo, s_hi) of a ring-backed key's direction field, written by the slice writer itself
+        (oc_hjb_ring_slices): (s_hi - s_lo, rows, Nx) tensors -- or, full=True, (nslice, rows, Nx) with the slices in place
+        and zeros elsewhere (what alloc_field's zero-initialised arrays hold beyond a solve's horizon)."""
+        f = self.fields[key]
+        if not f.is_ring or f.ring is None:
+            raise ValueError("key %d has no ring (field_mode='slices', or not solved yet)" % key)
+        s_hi = min(int(s_hi), max(f.nt - 1, 0))
+        s_lo = min(int(s_lo), s_hi)
+        n_out = f.nslice if full else s_hi - s_lo
+        vx = torch.zeros((max(n_out, 0), f.rows, self.Nx), dtype=self.field_tdtype, device=self.device)
+        vy = torch.zeros_like(vx)
+        if s_hi > s_lo:
+            ox, oy = (vx[s_lo:], vy[s_lo:]) if full else (vx, vy)
+            check(self.lib.oc_hjb_ring_slices(self.h, self.solve_dtype, C.byref(f.ring["struct"]), s_lo, s_hi, _ptr(ox),
+                                              _ptr(oy), self.stream()))
         return vx, vy
+
+    def _register_field(self, key):
+        """(re-)register the key's field with the agent step: ring or slices, whole grid or this rank's row block"""
+        f = self.fields[key]
+        if not f.held:
+            return
+        rc = self._key_rows(key)
+        if f.is_ring:
+            if f.ring is None:
+                return
+            sh = rc.shard if rc is not None else None
+            check(self.lib.oc_set_field_ring(self.h, key, self.solve_dtype, C.byref(f.ring["struct"]), int(f.nt),
+                                             int(sh.row0) if sh else -1, int(sh.g0) if sh else 0, int(sh.g1) if sh else 0))
+        elif rc is not None:
+            sh = rc.shard
+            check(self.lib.oc_set_field_rows(self.h, key, self.field_dtype, _ptr(f.vx), _ptr(f.vy), f.nslice, int(f.nt),
+                                             int(sh.row0), int(sh.Ny_local), int(sh.g0), int(sh.g1)))
+        else:
+            check(self.lib.oc_set_field(self.h, key, self.field_dtype, _ptr(f.vx), _ptr(f.vy), f.nslice, int(f.nt)))
 
     def field_interior(self, key):
         """(vx_opt, vy_opt) views of shape (nslice, Ny-2, Nx-2), the reference's arrays (optimals.py:80-81)."""
@@ -235,23 +350,23 @@ class Engine:
         return vx, vy
 
     def solve(self, key, T, nt, m=None, keep=None, want_steps=False):
-        """HJB solve for `key` with horizon nt = round((T - t)/dt); fills slices 0..nt-2 of the key's field.
+        """HJB solve for `key` with horizon nt = round((T - t)/dt): slices 0..nt-2 of the key's field -- written
+        (field_mode 'slices'), or kept as the accepted steps' interpolants and evaluated at lookup ('ring').
         keep: list of t_eval indices whose phi is returned (float64, (len, Ny, Nx))."""
-        vx, vy, nslice, _ = self.fields[key]
+        f = self.fields[key]
+        nslice = f.nslice
         if nt - 1 > nslice:
             raise ValueError("horizon exceeds allocated field slices")
         if not self.holds_key(key):
-            self.fields[key][3] = nt
+            f.nt = nt
             return None, None
         rc = self._key_rows(key)
         if rc is not None:
             if want_steps:
                 raise ValueError("want_steps is not available on a row-sharded key")
-            st, _, phi_keep = self.solve_rows(key, T, nt, rc, m=m, keep=keep, field=(vx, vy))
-            self.fields[key][3] = nt
-            sh = rc.shard
-            check(self.lib.oc_set_field_rows(self.h, key, self.field_dtype, _ptr(vx), _ptr(vy), nslice, int(nt),
-                                             int(sh.row0), int(sh.Ny_local), int(sh.g0), int(sh.g1)))
+            st, _, phi_keep = self.solve_rows(key, T, nt, rc, m=m, keep=keep, field=(f.vx, f.vy), _own=True)
+            f.nt = nt
+            self._register_field(key)
             return st, phi_keep
         self.make_coef(key, m)
         stats = OcHjbStats()
@@ -263,29 +378,46 @@ class Engine:
             phi_keep = torch.empty((n_keep, self.Ny, self.Nx), dtype=torch.float64, device=self.device)
         cap = 100000 if want_steps else 0
         tsteps = np.zeros(max(cap, 1))
-        check(self.lib.oc_hjb_solve(self.h, self.solve_dtype, _ptr(self.coef), float(T), int(nt), _ptr(vx), _ptr(vy),
-                                    keep_arr.ctypes.data_as(C.c_void_p) if keep_arr is not None else None, n_keep,
-                                    _ptr(phi_keep), tsteps.ctypes.data_as(C.c_void_p) if cap else None, cap,
-                                    C.byref(stats), self.stream()))
-        self.fields[key][3] = nt
-        check(self.lib.oc_set_field(self.h, key, self.field_dtype, _ptr(vx), _ptr(vy), nslice, int(nt)))
+        kp = keep_arr.ctypes.data_as(C.c_void_p) if keep_arr is not None else None
+        tp = tsteps.ctypes.data_as(C.c_void_p) if cap else None
+        if f.is_ring:
+            f.vx = f.vy = None                      # (a materialised copy of the previous solve)
+            ring = self._ring(key, T)
+            while True:
+                rcode = self.lib.oc_hjb_solve_ring(self.h, self.solve_dtype, _ptr(self.coef), float(T), int(nt),
+                                                   C.byref(ring["struct"]), kp, n_keep, _ptr(phi_keep), tp, cap,
+                                                   C.byref(stats), self.stream())
+                if rcode != OC_ERR_CAPACITY:
+                    break
+                ring = self._ring(key, T, grow=True)        # more accepted steps than slots: a larger ring, again
+            check(rcode)
+        else:
+            check(self.lib.oc_hjb_solve(self.h, self.solve_dtype, _ptr(self.coef), float(T), int(nt), _ptr(f.vx), _ptr(f.vy),
+                                        kp, n_keep, _ptr(phi_keep), tp, cap, C.byref(stats), self.stream()))
+        f.nt = nt
+        self._register_field(key)
         st = stats.as_dict()
         if want_steps:
             st["t_steps"] = tsteps[:st["n_accept"] + 1].copy()
         return st, phi_keep
 
-    def solve_rows(self, key, T, nt, comm, m=None, keep=None, field=None):
+    def solve_rows(self, key, T, nt, comm, m=None, keep=None, field=None, _own=False):
         """This rank's part of a row-block HJB solve (oc_hjb_solve_rows; `comm`: parallel.DistHaloComm or
         ThreadHaloComm built on a parallel.RowShard).  Returns (stats, (vx, vy), phi_keep): the direction field
-        (nt-1, Ny_local, Nx) and kept phi (len(keep), Ny_local, Nx) cover the LOCAL rows comm.shard.rows()."""
+        (nt-1, Ny_local, Nx) and kept phi (len(keep), Ny_local, Nx) cover the LOCAL rows comm.shard.rows().
+        (_own: called by solve() for a key whose field this engine manages -- with field_mode 'ring' the row block's
+        interpolants go to the key's ring, oc_hjb_solve_rows_ring, and (vx, vy) is (None, None).)"""
         sh = comm.shard
         self.make_coef(key, m)
         coef_rows = self.coef[sh.rows()]
-        if field is None:
+        use_ring = _own and self.fields[key].is_ring
+        if use_ring:
+            pass
+        elif field is None:
             shape = (max(nt - 1, 0), sh.Ny_local, self.Nx)
             field = (torch.zeros(shape, dtype=self.field_tdtype, device=self.device),
                      torch.zeros(shape, dtype=self.field_tdtype, device=self.device))
-        vx, vy = field
+        vx, vy = (None, None) if use_ring else field
         stats = OcHjbStats()
         keep_arr = phi_keep = None
         n_keep = 0
@@ -294,9 +426,21 @@ class Engine:
             n_keep = len(keep_arr)
             phi_keep = torch.empty((n_keep, sh.Ny_local, self.Nx), dtype=torch.float64, device=self.device)
         st = comm.struct()
-        rc = self.lib.oc_hjb_solve_rows(self.h, self.solve_dtype, _ptr(coef_rows), float(T), int(nt), _ptr(vx), _ptr(vy),
-                                        C.byref(st), keep_arr.ctypes.data_as(C.c_void_p) if n_keep else None, n_keep,
-                                        _ptr(phi_keep), C.byref(stats), self.stream())
+        kp = keep_arr.ctypes.data_as(C.c_void_p) if n_keep else None
+        if use_ring:
+            f = self.fields[key]
+            f.vx = f.vy = None
+            ring = self._ring(key, T)
+            while True:
+                rc = self.lib.oc_hjb_solve_rows_ring(self.h, self.solve_dtype, _ptr(coef_rows), float(T), int(nt),
+                                                     C.byref(ring["struct"]), C.byref(st), kp, n_keep, _ptr(phi_keep),
+                                                     C.byref(stats), self.stream())
+                if rc != OC_ERR_CAPACITY or comm.error is not None:
+                    break
+                ring = self._ring(key, T, grow=True)    # (every rank sees the same step count: all grow together)
+        else:
+            rc = self.lib.oc_hjb_solve_rows(self.h, self.solve_dtype, _ptr(coef_rows), float(T), int(nt), _ptr(vx), _ptr(vy),
+                                            C.byref(st), kp, n_keep, _ptr(phi_keep), C.byref(stats), self.stream())
         if comm.error is not None:
             err, comm.error = comm.error, None
             raise err
@@ -310,22 +454,14 @@ class Engine:
             raise ValueError("a lookup's second cell may lie one row beyond the owned rows: the row block needs "
                              "halo >= 8 (the field is exact halo - 7 rows beyond the block)")
         nslice = int(vx.shape[0])
-        self.fields[key] = [vx, vy, nslice, int(nt)]
+        f = self.fields[key] = _Field(self, key, nslice, int(shard.Ny_local))
+        f.vx, f.vy, f.nt = vx, vy, int(nt)
         check(self.lib.oc_set_field_rows(self.h, key, self.field_dtype, _ptr(vx), _ptr(vy), nslice, int(nt), int(shard.row0),
                                          int(shard.Ny_local), int(shard.g0), int(shard.g1)))
 
     def set_field_horizon(self, key, nt):
-        vx, vy, nslice, _ = self.fields[key]
-        self.fields[key][3] = nt
-        if vx is None:
-            return
-        rc = self._key_rows(key)
-        if rc is not None:
-            sh = rc.shard
-            check(self.lib.oc_set_field_rows(self.h, key, self.field_dtype, _ptr(vx), _ptr(vy), nslice, int(nt),
-                                             int(sh.row0), int(sh.Ny_local), int(sh.g0), int(sh.g1)))
-            return
-        check(self.lib.oc_set_field(self.h, key, self.field_dtype, _ptr(vx), _ptr(vy), nslice, int(nt)))
+        self.fields[key].nt = nt
+        self._register_field(key)
 
     # ------------------------------------------------------------------ agents
     def set_agents(self, x, y, vx, vy, v_des, key, status=None, agent_time=None):

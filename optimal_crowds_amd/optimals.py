@@ -2,8 +2,9 @@
 (reference optimals.py:11-250) backed by the HIP solver.
 
 compute_optimal_velocity(t, m) runs the Cole-Hopf HJB solve (RK45 with SciPy's controller and dense output)
-on the GPU and leaves the direction field in HBM; vx_opt / vy_opt are array-like views that copy slices to the
-host on demand (the field is 33.5 GB per key at 2048^2, nt = 1000).
+on the GPU and leaves in HBM what the direction field is evaluated from -- by default the accepted steps' interpolants
+(the "ring": 7.8 GB per key at 2048^2, T = 20), from which a lookup computes the one or two cells it reads; vx_opt / vy_opt
+are array-like views that materialise slices on demand (all of them would be 33.5 GB per key at 2048^2, nt = 1000).
 """
 import numpy as np
 import torch
@@ -33,6 +34,59 @@ class DeviceField:
 
     def __array__(self, dtype=None, copy=None):
         a = self._t.double().cpu().numpy()
+        return a if dtype is None else a.astype(dtype)
+
+
+class RingField:
+    """vx_opt / vy_opt of a key whose solve kept the interpolant ring (the default): the (nslice, Ny-2, Nx-2) array of
+    the reference (optimals.py:80-81), of which a slice exists only while somebody looks at it -- indexing materialises
+    the slices asked for with the slice writer's own kernel (Engine.ring_slices) and returns float64 NumPy.  Slices at
+    and beyond the current horizon nt_opt - 1 read as zeros (the reference keeps whatever an earlier solve left there;
+    its lookup never reads them, optimals.py:231-232)."""
+
+    def __init__(self, engine, key, comp):
+        self._e, self._k, self._c = engine, key, comp
+
+    @property
+    def shape(self):
+        f = self._e.fields[self._k]
+        return (f.nslice, f.rows - 2, self._e.Nx - 2)
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float64)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def _slices(self, lo, hi):
+        f = self._e.fields[self._k]
+        n = hi - lo
+        out = np.zeros((n, f.rows - 2, self._e.Nx - 2))
+        top = min(hi, max(f.nt - 1, 0))
+        if top > lo:
+            t = self._e.ring_slices(self._k, lo, top)[self._c]
+            out[:top - lo] = t[:, 1:-1, 1:-1].double().cpu().numpy()
+        return out
+
+    def __getitem__(self, idx):
+        first, rest = (idx[0], idx[1:]) if isinstance(idx, tuple) else (idx, ())
+        n = self.shape[0]
+        if isinstance(first, (int, np.integer)):
+            i = int(first) + (n if first < 0 else 0)
+            if not 0 <= i < n:
+                raise IndexError("index %d is out of bounds for axis 0 with size %d" % (first, n))
+            a = self._slices(i, i + 1)[0]
+            return a[rest] if rest else a
+        if isinstance(first, slice):
+            lo, hi, st = first.indices(n)
+            if st == 1:
+                a = self._slices(lo, max(hi, lo))
+                return a[(slice(None),) + rest] if rest else a
+        return np.asarray(self)[idx]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._slices(0, self.shape[0])
         return a if dtype is None else a.astype(dtype)
 
 
@@ -88,10 +142,14 @@ class optimals:
 
     @property
     def vx_opt(self):
+        if self._engine.fields[self._k].is_ring:
+            return RingField(self._engine, self._k, 0)
         return DeviceField(self._engine.field_interior(self._k)[0])
 
     @property
     def vy_opt(self):
+        if self._engine.fields[self._k].is_ring:
+            return RingField(self._engine, self._k, 1)
         return DeviceField(self._engine.field_interior(self._k)[1])
 
     def compute_optimal_velocity(self, t, m):

@@ -91,9 +91,12 @@ RASTER_DEVICE_MIN_CELLS = 1 << 22      # 2048 x 2048 and larger: rasterise the r
 class simulation:
     def __init__(self, room, T, recompute=False, *, config=None, device="cuda:0", dtype="float32",
                  noise=None, seed=20240807, history=None, record=None, wall_search_radius=None, sharding=None,
-                 fixes=(), rasterise=None, update="synchronous"):
+                 fixes=(), rasterise=None, update="synchronous", field="ring"):
         """rasterise: 'host' (NumPy, like the reference), 'device' (oc_rasterise_potential, bit-identical; Vs[key] and
         V become lazily downloaded arrays) or None = 'device' from 2048 x 2048 grid nodes on.
+        field: 'ring' (default) -- an HJB solve keeps the accepted steps' interpolants and the step's lookups evaluate the
+        direction from them (same values, bit for bit; nothing of the ~950 slices per re-solve that are never read is
+        written) -- or 'slices': every slice of vx_opt / vy_opt is written, as the reference does (optimals.py:200-204).
         fixes: opt-in corrections of reference quirks, default none = bug-compatible (SURVEY quirk register):
         'lookup' (Q7/Q8: bilinear interpolation over the four nodes, no IndexError band), 'wall_force' and 'pair_force'
         (Q12: unit vectors, q_i with its square root, no factor 3), 'density_norm' (Q11: 2 pi sigma^2), 'horizon' (Q9: a
@@ -168,7 +171,7 @@ class simulation:
         self.hjb_dtype = hjb_state_dtype(var_config, T, dtype)
         self._engine = Engine(var_config, self.room_length, self.room_height, self.Nx, self.Ny, self._X0, self._Y0,
                               len(key_names), self.N, device=device, dtype=self.hjb_dtype,
-                              wall_search_radius=wall_search_radius)
+                              wall_search_radius=wall_search_radius, field_mode=field)
         eng = self._engine
         # ---- potentials (reference simulations.py:104-121, 516-576; finalised like optimals.__init__ does, Q3)
         if rasterise is None:

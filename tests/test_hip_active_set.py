@@ -36,11 +36,14 @@ def _same(a, b):
     ("exit_opposite", 0.1, "float32", 20.0, 1000, False),       # 512 x 512: the front reaches most of the room; rescales
     ("slalom", 0.1, "float32", 20.0, 1000, False),              # 1024 x 1024: walls shape the front
 ])
-def test_active_set_equals_dense_sweep(room_name, gs, dtype, T, nt, with_m):
+@pytest.mark.parametrize("field_mode", ["slices", "ring"])
+def test_active_set_equals_dense_sweep(room_name, gs, dtype, T, nt, with_m, field_mode):
+    """field_mode 'slices': the slice writer's own use of the flags (zero-filled tiles; the poison below catches a tile it
+    forgot); 'ring': the stage launch's flags in the ring's slots (the field is materialised from the ring)."""
     setup = _setup(room_name, gs)
     cfg, room, Nx, Ny, X0, Y0, V = setup
     m = _density_like(Ny, Nx) if with_m else None
-    eng = _new_engine(*setup, dtype)
+    eng = _new_engine(*setup, dtype, field_mode)
     eng.alloc_field(0, nt - 1)
     st_d, vx_d, vy_d, _ = _solve(eng, T, nt, m, active=False)
     # poison the field so that a tile the active-set path forgot to write cannot pass for a zero

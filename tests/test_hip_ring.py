@@ -1,0 +1,219 @@
+"""The interpolant ring (oc_hjb_solve_ring / oc_set_field_ring / oc_hjb_ring_slices): a solve that keeps what SciPy's dense
+output of each accepted step is made of (rk.py:178-180, 560-575) instead of every slice of vx_opt / vy_opt
+(reference optimals.py:200-204), and a lookup (optimals.py:212-250) that evaluates `vels` (optimals.py:168-186) at the one or
+two cells it reads.  The bar is equality, not closeness: every test compares with the slice-writing solve (oc_hjb_solve)
+on the same engine inputs and asks for identical bit patterns --
+  * slices materialised from the ring == the slices oc_hjb_solve writes (all of them, every dtype, with the exact active
+    set forced on, with a density term, at T = 20 with power-of-two rescales, after a re-solve with a shorter horizon);
+  * lookups through the ring == lookups in the slices, on crowds of probe positions at many steps, default and
+    OC_FIX_LOOKUP (bilinear) forms, IndexError-band flags included;
+  * a ring that is too small is reported (OC_ERR_CAPACITY) and grown, with the same result;
+  * whole runs of the facade: field='ring' and field='slices' leave the same agent states (to the rounding of the pair
+    sums' float64 atomics, the only thing that differs between two launches of the same step).
+"""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oc_oracle as oc                     # noqa: E402  (room rasterisation for the inputs only)
+from optimal_crowds_amd import room_library            # noqa: E402
+from test_hjb_rows import _density_like, _setup        # noqa: E402
+
+
+def _engine(setup, dtype, mode, n_agents=4096):
+    from optimal_crowds_amd.engine import Engine
+    cfg, room, Nx, Ny, X0, Y0, V = setup
+    eng = Engine(cfg, room["room_length"], room["room_height"], Nx, Ny, X0, Y0, 1, n_agents, dtype=dtype, field_mode=mode)
+    eng.set_potential(0, V, np.zeros((0, 4)))
+    return eng
+
+
+def _probe_agents(eng, room, n, seed):
+    rng = np.random.RandomState(seed)
+    L, H = room["room_length"], room["room_height"]
+    gs = L / (eng.Nx - 1)
+    x = rng.uniform(2.5 * gs, L - 3.5 * gs, n)
+    y = rng.uniform(2.5 * gs, H - 3.5 * gs, n)
+    # a few on the special branches of optimals.py:234-245: x <= dx, x >= L - dx, and exactly on grid lines
+    x[:8] = [0.3 * gs, gs, 1.0000001 * gs, L - 0.5 * gs, L - gs, 7 * gs, 0.0, L - 2.2 * gs]
+    y[8:16] = [0.3 * gs, gs, 1.0000001 * gs, H - 0.5 * gs, H - gs, 7 * gs, 0.0, H - 2.2 * gs]
+    eng.set_agents(x, y, np.zeros(n), np.zeros(n), rng.normal(1.34, 0.26, n), np.zeros(n, dtype=np.int32))
+
+
+def _lookups(eng, steps):
+    out = []
+    for s in steps:
+        des, err = eng.lookup(int(s))
+        out.append((des.cpu().numpy().copy(), err))
+    return out
+
+
+CASES = [
+    # room, grid_step, dtype, T, nt, density term, active set forced at this size
+    ("gold_a", 0.05, "float32", 3.0, 150, False, 0),
+    ("gold_a", 0.05, "float32", 3.0, 150, True, 2),
+    ("gold_b", 0.05, "float64", 2.0, 100, False, 2),
+    ("gold_b", 0.05, "mixed", 2.0, 100, True, 2),
+    ("room_test", 0.05, "float32", 20.0, 1000, False, 2),       # 200 x 200, 383 accepted steps, rescales
+    ("exit_opposite", 0.1, "float32", 20.0, 1000, False, 2),    # 512 x 512: the front crosses the room
+    ("slalom", 0.1, "float32", 20.0, 1000, False, 1),           # 1024 x 1024: the default rule switches the active set on
+]
+
+
+@pytest.mark.parametrize("room_name,gs,dtype,T,nt,with_m,active", CASES)
+def test_ring_equals_slices(room_name, gs, dtype, T, nt, with_m, active):
+    import torch
+    setup = _setup(room_name, gs)
+    cfg, room, Nx, Ny, X0, Y0, V = setup
+    m = torch.as_tensor(_density_like(Ny, Nx)) if with_m else None
+    res = {}
+    for mode in ("slices", "ring"):
+        eng = _engine(setup, dtype, mode)
+        eng.set_tuning("hjb_active", active)
+        eng.alloc_field(0, nt - 1)
+        keep = [0, 1, nt // 3, nt - 1]
+        st, phi = eng.solve(0, T, nt, m=m, keep=keep, want_steps=True)
+        if mode == "ring":
+            assert eng.fields[0].is_ring and eng.fields[0].vx is None          # nothing of the field is in memory
+        _probe_agents(eng, room, 3000, 5)
+        steps = [0, 1, 2, nt // 7, nt // 2, nt - 3, nt - 2, nt - 1, nt + 5]
+        look = _lookups(eng, steps)
+        vx, vy = eng.fields[0][0], eng.fields[0][1]             # ring: materialised here (oc_hjb_ring_slices)
+        res[mode] = (st, phi.cpu(), look, vx.cpu(), vy.cpu())
+        if mode == "ring":
+            # a sub-range lands where it was asked for
+            a, b = nt // 5, nt // 5 + 7
+            sx, sy = eng.ring_slices(0, a, b)
+            assert torch.equal(sx.cpu(), res["ring"][3][a:b]) and torch.equal(sy.cpu(), res["ring"][4][a:b])
+        eng.close()
+        del eng
+    (st_s, phi_s, look_s, vx_s, vy_s), (st_r, phi_r, look_r, vx_r, vy_r) = res["slices"], res["ring"]
+    for k in ("nfev", "n_attempt", "n_accept", "n_rescale", "final_exponent"):
+        assert st_r[k] == st_s[k], (k, st_r[k], st_s[k])
+    assert np.array_equal(st_r["t_steps"], st_s["t_steps"])
+    assert torch.equal(phi_r, phi_s)                            # the audit output comes from the ring too
+    assert torch.equal(vx_r, vx_s) and torch.equal(vy_r, vy_s)  # every slice, every cell, every bit
+    assert float(vx_s.abs().max()) > 0.5                        # (not a comparison of zeros)
+    for (d_s, e_s), (d_r, e_r) in zip(look_s, look_r):
+        assert e_s == e_r
+        assert np.array_equal(d_s, d_r)
+    assert any(np.abs(d).max() > 0 for d, _ in look_s)
+    if dtype == "float32" and T >= 20.0:
+        assert st_s["n_rescale"] >= 1
+
+
+def test_ring_bilinear_lookup_and_shorter_horizon():
+    """OC_FIX_LOOKUP through the ring; then a re-solve with a shorter horizon (reference optimals.py:139-142: nt shrinks,
+    the span does not -- quirk Q9): slices at and beyond nt - 1 are never read (lookup returns 0)."""
+    setup = _setup("gold_a", 0.05)
+    cfg, room, Nx, Ny, X0, Y0, V = setup
+    T, nt0, nt1 = 3.0, 150, 97
+    res = {}
+    for mode in ("slices", "ring"):
+        eng = _engine(setup, "float32", mode)
+        eng.alloc_field(0, nt0 - 1)
+        eng.solve(0, T, nt0)
+        _probe_agents(eng, room, 2000, 9)
+        steps = [0, 3, 50, 95, 96, 97, 120, 148, 149]
+        out = [_lookups(eng, steps)]
+        eng.set_fix_flags(["lookup"])
+        out.append(_lookups(eng, steps))
+        eng.set_fix_flags([])
+        eng.solve(0, T, nt1)                                     # the recompute
+        out.append(_lookups(eng, steps))
+        res[mode] = out
+        if mode == "ring":
+            for d, _ in out[2][4:]:                              # steps >= nt1 - 1: zero desired velocity
+                assert not d.any()
+            vx = eng.fields[0][0]
+            assert vx.shape[0] == nt0 - 1 and not bool(vx[nt1 - 1:].any())
+        eng.close()
+    for part_s, part_r in zip(res["slices"], res["ring"]):
+        for (d_s, e_s), (d_r, e_r) in zip(part_s, part_r):
+            assert e_s == e_r and np.array_equal(d_s, d_r)
+
+
+def test_ring_too_small_is_reported_and_grown():
+    import ctypes as C
+    import torch
+    from optimal_crowds_amd import _lib
+    setup = _setup("gold_a", 0.05)
+    T, nt = 3.0, 150
+    eng = _engine(setup, "float32", "ring")
+    eng.alloc_field(0, nt - 1)
+    st, _ = eng.solve(0, T, nt)
+    want = eng.fields[0][0].clone()
+    assert eng.fields[0].ring["slots"] >= st["n_accept"]
+    # the C-ABI reports it ...
+    ring = eng.make_ring(0, 5)
+    eng.make_coef(0, None)
+    stats = _lib.OcHjbStats()
+    rc = eng.lib.oc_hjb_solve_ring(eng.h, eng.solve_dtype, C.c_void_p(eng.coef.data_ptr()), T, nt, C.byref(ring["struct"]),
+                                   None, 0, None, None, 0, C.byref(stats), eng.stream())
+    assert rc == _lib.OC_ERR_CAPACITY and b"ring is too small" in eng.lib.oc_last_error()
+    # ... and the engine grows the ring until the solve fits: 5 -> 10 -> 20 -> ... slots
+    st2, _ = eng.solve(0, T, nt)
+    assert st2["n_accept"] == st["n_accept"] and eng.fields[0].ring["slots"] >= st["n_accept"]
+    assert eng.fields[0].ring["slots"] == 5 * 2 ** int(np.ceil(np.log2(st["n_accept"] / 5)))
+    assert torch.equal(eng.fields[0][0], want)
+    eng.close()
+
+
+def test_facade_ring_and_slices_runs_are_identical():
+    """simulations.simulation(...).run() with field='ring' (default) and field='slices': same np.random stream, same
+    agent states at the end (1e-10 m), same exits -- on a room with two keys and a recompute=True run (density term, shrinking
+    horizon every 50 steps)."""
+    from optimal_crowds_amd import simulations
+    out = {}
+    for mode in ("ring", "slices"):
+        for room, T, rec in (("gold_a", 4.0, False), ("gold_b", 4.0, True)):
+            np.random.seed(12)
+            sim = simulations.simulation(room, T, recompute=rec, field=mode)
+            sim.run()
+            st = sim._engine.get_state()
+            out[(mode, room)] = (st["x"].copy(), st["y"].copy(), st["vx"].copy(), st["status"].copy(), sim.simu_step, sim.inside)
+            if mode == "ring":
+                key = next(iter(sim.targets))
+                vx = sim.targets[key].vx_opt
+                assert vx.shape == (round(T / sim.dt) - 1, sim.Ny - 2, sim.Nx - 2)
+                a = vx[3]
+                assert a.shape == (sim.Ny - 2, sim.Nx - 2) and a.dtype == np.float64
+                assert np.array_equal(vx[2:5][1], a) and np.array_equal(vx[3, 5:9, 2], a[5:9, 2])
+            sim._engine.close()
+    # (the lookups are bit-identical -- the tests above; the pair sums of a step are float64 LDS atomics whose order is not
+    # fixed from launch to launch, so two RUNS agree to rounding, 1e-16 per step, whatever the field mode)
+    for room in ("gold_a", "gold_b"):
+        r, s = out[("ring", room)], out[("slices", room)]
+        assert r[4] == s[4] and r[5] == s[5]
+        assert np.array_equal(r[3], s[3])
+        for a, b in zip(r[:3], s[:3]):
+            assert np.allclose(a, b, rtol=0, atol=1e-10)
+
+
+def test_ring_equals_slices_at_config2_with_agents():
+    """C2 (exit_opposite 512 x 512, 5 000 agents, 2 keys): 120 synchronous steps from the same start, device noise --
+    the same positions (1e-10 m) with the ring and with slices."""
+    from optimal_crowds_amd import simulations
+    fin = {}
+    for mode in ("ring", "slices"):
+        np.random.seed(20240807)
+        sim = simulations.simulation("exit_opposite", 20.0, field=mode, noise="device", record=False,
+                                     config=_cfg(0.1))
+        sim._solve_all()
+        for s in range(120):
+            sim._engine.step(s, noise=None, seed=7, sync=False)
+        st = sim._engine.get_state()
+        fin[mode] = (st["x"].copy(), st["y"].copy(), st["vx"].copy(), st["vy"].copy())
+        sim._engine.close()
+    for a, b in zip(fin["ring"], fin["slices"]):
+        assert np.allclose(a, b, rtol=0, atol=1e-10)           # (equal up to the order of float64 atomic additions)
+    assert np.abs(fin["ring"][2]).max() > 0.1
+
+
+def _cfg(gs):
+    cfg = copy.deepcopy(oc.DEFAULT_CONFIG)
+    cfg["grid_step"] = gs
+    return cfg

@@ -32,9 +32,9 @@ def _setup(room_name, grid_step):
     return cfg, room, Nx, Ny, X0, Y0, V
 
 
-def _new_engine(cfg, room, Nx, Ny, X0, Y0, V, dtype):
+def _new_engine(cfg, room, Nx, Ny, X0, Y0, V, dtype, field_mode="ring"):
     from optimal_crowds_amd.engine import Engine
-    eng = Engine(cfg, room["room_length"], room["room_height"], Nx, Ny, X0, Y0, 1, 64, dtype=dtype)
+    eng = Engine(cfg, room["room_length"], room["room_height"], Nx, Ny, X0, Y0, 1, 64, dtype=dtype, field_mode=field_mode)
     eng.set_potential(0, V, np.zeros((0, 4)))
     return eng
 
