@@ -56,7 +56,7 @@ def csrc_hash():
     return hsh.hexdigest()[:16]
 
 
-def build_sim(workload, seed=20240807, wall_search_radius=-1.0, sharding=None, dtype="float32"):
+def build_sim(workload, seed=20240807, wall_search_radius=-1.0, sharding=None, dtype="float32", field="ring"):
     import io
     import contextlib
     from optimal_crowds_amd import host, simulations
@@ -66,7 +66,7 @@ def build_sim(workload, seed=20240807, wall_search_radius=-1.0, sharding=None, d
     np.random.seed(seed)
     with contextlib.redirect_stdout(io.StringIO()):
         sim = simulations.simulation(room, T, recompute, config=cfg, noise="device", seed=seed, record=False, history=False,
-                                     wall_search_radius=wall_search_radius, sharding=sharding, dtype=dtype)
+                                     wall_search_radius=wall_search_radius, sharding=sharding, dtype=dtype, field=field)
     return sim, cfg
 
 
@@ -133,19 +133,32 @@ def cpu_baseline(sim, cfg, workload, stt, budget_s=25.0):
     V = np.ascontiguousarray(sim.Vs[key])
     m = np.zeros_like(V)
     nt = sim._nt0
-    ns = min(nt - 1, 24)                                    # sample of output slices
-    keep = sorted(set(int(k) for k in np.linspace(1, nt - 1, ns)))
+    # ONE complete solve (every RK attempt) that keeps three slices -- early, middle, late -- for the direction-field
+    # timing; the dense output (SciPy's quartic interpolant, rk.py:560-575, one pass over y and the seven K per t_eval
+    # point) and `vels` are timed DIRECTLY on arrays of the solve's size, `ns` evaluations each, and scaled to the nt - 1
+    # slices the reference fills (optimals.py:200-204).  (Round 2 took the dense output as the difference of two ~3 s
+    # solves: +-40 % from run to run.)
+    keep = sorted(set(int(k) for k in np.linspace(1, nt - 1, 3)))
     t0 = time.perf_counter()
     phi, st = occ.rk45_solve(P, V, m, sim.T, nt, keep=keep)
-    t_attempts_and_sample = time.perf_counter() - t0
+    t_solve_kept = time.perf_counter() - t0
+    ns = 24
+    rng0 = np.random.RandomState(0)
+    ysyn = rng0.uniform(0.5, 1.5, V.size)
+    Ksyn = [rng0.uniform(-1.0, 1.0, V.size) for _ in range(7)]
+    occ.dense_output(ysyn, Ksyn, -0.2, 0.5)                 # (first touch of the output pages, thread team start)
     t0 = time.perf_counter()
-    phi1, _ = occ.rk45_solve(P, V, m, sim.T, nt, keep=keep[:1])
-    t_attempts = time.perf_counter() - t0                   # (a second solve: what the sample's dense output cost)
-    t_dense = max(t_attempts_and_sample - t_attempts, 0.0) / max(len(keep) - 1, 1)
+    for q in range(ns):
+        occ.dense_output(ysyn, Ksyn, -0.2, (q + 0.5) / ns)
+    t_dense = (time.perf_counter() - t0) / ns
+    del ysyn, Ksyn
+    occ.vels(P, phi[0])
     t0 = time.perf_counter()
-    for q in range(len(keep)):
-        occ.vels(P, phi[q])
-    t_vels = (time.perf_counter() - t0) / len(keep)
+    for q in range(ns):
+        occ.vels(P, phi[q % len(keep)])
+    t_vels = (time.perf_counter() - t0) / ns
+    t_attempts = max(t_solve_kept - len(keep) * t_dense, 0.0)
+    t_attempts_and_sample = t_solve_kept
     t_hjb = t_attempts + (nt - 1) * (t_dense + t_vels)
     # ---- GCFM: complete step(s) on the state the timed region started from
     N = sim.N
@@ -162,7 +175,7 @@ def cpu_baseline(sim, cfg, workload, stt, budget_s=25.0):
     n_probe = min(N, 512)
     t_probe = part(0, n_probe)
     est = t_probe / n_probe * N
-    gcfm_budget = max(budget_s - t_attempts_and_sample - t_attempts, 5.0)
+    gcfm_budget = max(budget_s - t_attempts_and_sample - ns * (t_dense + t_vels), 5.0)
     if est <= gcfm_budget:
         t_step, share = part(0, N), N
     else:
@@ -172,9 +185,9 @@ def cpu_baseline(sim, cfg, workload, stt, budget_s=25.0):
     value = nt / (K * t_hjb + nt * t_step)
     out = {"value": value, "unit": "steps/s", "cores": cores, "kind": "port",
            "sample": "C/OpenMP float64 oracle on %d threads (%s): HJB = one complete RK45 solve of one key, %d attempts "
-                     "(%.2f s) + dense output and direction field of %d of %d slices (%.4f + %.4f s each, scaled); "
+                     "(%.2f s) + dense output and direction field timed directly, %d evaluations each, scaled to %d slices (%.4f + %.4f s each); "
                      "GCFM = one synchronous step of %d of %d agents against all (%.2f s%s); value = nt / (K t_solve + "
-                     "nt t_step), K = %d, nt = %d" % (cores, json.dumps(lim), st["n_attempt"], t_attempts, len(keep),
+                     "nt t_step), K = %d, nt = %d" % (cores, json.dumps(lim), st["n_attempt"], t_attempts, ns,
                                                       nt - 1, t_dense, t_vels, share, N, t_step,
                                                       "" if share == N else ", scaled", K, nt),
            "t_hjb_solve_s": t_hjb, "t_step_s": t_step, "rk_attempts": st["n_attempt"], **lim}
@@ -248,13 +261,17 @@ def pmc_file(pattern, workload="metro_station"):
     return None
 
 
-def pmc_traffic(workload):
-    """HBM bytes per k_out launch from the committed PMC summary (profiles/rNN_pmc_traffic*.json: separate rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE passes of this very command, gfx950 FETCH_SIZE x2 correction applied by
+def pmc_traffic(workload, kernel_class="hjb_out"):
+    """HBM bytes per launch of a kernel class from the committed PMC summary (profiles/rNN_pmc_traffic*.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command, gfx950 FETCH_SIZE x2 correction applied by
     tools/collect_profiles.py).  Counters cannot be collected from inside the timed run, hence the file; null if the
     file is absent, belongs to another workload or was taken with other kernel sources."""
     d = pmc_file("r*_pmc_traffic*.json", workload)
-    return d.get("k_out_hbm_bytes_per_launch") if d else None
+    if not d:
+        return None
+    key = {"hjb_out": "k_out_hbm_bytes_per_launch", "hjb_stage": "k_stageV_hbm_bytes_per_launch",
+           "gcfm_forces": "k_forces_hbm_bytes_per_launch", "density": "k_density_hbm_bytes_per_launch"}.get(kernel_class)
+    return d.get(key)
 
 
 def pmc_step(workload):
@@ -308,6 +325,10 @@ def main():
                     help="do not also run the HJB solves with every tile computed (profiling passes: keeps the kernel "
                          "averages to the product path)")
     ap.add_argument("--tune", default="", help="launch-shape knobs, e.g. pair_split=4 (oc_set_tuning)")
+    ap.add_argument("--field", default="ring", choices=["ring", "slices"],
+                    help="what an HJB solve leaves in HBM: ring = the accepted steps' interpolants, lookups evaluate the "
+                         "direction from them (default, the product path); slices = every slice of vx_opt / vy_opt is written "
+                         "like the reference does (optimals.py:200-204)")
     ap.add_argument("--hjb-dtype", default="float32", choices=["float32", "mixed", "float64"],
                     help="HJB state: float32 (BASELINE's configs, default), mixed (float64 state, float32 field), float64")
     args = ap.parse_args()
@@ -346,9 +367,10 @@ def main():
     t_init = time.perf_counter()
     if sharded:     # one simulation on all ranks: same seed everywhere (replicated agents)
         sim, cfg = build_sim(args.workload, wall_search_radius=args.wall_radius, sharding=parallel.dist_sharding(),
-                             dtype=args.hjb_dtype)
+                             dtype=args.hjb_dtype, field=args.field)
     else:           # N = 1, or an ensemble: every rank simulates its own member (own placement and noise seed)
-        sim, cfg = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius, dtype=args.hjb_dtype)
+        sim, cfg = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius, dtype=args.hjb_dtype,
+                             field=args.field)
     t_init = time.perf_counter() - t_init
     eng = sim._engine
     for kv in filter(None, args.tune.split(",")):
@@ -370,34 +392,89 @@ def main():
     mine = [s for rnd in stats for s in rnd if s is not None]
     t_hjb = sum(s["seconds"] for s in mine)
     first = mine[0] if mine else None
+    ring = any(f is not None and f.is_ring for f in eng.fields)
     kstats = {}
-    for name in ("hjb_out", "hjb_stage", "gcfm_forces", "gcfm_finish", "density"):
+    for name in ("hjb_out", "hjb_stage", "hjb_list", "gcfm_forces", "gcfm_finish", "density"):
         nl, ms, by = eng.kernel_stats(name)
         kstats[name] = {"launches_timed": nl, "avg_ms": (ms / nl if nl else None),
                         "designed_GB_per_launch": (by / nl / 1e9 if nl else None),
                         "achieved_GBps": (by / (ms * 1e-3) / 1e9 if ms > 0 and by > 0 else None)}
-    # dominant HBM-bound kernel: the dense-output + direction-field writer (one launch per accepted RK step)
+    # ---- the dominant kernel of the timed region: launches x average event time per class (the HJB classes are sampled
+    # every 8th attempt, the step's every 16th step; the launch counts are exact)
+    n_att = sum(s_["n_attempt"] for s_ in mine)
+    n_acc = sum(s_["n_accept"] for s_ in mine)
+    launches = {"gcfm_forces": K, "gcfm_finish": K, "hjb_stage": n_att, "hjb_list": n_att if ring else 0,
+                "hjb_out": 0 if ring else n_acc, "density": max(len(stats) - max(1, -(-K // nt)), 0) if sim.recompute else 0}
+    for name, n_l in launches.items():
+        kstats[name]["launches_in_timed_region"] = n_l
+        kstats[name]["est_total_ms"] = (kstats[name]["avg_ms"] or 0.0) * n_l
+    # (the controller / list-builder launches and k_finish are latency-sized helpers: reported, never "the" kernel)
+    dominant = max((n_ for n_ in launches if n_ not in ("hjb_list", "gcfm_finish")), key=lambda n_: kstats[n_]["est_total_ms"])
+    kf = kstats["gcfm_forces"]
+    gw = None
+    if rank == 0 and kf.get("avg_ms") and not args.no_work_count and not sharded:
+        kn_ms = kstats["gcfm_finish"]["avg_ms"] or 0.0
+        gw = gcfm_work(sim, cfg, kf["avg_ms"] * 1e-3, (kf["avg_ms"] + kn_ms) * 1e-3)
+
+    def hbm_roof(name, kernel, note=None):
+        k_ = kstats[name]
+        if not k_["launches_timed"] or not k_["achieved_GBps"]:
+            return None
+        r = {"bound": "hbm", "kernel": kernel, "achieved": k_["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": k_["achieved_GBps"] / HBM_PEAK_GBS,
+             "traffic": pmc_traffic(args.workload, name), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, "
+             "profiles/; null unless taken with these kernel sources)",
+             "launches_timed": k_["launches_timed"], "avg_launch_ms": k_["avg_ms"],
+             "algorithmic_GB_per_launch": k_["designed_GB_per_launch"],
+             "share_of_timed_region_gpu_ms": k_["est_total_ms"]}
+        if note:
+            r["note"] = note
+        return r
+    stage_note = None
+    if active_set:
+        stage_note = ("exact active set: only the tiles where phi is not constant are loaded and computed (bytes = the designed "
+                      "passes x the solve's mean share of such tiles); with a few dozen listed tiles the launch is one tile's "
+                      "trip through its block -- latency, not bandwidth; the same launch with every tile computed is in "
+                      "`dense_sweep.k_stageV`")
+    roofs = {
+        "hjb_out": lambda: hbm_roof("hjb_out", "k_out (HJB dense output + direction-field writer)",
+                                    ("exact active set: the far field's slices are written as zeros without reads -- (almost) "
+                                     "a pure write stream of the whole direction field") if active_set else None),
+        "hjb_stage": lambda: hbm_roof("hjb_stage", "k_stageV (all six RK stages of an attempt in one launch%s)"
+                                      % ("; stores the step's interpolant into the ring" if ring else ""), stage_note),
+        "density": lambda: hbm_roof("density", "k_density (separable Gaussian splat)"),
+    }
     roof = None
-    ko = kstats["hjb_out"]
-    if ko["launches_timed"]:
-        ach = ko["achieved_GBps"]
-        roof = {"bound": "hbm", "kernel": "k_out (HJB dense output + direction-field writer)",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.workload), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, "
-                "profiles/; null unless taken with these kernel sources)",
-                "launches_timed": ko["launches_timed"], "avg_launch_ms": ko["avg_ms"],
-                "algorithmic_GB_per_launch": ko["designed_GB_per_launch"]}
-        if active_set:
-            roof["note"] = ("product path = exact active set: the far field's slices are written as zeros without reads, so the "
-                            "launch is (almost) a pure write stream of the whole direction field -- bytes = the field written + "
-                            "the state arrays of the non-trivial tiles; the dense sweep's launch (5 arrays read + the same "
-                            "writes, in the same time) is in `dense_sweep.k_out`")
+    if dominant in roofs:
+        roof = roofs[dominant]()
+    elif dominant in ("gcfm_forces", "gcfm_finish") and kf.get("avg_ms"):
+        # The step's force kernel is bound by vector-instruction issue and latency -- neither by HBM nor by MFMA (the pair
+        # "contraction" has inner dimension 2; 88 B of state per agent and step).  SURVEY 8d prescribes the fp32-vector
+        # fraction as its binding figure, with the HBM fraction beside it: achieved = 60 flop x near pairs / launch time.
+        roof = {"bound": "valu", "bound_note": "fp32 vector ALU (SURVEY 8d: the GCFM step is VALU/transcendental-bound, not "
+                "HBM, not MFMA); the contract's hbm / mfma choices do not apply to this kernel",
+                "kernel": "k_forces (pair forces + nearest-wall search + floor-field lookup)",
+                "achieved": gw["near_pair_TFLOPs"] if gw else None, "peak": 157.3, "unit": "TFLOP/s",
+                "frac": gw["near_pair_frac_of_fp32_vector_peak"] if gw else None,
+                "flop_model": "60 flop per ordered pair within the cutoff (SURVEY 8d), pairs counted on the final state",
+                "traffic": pmc_traffic(args.workload, "gcfm_forces"),
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, profiles/; null unless taken with these sources)",
+                "algorithmic_bytes_per_launch": 88.0 * (gw["active_agents"] if gw else sim.N),
+                "hbm_frac": (88.0 * gw["active_agents"] / (kf["avg_ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9)) if gw else None,
+                "launches_timed": kf["launches_timed"], "avg_launch_ms": kf["avg_ms"],
+                "share_of_timed_region_gpu_ms": kf["est_total_ms"]}
+    # the HBM-bound kernel that matters most, when the dominant kernel is not HBM-bound
+    roof_hbm = None
+    if roof is None or roof.get("bound") != "hbm":
+        cand = [n_ for n_ in ("hjb_stage", "hjb_out", "density") if kstats[n_]["est_total_ms"] > 0]
+        if cand:
+            roof_hbm = roofs[max(cand, key=lambda n_: kstats[n_]["est_total_ms"])]()
     keys_n = len(sim._key_names)
     parallelism = "single GPU"
     if world > 1:
         parallelism = ("one simulation on %d GPUs: keys first, then HJB row blocks; replicated agents" % world if sharded
                        else "ensemble of %d replicas, one per GPU" % world)
-    kf, kn = kstats["gcfm_forces"], kstats["gcfm_finish"]
+    kn = kstats["gcfm_finish"]
     kernel_step_ms = (kf["avg_ms"] + kn["avg_ms"]) if kf["avg_ms"] and kn["avg_ms"] else None
     result = {
         "metric": "sim steps/sec (HJB sweep + GCFM update), %s %d^2 grid x %d agents" % (args.workload, sim.Nx, sim.N),
@@ -411,11 +488,15 @@ def main():
                    "parallelism": parallelism, "mode": "sharded" if sharded else ("ensemble" if world > 1 else "single"),
                    "noise": "device Philox", "agent_state": "f64", "pair_math": "f32",
                    "hjb_state": {"float32": "f32", "mixed": "f64", "float64": "f64"}[sim.hjb_dtype],
-                   "hjb_field": "f64" if sim.hjb_dtype == "float64" else "f32",
-                   "hjb_active_set": ("exact: tiles where phi is constant and K = 0 are not computed; every slice of the "
-                                      "direction field is written (bit-identical to the dense sweep)") if active_set
+                   "hjb_field_type": "f64" if sim.hjb_dtype == "float64" else "f32",
+                   "hjb_field": ("ring: the accepted steps' interpolants stay in HBM, lookups evaluate the direction from them "
+                                 "(bit-identical to the slices)") if ring else "slices: every slice of vx_opt / vy_opt is written",
+                   "hjb_active_set": ("exact: tiles where phi is constant and K = 0 are not computed (bit-identical to the "
+                                      "dense sweep)") if active_set
                    else "off: every tile of every attempt is computed"},
         "roofline": roof,
+        "roofline_hbm": roof_hbm,
+        "dominant_kernel_class": dominant,
         "breakdown": {"hjb_solve_s_total_this_rank": t_hjb, "hjb_solves_this_rank": len(mine),
                       "gcfm_kernel_ms_per_step": kernel_step_ms,
                       "gcfm_kernel_ms_note": "k_forces + k_finish HIP-event times, sampled every 16th step (the steps are "
@@ -458,9 +539,9 @@ def main():
             result["roofline_valu"]["occupancy"] = {
                 "waves_per_simd_hardware": 8, "mean_resident_waves_per_simd": 4.0 * wc / (bc / 32.0) / 1024.0,
                 "waves_per_launch": nw, "source": "SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAVES (profiles/)"}
-    if rank == 0 and kf.get("avg_ms") and not args.no_work_count and not sharded:
-        result["breakdown"]["gcfm_work"] = gcfm_work(sim, cfg, kf["avg_ms"] * 1e-3, (kernel_step_ms or 1.0) * 1e-3)
-    if rank == 0 and world == 1 and active_set and roof is not None and not args.no_dense_line:
+    if gw is not None:
+        result["breakdown"]["gcfm_work"] = gw
+    if rank == 0 and world == 1 and active_set and not args.no_dense_line:
         # the same solve with every tile computed (one untimed round, right after): the dense sweep's kernels beside it
         eng.set_tuning("hjb_active", 0)
         eng.reset_kernel_stats()
@@ -480,7 +561,7 @@ def main():
             "what": "the same HJB solves with hjb_active=0 (every tile of every attempt computed), one untimed round",
             "hjb_solve_s_per_key": t_dense / max(len(dstat), 1), "rk_attempts": dstat[0]["n_attempt"] if dstat else None,
             "k_out": dict(dk["hjb_out"], frac_of_hbm_peak=(dk["hjb_out"]["achieved_GBps"] or 0) / HBM_PEAK_GBS),
-            "k_stageV": dk["hjb_stage"]}
+            "k_stageV": dict(dk["hjb_stage"], frac_of_hbm_peak=(dk["hjb_stage"]["achieved_GBps"] or 0) / HBM_PEAK_GBS)}
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(sim, cfg, args.workload, state0,
                                               budget_s=float(os.environ.get("OC_BENCH_CPU_BUDGET", "25")))
@@ -489,7 +570,7 @@ def main():
         eng.close()
         del sim, eng
         torch.cuda.empty_cache()
-        sim2, _ = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius)
+        sim2, _ = build_sim(args.workload, seed=20240807 + rank, wall_search_radius=args.wall_radius, field=args.field)
         el2, _, _ = measure(sim2, args, nt, world, dist, red_dev)
         result["ensemble"] = {"value": world * K / el2, "unit": "steps/s (aggregate over %d independent replicas)" % world,
                               "scaling": "weak", "ms_per_step_per_replica": 1e3 * el2 / K}

@@ -47,6 +47,15 @@ struct KeyDev {
     double rect[OC_MAX_TARGET_RECTS][4];
 };
 
+// What a lookup through the interpolant ring needs of (key, simulation step), resolved ONCE per step and key instead of
+// by every lane through two dependent loads (slice table -> slot record): written by k_ring_step, or by k_finish for the
+// step that follows it.  Values of the ring's type T are held as doubles (exact for float).
+struct KeyStep {
+    const void* slot;           // the slot's data, or NULL: no ring / the step lies beyond the horizon
+    const uint8_t* flags;       // its tile flags, or NULL: every stage tile holds data
+    double h[4], lim_s, u;
+};
+
 struct GcfmParams {
     int32_t Ny, Nx;
     double dx, dy, L, H, dt;
@@ -1044,15 +1053,13 @@ struct RingCtx {
 };
 
 template <typename T>
-__device__ __forceinline__ RingCtx<T> ring_open(const GcfmParams& P, const KeyDev& kd, int step) {
+__device__ __forceinline__ RingCtx<T> ring_open(const GcfmParams& P, const KeyDev& kd, const KeyStep& ks) {
     RingCtx<T> c;
-    const OcRingSlice<T> sl = ((const OcRingSlice<T>*)kd.ring_slices)[step];
-    const OcRingSlot<T> rs = ((const OcRingSlot<T>*)kd.ring_slots)[sl.slot];
-    c.slot = (const T*)kd.ring_data + (size_t)sl.slot * (size_t)kd.ring_slot_elems;
-    c.flags = rs.dense ? nullptr : kd.ring_flags + (size_t)sl.slot * kd.ring_ntile;
-    c.h1 = sl.h[0]; c.h2 = sl.h[1]; c.h3 = sl.h[2]; c.h4 = sl.h[3];
-    c.lim_s = rs.lim_s;
-    c.u = rs.u;
+    c.slot = (const T*)ks.slot;
+    c.flags = ks.flags;
+    c.h1 = (T)ks.h[0]; c.h2 = (T)ks.h[1]; c.h3 = (T)ks.h[2]; c.h4 = (T)ks.h[3];
+    c.lim_s = (T)ks.lim_s;
+    c.u = (T)ks.u;
     c.mu = (T)P.mu;
     c.lim = (T)P.lim;
     c.inv2dx = (T)(1.0 / (2 * P.dx));
@@ -1064,17 +1071,39 @@ __device__ __forceinline__ RingCtx<T> ring_open(const GcfmParams& P, const KeyDe
     return c;
 }
 
+// the step's entry of the table, for one key (k_ring_step / k_finish)
+template <typename T>
+__device__ __forceinline__ void ring_step_of(const KeyDev& kd, int step, KeyStep& out) {
+    const OcRingSlice<T> sl = ((const OcRingSlice<T>*)kd.ring_slices)[step];
+    const OcRingSlot<T> rs = ((const OcRingSlot<T>*)kd.ring_slots)[sl.slot];
+    out.slot = (const T*)kd.ring_data + (size_t)sl.slot * (size_t)kd.ring_slot_elems;
+    out.flags = rs.dense ? nullptr : kd.ring_flags + (size_t)sl.slot * kd.ring_ntile;
+    for (int q = 0; q < 4; ++q) out.h[q] = (double)sl.h[q];
+    out.lim_s = (double)rs.lim_s;
+    out.u = (double)rs.u;
+}
+__device__ __forceinline__ void ring_step_prepare(const KeyDev& kd, int step, KeyStep& out) {
+    out.slot = nullptr;
+    out.flags = nullptr;
+    if (kd.ring_data == nullptr || step < 0 || step >= kd.nt_opt - 1 || step >= kd.nslice_alloc) return;
+    if (kd.ring_state_dtype == OC_F32) ring_step_of<float>(kd, step, out);
+    else ring_step_of<double>(kd, step, out);
+}
+__global__ void k_ring_step(const KeyDev* __restrict__ keys, int nkeys, int step, KeyStep* __restrict__ ksteps) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nkeys) ring_step_prepare(keys[k], step, ksteps[k]);
+}
+
 // clipped phi(t_eval) at LOCAL row r, column c (optimals.py:172)
 template <typename T>
 __device__ __forceinline__ T ring_phi(const RingCtx<T>& c, int r, int cc) {
-    T ph;
-    if (c.flags != nullptr && c.flags[(r / OC_RING_STY) * c.tnbx + cc / OC_RING_STX] != 0) {
-        ph = c.u;                       // (u + h (0 x + 0 x^2 + ...) = u)
-    } else {
-        const T* b = c.slot + ((size_t)r * c.Nx + cc >> 2) * (4 * OC_RING_VALS) + (cc & 3);
-        const T y = b[0], q0 = b[4], q1 = b[8], q2 = b[12], q3 = b[16];
-        ph = y + fma_t(q3, c.h4, fma_t(q2, c.h3, fma_t(q1, c.h2, q0 * c.h1)));
-    }
+    // (the loads are issued whatever the flag says -- a trivial tile's slot memory exists, its content is simply not used --
+    // so that the five cells' flags and values of a lookup are all in flight together: one level of latency)
+    const T* b = c.slot + ((size_t)r * c.Nx + cc >> 2) * (4 * OC_RING_VALS) + (cc & 3);
+    const T y = b[0], q0 = b[4], q1 = b[8], q2 = b[12], q3 = b[16];
+    const bool triv = c.flags != nullptr && c.flags[(r / OC_RING_STY) * c.tnbx + cc / OC_RING_STX] != 0;
+    T ph = y + fma_t(q3, c.h4, fma_t(q2, c.h3, fma_t(q1, c.h2, q0 * c.h1)));
+    ph = triv ? c.u : ph;               // (u + h (0 x + 0 x^2 + ...) = u)
     return (ph > c.lim_s) ? ph : ((ph < c.lim_s) ? c.lim_s : (T)0);
 }
 
@@ -1094,18 +1123,18 @@ __device__ __forceinline__ double2 ring_dir(const RingCtx<T>& c, int Ny, int gr,
 }
 
 template <typename T, typename TO>
-__device__ __forceinline__ double2 ring_fetch(const GcfmParams& P, const KeyDev& kd, int step, int i0, int i1, int j0,
+__device__ __forceinline__ double2 ring_fetch(const GcfmParams& P, const KeyDev& kd, const KeyStep& ks, int i0, int i1, int j0,
                                               int j1) {
     // interior index i of the reference's (Ny-2, Nx-2) array is grid row i + 1 (field_fetch)
-    const RingCtx<T> c = ring_open<T>(P, kd, step);
+    const RingCtx<T> c = ring_open<T>(P, kd, ks);
     const double2 a = ring_dir<T, TO>(c, P.Ny, i0 + 1, j0 + 1), b = ring_dir<T, TO>(c, P.Ny, i1 + 1, j1 + 1);
     return make_double2((a.x + b.x) / 2, (a.y + b.y) / 2);
 }
 
 template <typename T, typename TO>
-__device__ __forceinline__ double2 ring_bilinear(const GcfmParams& P, const KeyDev& kd, int step, int r0, int r1, int c0,
+__device__ __forceinline__ double2 ring_bilinear(const GcfmParams& P, const KeyDev& kd, const KeyStep& ks, int r0, int r1, int c0,
                                                  int c1, double fy, double fx) {
-    const RingCtx<T> c = ring_open<T>(P, kd, step);
+    const RingCtx<T> c = ring_open<T>(P, kd, ks);
     const double2 g00 = ring_dir<T, TO>(c, P.Ny, r0, c0), g01 = ring_dir<T, TO>(c, P.Ny, r0, c1);
     const double2 g10 = ring_dir<T, TO>(c, P.Ny, r1, c0), g11 = ring_dir<T, TO>(c, P.Ny, r1, c1);
     const double w00 = (1.0 - fy) * (1.0 - fx), w01 = (1.0 - fy) * fx, w10 = fy * (1.0 - fx), w11 = fy * fx;
@@ -1129,8 +1158,8 @@ __device__ __forceinline__ double2 field_bilinear(const KeyDev& kd, int step, in
         w00 * (double)gy[a + c0] + w01 * (double)gy[a + c1] + w10 * (double)gy[b + c0] + w11 * (double)gy[b + c1]);
 }
 
-__device__ __forceinline__ double2 lookup_bilinear(const GcfmParams& P, const KeyDev& kd, double x, double y,
-                                                   double vdes, int step) {
+__device__ __forceinline__ double2 lookup_bilinear(const GcfmParams& P, const KeyDev& kd, const KeyStep& ks, double x,
+                                                   double y, double vdes, int step) {
     const int Nx = P.Nx, Ny = P.Ny;
     if (step >= kd.nslice_alloc) return make_double2(0.0, 0.0);
     // node j sits at X0[j] = j * L / (Nx - 1); the field lives on the interior nodes 1 .. Nx-2 (clamped outside)
@@ -1150,9 +1179,10 @@ __device__ __forceinline__ double2 lookup_bilinear(const GcfmParams& P, const Ke
     if (kd.rows >= 0 && (r1 < kd.row0 || r1 >= kd.row0 + kd.rows)) r1 = r0;
     double2 d;
     if (kd.ring_data != nullptr) {
-        if (kd.ring_state_dtype == OC_F32) d = ring_bilinear<float, float>(P, kd, step, r0, r1, c0, c1, fy, fx);
-        else if (kd.dtype == OC_F32) d = ring_bilinear<double, float>(P, kd, step, r0, r1, c0, c1, fy, fx);
-        else d = ring_bilinear<double, double>(P, kd, step, r0, r1, c0, c1, fy, fx);
+        if (ks.slot == nullptr) return make_double2(0.0, 0.0);
+        if (kd.ring_state_dtype == OC_F32) d = ring_bilinear<float, float>(P, kd, ks, r0, r1, c0, c1, fy, fx);
+        else if (kd.dtype == OC_F32) d = ring_bilinear<double, float>(P, kd, ks, r0, r1, c0, c1, fy, fx);
+        else d = ring_bilinear<double, double>(P, kd, ks, r0, r1, c0, c1, fy, fx);
     } else {
         d = (kd.dtype == OC_F32) ? field_bilinear<float>(kd, step, r0, r1, c0, c1, fy, fx, Nx, Ny)
                                  : field_bilinear<double>(kd, step, r0, r1, c0, c1, fy, fx, Nx, Ny);
@@ -1161,10 +1191,10 @@ __device__ __forceinline__ double2 lookup_bilinear(const GcfmParams& P, const Ke
 }
 
 // des = v_des * choose_optimal_velocity(pos, step)  (optimals.py:212-250, simulations.py:281)
-__device__ __forceinline__ double2 lookup(const GcfmParams& P, const KeyDev& kd, double x, double y, double vdes,
-                                          int step, int agent, int32_t* err) {
+__device__ __forceinline__ double2 lookup(const GcfmParams& P, const KeyDev& kd, const KeyStep& ks, double x, double y,
+                                          double vdes, int step, int agent, int32_t* err) {
     if (step >= kd.nt_opt - 1) return make_double2(0.0, 0.0);
-    if (P.fix & OC_FIX_LOOKUP) return lookup_bilinear(P, kd, x, y, vdes, step);
+    if (P.fix & OC_FIX_LOOKUP) return lookup_bilinear(P, kd, ks, x, y, vdes, step);
     const int Nx = P.Nx, Ny = P.Ny;
     int j0, j1, i0, i1;
     if (x < P.L - P.dx) {
@@ -1200,9 +1230,10 @@ __device__ __forceinline__ double2 lookup(const GcfmParams& P, const KeyDev& kd,
                                                                                       // agent outside the room)
     double2 d;
     if (kd.ring_data != nullptr) {
-        if (kd.ring_state_dtype == OC_F32) d = ring_fetch<float, float>(P, kd, step, i0, i1, j0, j1);
-        else if (kd.dtype == OC_F32) d = ring_fetch<double, float>(P, kd, step, i0, i1, j0, j1);
-        else d = ring_fetch<double, double>(P, kd, step, i0, i1, j0, j1);
+        if (ks.slot == nullptr) return make_double2(0.0, 0.0);
+        if (kd.ring_state_dtype == OC_F32) d = ring_fetch<float, float>(P, kd, ks, i0, i1, j0, j1);
+        else if (kd.dtype == OC_F32) d = ring_fetch<double, float>(P, kd, ks, i0, i1, j0, j1);
+        else d = ring_fetch<double, double>(P, kd, ks, i0, i1, j0, j1);
     } else {
         d = (kd.dtype == OC_F32) ? field_fetch<float>(kd, step, i0, i1, j0, j1, Nx, Ny)
                                  : field_fetch<double>(kd, step, i0, i1, j0, j1, Nx, Ny);
@@ -1242,8 +1273,9 @@ struct StepArgs {               // caller-owned state (agent order) and the step
 // -> field) with little arithmetic: it runs in spare wavefronts beside the pair forces and leaves k_finish one level
 // of loads.
 __device__ __forceinline__ void prep_tile(const GcfmParams& P, const Scratch& S, const Snap& C,
-                                          const KeyDev* __restrict__ keys, int step, const Axis X0, const Axis Y0,
-                                          int it, int lane, int32_t* err, bool do_wall, bool do_lookup) {
+                                          const KeyDev* __restrict__ keys, const KeyStep* __restrict__ ksteps, int step,
+                                          const Axis X0, const Axis Y0, int it, int lane, int32_t* err, bool do_wall,
+                                          bool do_lookup) {
     const int k = it * 64 + lane;
     const int i = C.pidx[k];
     const bool act = i >= 0;
@@ -1255,7 +1287,7 @@ __device__ __forceinline__ void prep_tile(const GcfmParams& P, const Scratch& S,
     // the tile's owner when every rank holds the whole field; what a rank does not compute stays zero for the sum)
     if (do_lookup) {
         double2 ds = make_double2(0.0, 0.0);
-        if (act) ds = lookup(P, kd, p.x, p.y, dk.v_des, step, i, err);      // its loads fly during the search
+        if (act) ds = lookup(P, kd, ksteps[dk.key], p.x, p.y, dk.v_des, step, i, err);     // its loads fly during the search
         S.des[k] = ds;
     }
     if (do_wall) {
@@ -1281,9 +1313,9 @@ struct TileShare {              // which tiles this launch works on (the whole s
 // CU resident.
 // FIX = false: the OC_FIX_* corrections are compiled out (the default, bug-compatible kernel pays nothing for them)
 template <int NS, bool FIX>
-__global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, int step,
-                                                const Axis X0, const Axis Y0, int nprep, TileShare sh,
-                                                int32_t* __restrict__ cnt_out) {
+__global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
+                                                const KeyStep* __restrict__ ksteps, int step, const Axis X0, const Axis Y0,
+                                                int nprep, TileShare sh, int32_t* __restrict__ cnt_out) {
     __shared__ PairLds<NS> L;
     if (!FIX) __builtin_assume(P.fix == 0u);        // (launch_step picks FIX = true whenever a bit is set)
     const Snap& C = S.snap;
@@ -1299,7 +1331,7 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
         for (int t = blockIdx.x * 4 + w; t < S.ntiles; t += nprep * 4) {
             const bool mine = t >= sh.lo && t < sh.hi;
             if ((mine || sh.lookup_all) && !(P.diag & 2u))
-                prep_tile(P, S, C, keys, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8], mine, mine || sh.lookup_all);
+                prep_tile(P, S, C, keys, ksteps, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8], mine, mine || sh.lookup_all);
         }
         return;
     }
@@ -1328,10 +1360,14 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
 template <bool SEQ>
 __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const double* __restrict__ rect_tab, int nkeys,
                                                StepArgs A, int seq_round, double seq_margin,
-                                               const double* __restrict__ err_slots, int n_err_slots) {
+                                               const double* __restrict__ err_slots, int n_err_slots,
+                                               const KeyDev* __restrict__ keys, KeyStep* __restrict__ ksteps) {
     __shared__ double l_rect[RECT_KEYS_LDS * RECT_TAB];
     const Snap& C = S.snap;
     const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
+    // the NEXT step's ring lookups (interpolant ring: slice -> slot, factors): resolved here, once per key, off every path
+    if (ksteps != nullptr && it == (int)gridDim.x - 1)
+        for (int q = lane; q < nkeys; q += 64) ring_step_prepare(keys[q], A.step + 1, ksteps[q]);
     const bool tab_lds = nkeys <= RECT_KEYS_LDS;
     if (tab_lds)
         for (int q = lane; q < nkeys * RECT_TAB; q += 64) l_rect[q] = rect_tab[q];
@@ -1563,8 +1599,8 @@ __global__ void __launch_bounds__(64) k_seq_pairs(GcfmParams P, Scratch S, int r
 }
 
 // ---------------------------------------------------------------------------------- diagnostics (single-shot exports)
-__global__ void k_lookup_diag(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys, int step,
-                              int32_t* err) {
+__global__ void k_lookup_diag(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
+                              const KeyStep* __restrict__ ksteps, int step, int32_t* err) {
     const Snap& C = S.snap;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= S.Np) return;
@@ -1573,7 +1609,7 @@ __global__ void k_lookup_diag(GcfmParams P, Scratch S, const KeyDev* __restrict_
     if (i >= 0) {
         double2 p = C.ppos[k];
         const PDK dk = S.pdk[k];
-        d = lookup(P, keys[dk.key], p.x, p.y, dk.v_des, step, i, err);
+        d = lookup(P, keys[dk.key], ksteps[dk.key], p.x, p.y, dk.v_des, step, i, err);
     }
     S.des[k] = d;
 }
@@ -1776,7 +1812,12 @@ int upload_keys(oc_handle* h, hipStream_t s) {
     if (!h->key_tables_dev) {
         OC_HIP_CHECK(hipMalloc(&h->key_tables_dev, sizeof(KeyDev) * nk));
         OC_HIP_CHECK(hipMalloc(&h->rect_tab_dev, sizeof(double) * nk * RECT_TAB));
+        OC_HIP_CHECK(hipMalloc(&h->key_steps_dev, sizeof(KeyStep) * nk));
+        OC_HIP_CHECK(hipMemset(h->key_steps_dev, 0, sizeof(KeyStep) * nk));
     }
+    h->ring_step_ready = -1;            // (the per-step ring table was resolved from the old descriptors)
+    h->any_ring = false;
+    for (size_t k = 0; k < nk; ++k) h->any_ring = h->any_ring || h->fields[k].ring_data != nullptr;
     // synchronous copy of a small table: happens only when a field / target / wall map changed
     OC_HIP_CHECK(hipStreamSynchronize(s));
     OC_HIP_CHECK(hipMemcpy(h->key_tables_dev, host.data(), sizeof(KeyDev) * nk, hipMemcpyHostToDevice));
@@ -1890,8 +1931,13 @@ extern "C" int oc_field_lookup(oc_handle* h, const oc_agents* a, int32_t simu_st
     h->packed_valid = false;
     OC_HIP_CHECK(hipMemsetAsync(des, 0, sizeof(double) * 2 * (size_t)a->N, s));
     if (err_flag) OC_HIP_CHECK(hipMemsetAsync(err_flag, 0, sizeof(int32_t) * 2, s));
+    if (h->any_ring) {
+        hipLaunchKernelGGL(k_ring_step, dim3(1), dim3(64 * (((int)h->fields.size() + 63) / 64)), 0, s,
+                           (const KeyDev*)h->key_tables_dev, (int)h->fields.size(), simu_step, (KeyStep*)h->key_steps_dev);
+        h->ring_step_ready = simu_step;
+    }
     hipLaunchKernelGGL(k_lookup_diag, dim3((S.Np + 255) / 256), dim3(256), 0, s, P, S, (const KeyDev*)h->key_tables_dev,
-                       simu_step, err_flag);
+                       (const KeyStep*)h->key_steps_dev, simu_step, err_flag);
     hipLaunchKernelGGL(k_scatter<double2>, dim3((S.Np + 255) / 256), dim3(256), 0, s, S.des, S.snap.pidx, S.Np,
                        (double2*)des);
     OC_HIP_CHECK(hipGetLastError());
@@ -1974,9 +2020,15 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
     }
     auto kf = P.fix ? (ns == 4 ? k_forces<4, true> : (ns == 2 ? k_forces<2, true> : k_forces<1, true>))
                     : (ns == 4 ? k_forces<4, false> : (ns == 2 ? k_forces<2, false> : k_forces<1, false>));
+    KeyStep* const ksteps = (KeyStep*)h->key_steps_dev;
+    const int nkeys = (int)h->fields.size();
+    if (h->any_ring && h->ring_step_ready != (int64_t)simu_step) {     // (the previous step's k_finish resolves it otherwise)
+        hipLaunchKernelGGL(k_ring_step, dim3(1), dim3(64 * ((nkeys + 63) / 64)), 0, s, kd, nkeys, simu_step, ksteps);
+        h->ring_step_ready = simu_step;
+    }
     oc_timer_begin(h, "gcfm_forces", s);
-    hipLaunchKernelGGL(kf, dim3(nprep + npair), dim3(256), 0, s, P, S, kd, simu_step, axis_x(h), axis_y(h), nprep, share,
-                       A.cnt_out);
+    hipLaunchKernelGGL(kf, dim3(nprep + npair), dim3(256), 0, s, P, S, kd, (const KeyStep*)ksteps, simu_step, axis_x(h),
+                       axis_y(h), nprep, share, A.cnt_out);
     oc_timer_end(h, "gcfm_forces", s);
     h->work_valid = share.by_work != 0;     // (a rank's share measures only its own tiles)
     h->work_tiles = S.ntiles;
@@ -1993,7 +2045,8 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
     }
     oc_timer_begin(h, "gcfm_finish", s);
     hipLaunchKernelGGL(k_finish<false>, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
-                       (int)h->fields.size(), A, 0, 0.0, err_slots, n_err_slots);
+                       (int)h->fields.size(), A, 0, 0.0, err_slots, n_err_slots, kd, h->any_ring ? ksteps : (KeyStep*)nullptr);
+    if (h->any_ring) h->ring_step_ready = (int64_t)simu_step + 1;
     oc_timer_end(h, "gcfm_finish", s);
     OC_HIP_CHECK(hipGetLastError());
     h->packed_valid = true;
@@ -2067,8 +2120,13 @@ extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t
         const int nprep = std::max((S.ntiles + 3) / 4, 1);
         const TileShare all = {0, S.ntiles, 0, 0};
         auto kf = P.fix ? k_forces<4, true> : k_forces<4, false>;
-        hipLaunchKernelGGL(kf, dim3(nprep), dim3(256), 0, s, P, S, kd, simu_step, axis_x(h), axis_y(h), nprep, all,
-                           A.cnt_out);
+        if (h->any_ring && h->ring_step_ready != (int64_t)simu_step) {
+            hipLaunchKernelGGL(k_ring_step, dim3(1), dim3(64 * (((int)h->fields.size() + 63) / 64)), 0, s, kd,
+                               (int)h->fields.size(), simu_step, (KeyStep*)h->key_steps_dev);
+            h->ring_step_ready = simu_step;
+        }
+        hipLaunchKernelGGL(kf, dim3(nprep), dim3(256), 0, s, P, S, kd, (const KeyStep*)h->key_steps_dev, simu_step, axis_x(h),
+                           axis_y(h), nprep, all, A.cnt_out);
     }
     GcfmParams Pf = P;
     Pf.drift = P.drift - margin;            // validity bound of the neighbour lists in this mode (see above)
@@ -2079,7 +2137,7 @@ extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t
         for (int b = 0; b < burst; ++b, ++rounds) {
             hipLaunchKernelGGL(k_seq_pairs, dim3(S.ntiles), dim3(64), 0, s, P, S, rounds, margin);
             hipLaunchKernelGGL((k_finish<true>), dim3(S.ntiles), dim3(64), 0, s, Pf, S, (const double*)h->rect_tab_dev,
-                               (int)h->fields.size(), A, rounds, margin, (const double*)nullptr, 0);
+                               (int)h->fields.size(), A, rounds, margin, (const double*)nullptr, 0, kd, (KeyStep*)nullptr);
         }
         OC_HIP_CHECK(hipMemcpyAsync(ctl, S.seq_ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
         OC_HIP_CHECK(hipStreamSynchronize(s));

@@ -60,6 +60,7 @@ struct HjbCtl {
     double hh, t_new;                   // the attempt about to run: step and its end time
     double out_t, out_hh, out_unscale;  // the step just accepted (k_out): its start, length and 2^expo
     double h_min, h_max;
+    double h_abs0;                      // the initial step select_initial_step chose (k_init_step)
     double act_sum;                     // stage tiles with a non-zero error share, summed over the attempts (active-set statistics)
     int32_t nt, k_next;                 // t_eval = linspace(T, 0, nt); next index to emit
     int32_t parity;                     // y = Y[parity], y_new = Y[1 - parity], K0 = KX[parity], K6 = KX[1 - parity]
@@ -337,47 +338,75 @@ __global__ void __launch_bounds__(1024) k_reduce_final(const double* __restrict_
 // att_log[attempt]: bit 0 = a real attempt, bit 1 = accepted, bits 8.. = direction-field slices its k_out writes.
 // mailbox (pinned host memory): ONE word = ticks (control launches so far) + 2^32 * done -- a single store, so the host
 // never sees a torn pair and the kernel needs no system-scope fence.
+// what the attempt's blocks wrote for the controller, read by the LAST block of the same launch (fused tail, SC1): every such
+// word was stored `sc1` by one lane of its block before that block's ticket (MI355X_MICROARCH.md, inter-workgroup
+// visibility: sc1 stores + drained + agent-scope add; the last adder reads with sc1 loads).  Plain loads behind a kernel boundary.
+template <bool SC1>
+__device__ __forceinline__ double ld_part(const double* p) {
+    return SC1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool SC1>
+__device__ __forceinline__ int32_t ld_flag(const int32_t* p) {
+    return SC1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, const double* parts,
-                                                 int nparts, double* __restrict__ t_steps, int t_cap,
-                                                 int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox,
-                                                 int active_set = 0, OcRingSlot<T>* __restrict__ rslots = nullptr,
-                                                 OcRingSlice<T>* __restrict__ rslices = nullptr, int ring_cap = 0) {
-    // the controller block is worked on in LDS (one coalesced load, one coalesced store): thread 0's serial code would
-    // otherwise pay a memory round trip for every field it touches
-    __shared__ HjbCtl<T> c;
-    __shared__ double ls[4], lm[4], la[4];
-    __shared__ int all_active;          // every tile had an error share: all were computed, the next work list is every tile
+struct CtlLds {
+    HjbCtl<T> c;                        // the controller block is worked on in LDS (one coalesced load, one coalesced store):
+    double ls[4], lm[4], la[4];         // thread 0's serial code would otherwise pay a memory round trip per field
+    int all_active;                     // every tile had an error share: all were computed, the next work list is every tile
+};
+
+// Called by EVERY thread of the block (barriers inside); threads 0 .. 255 do the work -- the same reduction tree whatever the
+// block's size, so the launch shape never changes a decision.  ctl_in: the attempt's controller block; ctl_out: where the
+// next attempt's goes (the two alternate, so that a late block of the attempt's own launch never reads a block that the
+// fused tail is already rewriting).
+template <typename T, bool SC1>
+__device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_in, HjbCtl<T>* __restrict__ ctl_out,
+                                             const double* parts, int nparts, double* __restrict__ t_steps, int t_cap,
+                                             int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox,
+                                             int active_set, OcRingSlot<T>* __restrict__ rslots,
+                                             OcRingSlice<T>* __restrict__ rslices, int ring_cap, CtlLds<T>& L,
+                                             bool store_out = true) {
+    HjbCtl<T>& c = L.c;
+    double (&ls)[4] = L.ls, (&lm)[4] = L.lm, (&la)[4] = L.la;
+    int& all_active = L.all_active;
+    const bool worker = threadIdx.x < 256;
+    const int nth = 256;
     if (threadIdx.x == 0) all_active = 0;
     constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
     static_assert(sizeof(HjbCtl<T>) % 4 == 0, "controller block must be a whole number of words");
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
+    if (worker) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl_in);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&c);
-        for (int i = threadIdx.x; i < NW32; i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < NW32; i += nth) dst[i] = src[i];
     }
     // the attempt's error sums (issued together with the block's load; unused if the solve is over)
-    const double2* p2 = reinterpret_cast<const double2*>(parts);
     double s = 0.0, m = 0.0, na = 0.0;
-    const int nth = blockDim.x;
-    for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * nth) {
-        double2 v[4];
+    if (worker) {
+        for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * nth) {
+            double2 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (i0 + u * nth < nparts) ? p2[i0 + u * nth] : make_double2(0.0, 0.0);
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nth;
+                v[u] = (i < nparts) ? make_double2(ld_part<SC1>(parts + 2 * i), ld_part<SC1>(parts + 2 * i + 1))
+                                    : make_double2(0.0, 0.0);
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            s += v[u].x;
-            m = fmax(m, v[u].y);
-            na += v[u].x > 0.0 ? 1.0 : 0.0;
+            for (int u = 0; u < 4; ++u) {
+                s += v[u].x;
+                m = fmax(m, v[u].y);
+                na += v[u].x > 0.0 ? 1.0 : 0.0;
+            }
         }
-    }
-    s = wave_sum(s);
-    m = wave_max(m);
-    na = wave_sum(na);
-    if ((threadIdx.x & 63) == 0) {
-        ls[threadIdx.x >> 6] = s;
-        lm[threadIdx.x >> 6] = m;
-        la[threadIdx.x >> 6] = na;
+        s = wave_sum(s);
+        m = wave_max(m);
+        na = wave_sum(na);
+        if ((threadIdx.x & 63) == 0) {
+            ls[threadIdx.x >> 6] = s;
+            lm[threadIdx.x >> 6] = m;
+            la[threadIdx.x >> 6] = na;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -482,7 +511,7 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
     // coefficients (threads 0..42) and the accepted step's dense-output factors (threads 64..; rk.py:560-575:
     // x = (t_eval - t_old) / h, h x^1..4)
     if (!c.done && (int)threadIdx.x < 43) ctl_prepare_entry(c, (int)threadIdx.x);
-    if (c.accepted && threadIdx.x >= 64 && (int)threadIdx.x - 64 < c.n_hx) {
+    if (c.accepted && threadIdx.x >= 64 && worker && (int)threadIdx.x - 64 < c.n_hx) {
         const int q = (int)threadIdx.x - 64;
         const double x = (ctl_te(c, c.k_lo + q) - c.out_t) / c.out_hh;
         double xp = x;
@@ -493,9 +522,9 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
     }
     // interpolant ring: the slice table -- for every t_eval point of the accepted step its slot and the same four factors
     // (slice nt - 1 - k <-> t_eval[k], optimals.py:200-204; k = 0 is never looked up)
-    if (rslices != nullptr && c.accepted && threadIdx.x >= 64) {
+    if (rslices != nullptr && c.accepted && threadIdx.x >= 64 && worker) {
         const int slot = c.n_accept - 1;
-        for (int q = (int)threadIdx.x - 64; q < c.k_hi - c.k_lo; q += (int)blockDim.x - 64) {
+        for (int q = (int)threadIdx.x - 64; q < c.k_hi - c.k_lo; q += nth - 64) {
             const int k = c.k_lo + q;
             if (k < 1) continue;
             const double x = (ctl_te(c, k) - c.out_t) / c.out_hh;
@@ -514,11 +543,82 @@ __global__ void __launch_bounds__(256) k_control(HjbCtl<T>* __restrict__ ctl, co
     // blocks, off the critical path): here only the order for it
     if (threadIdx.x == 0) c.list_todo = (active_set != 0 && !c.done) ? ((all_active || c.dense_mode) ? 2 : 1) : 0;
     __syncthreads();
+    if (worker && store_out) {          // (the fused tail lets the list builder work on the LDS copy first)
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(ctl_out);
+        for (int i = threadIdx.x; i < NW32; i += nth) dst[i] = src[i];
+        // the solve is over: attempts enqueued past its end alternate between the two blocks -- both must say so
+        if (c.done && ctl_in != ctl_out) {
+            uint32_t* dst2 = reinterpret_cast<uint32_t*>(const_cast<HjbCtl<T>*>(ctl_in));
+            for (int i = threadIdx.x; i < NW32; i += nth) dst2[i] = src[i];
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_control(const HjbCtl<T>* __restrict__ ctl_in, HjbCtl<T>* __restrict__ ctl_out,
+                                                 const double* parts, int nparts, double* __restrict__ t_steps, int t_cap,
+                                                 int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox,
+                                                 int active_set = 0, OcRingSlot<T>* __restrict__ rslots = nullptr,
+                                                 OcRingSlice<T>* __restrict__ rslices = nullptr, int ring_cap = 0) {
+    __shared__ CtlLds<T> L;
+    control_body<T, false>(ctl_in, ctl_out, parts, nparts, t_steps, t_cap, att_log, log_cap, mailbox, active_set, rslots, rslices,
+                           ring_cap, L);
+}
+
+// SciPy's select_initial_step (common.py:68-134, order 4) without the host: the three RMS norms are reduced on the device
+// (k_norm_scaled + k_reduce_final into red[2], red[4], red[6]) and this kernel turns them into h0 (phase 0: red[8], d1 in
+// red[9]) and into the first step, finishing the controller block the host uploaded (phase 1: h_abs and the first attempt's
+// coefficient tables) -- three host round trips (0.3 ms of a 3 ms solve) gone.
+template <typename T>
+__global__ void __launch_bounds__(64) k_init_step(HjbCtl<T>* __restrict__ ctl, double* __restrict__ red, int phase,
+                                                  double n_rms, double interval) {
+    __shared__ HjbCtl<T> c;
+    if (phase == 0) {
+        if (threadIdx.x == 0) {
+            const double d0 = sqrt(red[2]) / sqrt(n_rms), d1 = sqrt(red[4]) / sqrt(n_rms);
+            double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+            h0 = fmin(h0, interval);
+            red[8] = h0;
+            red[9] = d1;
+        }
+        return;
+    }
+    constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&c);
+        for (int i = threadIdx.x; i < NW32; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double h0 = red[8], d1 = red[9];
+        const double d2 = sqrt(red[6]) / sqrt(n_rms) / h0;
+        double h1;
+        if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
+        else h1 = pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+        c.h_abs = fmin(fmin(100 * h0, h1), interval);
+        c.h_abs0 = c.h_abs;
+        ctl_prepare_step(c, true);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 43) ctl_prepare_entry(c, (int)threadIdx.x);
+    __syncthreads();
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
         uint32_t* dst = reinterpret_cast<uint32_t*>(ctl);
         for (int i = threadIdx.x; i < NW32; i += blockDim.x) dst[i] = src[i];
     }
+}
+
+// y1 = y0 + h0 * direction * f0 with h0 on the device (red[8]): the k_lincomb of select_initial_step
+template <typename T>
+__global__ void k_axpy_h0(const T* __restrict__ base, const T* __restrict__ k, const double* __restrict__ red,
+                          double direction, T* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T cc = (T)(red[8] * direction);
+    out[i] = base[i] + fma_t(cc, k[i], (T)0);
 }
 
 // dense output (scipy rk.py:560-575): phi = y_old + h * sum_p (sum_j K_j P_jp) x^(p+1)
@@ -755,6 +855,21 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     size_t ring_slot_elems;         // 5 * rows * Nx
     uint8_t* ring_flags;            // [cap][ntile]: 1 = the tile was trivial in the slot's attempt (nothing stored for it)
     int32_t ring_cap, ring_ntile;
+    // fused tail (FUSED kernels): the LAST block of the launch to finish is the attempt's step controller and list builder
+    // -- one launch per attempt instead of three.  Every participating block stores its words for the controller `sc1`,
+    // drains them and takes a ticket (agent-scope add); the block whose ticket is the last runs control_body and
+    // build_work_list on what the others wrote (sc1 loads) and leaves the NEXT attempt's controller block in ctl_out.
+    HjbCtl<T>* ctl_out;
+    int32_t* tail_counter;          // zero between launches (the tail resets it)
+    double* t_steps;
+    int32_t* att_log;
+    int32_t t_cap, log_cap;
+    volatile double* mailbox;
+    int32_t active_set;
+    OcRingSlot<T>* rslots;
+    OcRingSlice<T>* rslices;
+    int32_t* flags_next;            // the next attempt's flags / work list (the builder's outputs)
+    int32_t* work_next;
 };
 
 // value of the previous / next lane of the wavefront (DPP wave shifts: no LDS traffic; lane 0 / 63 get 0)
@@ -802,9 +917,11 @@ __device__ __forceinline__ bool is_pow2(double v) {
 //   NQ = 3: two launches per attempt (A: K1..K3 from y, K0; B: Q1..Q3, y_new, K6 + error), region 128 x 32 -> tile 120 x 26
 //   NQ = 6: one launch (writes Q1..Q3, K6, y_new: 3 arrays read, 5 written), region 128 x 32 -> tile 112 x 20
 // Same arithmetic per cell as k_stage (one stage per launch, the cross-check variant): bit-identical results.
-template <typename T, int NQ, int S0, bool FINAL, int RWV, int RH, bool RING = false>
+template <typename T, int NQ, int S0, bool FINAL, int RWV, int RH, bool RING = false, bool FUSED = false>
 __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Stage3Args<T> A) {      // float: 64 VGPRs, two blocks per CU
     static_assert(!RING || (NQ == 6 && FINAL), "the ring is written by the one-launch attempt");
+    static_assert(!FUSED || RING, "the fused tail belongs to the ring path");
+    __shared__ int s_last;
     constexpr int HX = 4 * ((NQ + 3) / 4), HY = NQ, RW = 4 * RWV, NT = RWV * RH;
     constexpr int TX = RW - 2 * HX, TY = RH - 2 * HY, LS = RW + 8;
     constexpr int NK = S0 + NQ;                     // stage derivatives alive at the end of the launch
@@ -833,6 +950,46 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);              // XCD-aware order (tile_of_block)
     if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
     const bool sparse = NQ == 6 && A.flags_cur != nullptr && ctl->dense_mode == 0;
+    // blocks that take part in the attempt (the others have returned above or do so just below): what the tail waits for
+    const int n_part = (sparse && A.work != nullptr) ? min(ctl->work_count, nb) : nb;
+    auto st_part = [&](double* p, double v) {           // a word for the controller (thread 0 only)
+        if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
+    auto st_flag = [&](int32_t* p, int32_t v) {
+        if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
+    auto fused_tail = [&]() {                           // called by every thread of a participating block, at its end
+        if (threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this block's sc1 words have left
+            const int ticket = __hip_atomic_fetch_add(A.tail_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (ticket == n_part - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (threadIdx.x == 0) __hip_atomic_store(A.tail_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the tile buffers are free now: the controller's LDS block, then the builder's flag bytes
+        CtlLds<T>& L = *reinterpret_cast<CtlLds<T>*>(&buf[0][0][0]);
+        static_assert(sizeof(CtlLds<T>) <= 4096 && sizeof(buf) >= 4096 + 12000, "the tail's scratch fits the tile buffers");
+        control_body<T, true>(ctl, A.ctl_out, A.partial, nb, A.t_steps, A.t_cap, A.att_log, A.log_cap, A.mailbox, A.active_set,
+                              A.rslots, A.rslices, A.ring_cap, L, false);
+        if (A.active_set)
+            build_work_list<T, true>(&L.c, A.flags_cur, A.flags_next, A.work_next, A.partial, nbx, nby,
+                                     reinterpret_cast<uint8_t*>(&buf[0][0][0]) + 4096, (int)sizeof(buf) - 4096, A.ring_flags,
+                                     A.ring_cap, A.mailbox);
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&L.c);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(A.ctl_out);
+            for (int i = threadIdx.x; i < NW32; i += 256) dst[i] = src[i];
+            if (L.c.done) {             // (both blocks: see control_body)
+                uint32_t* dst2 = reinterpret_cast<uint32_t*>(const_cast<HjbCtl<T>*>(ctl));
+                for (int i = threadIdx.x; i < NW32; i += 256) dst2[i] = src[i];
+            }
+        }
+    };
     if (sparse && A.work != nullptr) {              // active set: entry `logical` of the work list, or nothing to do
         if (logical >= ctl->work_count) return;
         logical = A.work[logical];
@@ -932,15 +1089,16 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             }
             if (threadIdx.x == 0) {
                 const int r_lo = bi * TY, r_hi = min(r_lo + TY, Ny);
-                A.partial[2 * logical] = 0.0;
-                A.partial[2 * logical + 1] = (r_hi > A.row_lo && r_lo < A.row_hi) ? (double)fabs(un) : 0.0;
-                A.flags_cur[logical] = 1;
+                st_part(A.partial + 2 * logical, 0.0);
+                st_part(A.partial + 2 * logical + 1, (r_hi > A.row_lo && r_lo < A.row_hi) ? (double)fabs(un) : 0.0);
+                st_flag(A.flags_cur + logical, 1);
                 if (ring_ok) A.ring_flags[(size_t)rslot * A.ring_ntile + logical] = 1;
             }
+            if (FUSED) fused_tail();
             return;
         }
         if (threadIdx.x == 0) {
-            A.flags_cur[logical] = 0;
+            st_flag(A.flags_cur + logical, 0);
             if (ring_ok) A.ring_flags[(size_t)rslot * A.ring_ntile + logical] = 0;
         }
     }
@@ -1007,9 +1165,12 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             // -- 20 consecutive values per thread -- and nothing reads them before a lookup or the slice writer does.
             constexpr int rows[6] = {0, 2, 3, 4, 5, 6};
             T* const rb = RING ? A.ring + (size_t)rslot * A.ring_slot_elems + (size_t)idx * OC_RING_VALS : nullptr;
+            // (plain stores: a thread's five 16-byte pieces are consecutive, a wavefront's 5 KB are contiguous -- the L2 merges them
+            // into whole lines; as nontemporal stores each instruction's 16-byte pieces at an 80-byte stride went out as
+            // partial writes: 147 us per launch at 2048 x 2048 with every tile computed)
             if (RING && ring_ok) {
-                st4_nt(rb, quad(yv[0], yv[1]));
-                st4_nt(rb + 4, quad(kv[0][0], kv[0][1]));
+                st4(rb, quad(yv[0], yv[1]));
+                st4(rb + 4, quad(kv[0][0], kv[0][1]));
             }
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp) {
@@ -1021,7 +1182,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                     q1 = __builtin_elementwise_fma(kv[rows[j]][1], p2, q1);
                 }
                 if (!RING) st4(A.KM[1 + pp] + idx, quad(q0, q1));
-                else if (ring_ok) st4_nt(rb + 8 + 4 * pp, quad(q0, q1));
+                else if (ring_ok) st4(rb + 8 + 4 * pp, quad(q0, q1));
             }
             st4(A.KX[par ^ 1] + idx, quad(kv[NK - 1][0], kv[NK - 1][1]));     // K6 = the next step's K0 (FSAL)
         } else {
@@ -1064,8 +1225,12 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                 a += ls[q];
                 b = fmax(b, lm[q]);
             }
-            A.partial[2 * logical] = a;
-            A.partial[2 * logical + 1] = b;
+            st_part(A.partial + 2 * logical, a);
+            st_part(A.partial + 2 * logical + 1, b);
+        }
+        if (FUSED) {
+            __syncthreads();            // (the tail reuses the tile buffers and the reduction's LDS words)
+            fused_tail();
         }
     }
 }
@@ -1168,28 +1333,37 @@ __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* 
 // was trivial in the attempt just run, with all 8 neighbours, is trivial in the next one whatever the decision was; if the
 // target buffers hold the trivial values already (the attempt was rejected, or no rescale lies between the buffers) it needs
 // no block at all: its flag and error share are set here.  sflag: the block's LDS (nbytes of it).
-template <typename T>
-__device__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __restrict__ flags_cur,
-                                int32_t* __restrict__ flags_next, int32_t* __restrict__ work, double* __restrict__ parts_rw,
-                                int tnbx, int tnby, uint8_t* sflag, int nbytes, uint8_t* __restrict__ ring_flags = nullptr,
-                                int ring_cap = 0) {
+template <typename T, bool SC1 = false>
+__device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __restrict__ flags_cur,
+                                                int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
+                                                double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* sflag, int nbytes,
+                                                uint8_t* __restrict__ ring_flags = nullptr, int ring_cap = 0,
+                                                volatile double* mailbox = nullptr) {
+    // Called by every thread of the block (barriers inside); threads 0 .. 255 do the work.  SC1: flags_cur was written by
+    // other blocks of this very launch (fused tail) -- sc1 loads, see ld_part.
     __shared__ int32_t wsum[4];
-    const int todo = ctl->list_todo, nth = (int)blockDim.x;
+    const int todo = ctl->list_todo, nth = 256;
+    const bool worker = threadIdx.x < 256;
+    const int ntile = tnbx * tnby;
     if (todo == 0) return;
     if (todo == 2) {                                // every tile is active and stays so: no flags, no list from now on
-        if (threadIdx.x == 0) ctl->dense_mode = 1;
+        if (threadIdx.x == 0) {
+            ctl->dense_mode = 1;
+            if (mailbox) mailbox[1] = (double)ntile;
+        }
         return;
     }
-    const int ntile = tnbx * tnby;
     // (interpolant ring: a tile left off the list is trivial in the next attempt -- flagged in that attempt's slot here,
     // since no block will look at it)
     uint8_t* const rf = (ring_flags != nullptr && ctl->n_accept < ring_cap) ? ring_flags + (size_t)ctl->n_accept * ntile : nullptr;
     const bool skip_ok = (ctl->rejected != 0 || (ctl->in_scale == (T)1 && ctl->out_in_scale == (T)1)) && ntile <= nbytes;
     // every thread owns a contiguous run of tiles (an ordered list keeps neighbouring tiles in neighbouring blocks)
-    const int per_thr = (ntile + nth - 1) / nth, t_lo = min((int)threadIdx.x * per_thr, ntile), t_hi = min(t_lo + per_thr, ntile);
+    const int per_thr = (ntile + nth - 1) / nth;
+    const int t_lo = worker ? min((int)threadIdx.x * per_thr, ntile) : ntile, t_hi = min(t_lo + per_thr, ntile);
     uint32_t listed = 0xFFFFFFFFu, listed_hi = 0xFFFFFFFFu;     // bit q: tile t_lo + q goes on the list (per_thr <= 64)
     if (skip_ok) {
-        for (int t = threadIdx.x; t < ntile; t += nth) sflag[t] = flags_cur[t] != 0 ? 1 : 0;
+        if (worker)
+            for (int t = threadIdx.x; t < ntile; t += nth) sflag[t] = ld_flag<SC1>(flags_cur + t) != 0 ? 1 : 0;
         __syncthreads();
         int bi = t_lo / tnbx, bj = t_lo % tnbx;
         for (int t = t_lo; t < t_hi; ++t) {
@@ -1226,10 +1400,10 @@ __device__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __re
         const int v = __shfl_up(incl, o, 64);
         if (lane >= o) incl += v;
     }
-    if (lane == 63) wsum[wv] = incl;
+    if (lane == 63 && worker) wsum[wv] = incl;
     __syncthreads();
     int off = incl - mine;
-    for (int q = 0; q < wv; ++q) off += wsum[q];
+    for (int q = 0; q < wv && q < 4; ++q) off += wsum[q];
     for (int t = t_lo; t < t_hi; ++t) {
         const int q = t - t_lo;
         const bool on = q < 32 ? ((listed >> q) & 1u) != 0 : ((listed_hi >> (q - 32)) & 1u) != 0;
@@ -1242,7 +1416,11 @@ __device__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __re
             if (rf) rf[t] = 1;
         }
     }
-    if (threadIdx.x == 0) ctl->work_count = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        const int wc = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        ctl->work_count = wc;
+        if (mailbox) mailbox[1] = (double)wc;        // (the host picks the launch sequence by it: fused tail or not)
+    }
 }
 
 // With the interpolant ring no k_out launch follows an attempt: the list builder is a launch of its own (one block).
@@ -1250,9 +1428,10 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_list(HjbCtl<T>* ctl, const int32_t* __restrict__ flags_cur,
                                               int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
                                               double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* ring_flags,
-                                              int ring_cap) {
+                                              int ring_cap, volatile double* mailbox) {
     __shared__ uint8_t sflag[16384];
-    build_work_list<T>(ctl, flags_cur, flags_next, work, parts_rw, tnbx, tnby, sflag, (int)sizeof(sflag), ring_flags, ring_cap);
+    build_work_list<T>(ctl, flags_cur, flags_next, work, parts_rw, tnbx, tnby, sflag, (int)sizeof(sflag), ring_flags, ring_cap,
+                       mailbox);
 }
 
 // ---- slices from the ring (oc_hjb_ring_slices; the audit output phi_keep of a ring solve) ---------------------------
@@ -1556,8 +1735,8 @@ int ring_emit(oc_handle* h, const RingView<T>& R, int n_slots, int s_lo, int s_h
               double* keep_base, const int32_t* keep_slot_dev, hipStream_t s) {
     const oc_config& c = h->cfg;
     const int Ny = R.rows, Nx = c.Nx;
-    if (!h->hjb_ctl) OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 4096));
-    HjbCtl<T>* ctl = (HjbCtl<T>*)((char*)h->hjb_ctl + 2048);       // (the second half: the first is a solve's controller)
+    if (!h->hjb_ctl) OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 8192));
+    HjbCtl<T>* ctl = (HjbCtl<T>*)((char*)h->hjb_ctl + 4096);       // (behind a solve's two alternating controller blocks)
     static_assert(sizeof(HjbCtl<T>) <= 2048, "controller block too large");
     OutArgs<T> OA;
     memset(&OA, 0, sizeof(OA));
@@ -1763,11 +1942,17 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     }
     // ---- device-side bookkeeping (allocated once per handle)
     const int T_CAP = 65536, LOG_CAP = 65536;
-    if (!h->hjb_ctl) OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 4096));
+    if (!h->hjb_ctl) OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 8192));
     if (!h->hjb_tsteps) OC_HIP_CHECK(hipMalloc((void**)&h->hjb_tsteps, sizeof(double) * T_CAP));
     if (!h->hjb_log) OC_HIP_CHECK(hipMalloc((void**)&h->hjb_log, sizeof(int32_t) * LOG_CAP));
-    static_assert(sizeof(HjbCtl<T>) <= 4096, "controller block too large");
-    HjbCtl<T>* ctl = (HjbCtl<T>*)h->hjb_ctl;
+    if (!h->hjb_tail) {
+        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_tail, 64));
+        OC_HIP_CHECK(hipMemset(h->hjb_tail, 0, 64));
+    }
+    static_assert(sizeof(HjbCtl<T>) <= 2048, "controller block too large");
+    // two controller blocks: attempt a reads ctlb[a & 1], its controller leaves the next attempt's in ctlb[(a + 1) & 1]
+    HjbCtl<T>* const ctlb[2] = {(HjbCtl<T>*)h->hjb_ctl, (HjbCtl<T>*)((char*)h->hjb_ctl + 2048)};
+    HjbCtl<T>* ctl = ctlb[0];
     int32_t* keep_slot_dev = nullptr;
     if (n_keep > 0) {
         std::vector<int32_t> slot(nt, -1);
@@ -1789,9 +1974,27 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     hipLaunchKernelGGL(k_fill<T>, S.g1(), dim3(256), 0, s, S.y, (T)1, n);
     const double t0 = Tfinal, tf = 0.0, direction = -1.0;
     S.rhs(S.y, KX[0]);                  // f0 = K0 of the first step
-    // ---- select_initial_step (scipy common.py:68-134), order = 4
-    double h_abs;
-    {
+    // ---- select_initial_step (scipy common.py:68-134), order = 4: on the device (k_init_step) for a whole-grid solve; a
+    // row-block solve completes each norm with the caller's all-gather, read back by the host
+    const bool dev_init = sh == nullptr;
+    double h_abs = 0.0;
+    if (dev_init) {
+        const double interval = std::fabs(tf - t0);
+        double* red = h->red_out;
+        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, S.y + own_off, (const T*)nullptr,
+                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, RB, red + 2, (volatile double*)nullptr, 0.0);
+        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, KX[0] + own_off, (const T*)nullptr,
+                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, RB, red + 4, (volatile double*)nullptr, 0.0);
+        hipLaunchKernelGGL(k_init_step<T>, dim3(1), dim3(64), 0, s, (HjbCtl<T>*)nullptr, red, 0, n_rms, interval);
+        hipLaunchKernelGGL(k_axpy_h0<T>, S.g1(), dim3(256), 0, s, S.y, KX[0], (const double*)red, direction, S.ytmp, n);
+        S.rhs(S.ytmp, S.K[1]);
+        hipLaunchKernelGGL((k_norm_scaled<T, 1>), dim3(RB), dim3(256), 0, s, S.K[1] + own_off, KX[0] + own_off,
+                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, RB, red + 6, (volatile double*)nullptr, 0.0);
+        // (phase 1 runs once the controller block has been uploaded, below)
+    } else {
         double interval = std::fabs(tf - t0);
         double s0, s1, s2;
         hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, S.y + own_off, (const T*)nullptr,
@@ -1833,11 +2036,18 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     hc.in_scale = hc.out_in_scale = (T)1;
     hc.u_bg = (T)1;
     hc.work_count = 1 << 30;            // (the first attempt looks at every tile)
-    ctl_prepare_attempt(hc, true);
-    OC_HIP_CHECK(hipMemcpyAsync(ctl, &hc, sizeof(hc), hipMemcpyHostToDevice, s));
-    OC_HIP_CHECK(hipStreamSynchronize(s));          // (hc lives on this stack frame)
-    volatile double* mb = h->red_host + 2 * OC_MAX_WORLD + 4;      // ticks + 2^32 * done (k_control)
+    hc.h_abs0 = h_abs;
+    if (!dev_init) ctl_prepare_attempt(hc, true);
+    // (through a pinned staging block: no synchronisation -- the block is rewritten by the next solve at the earliest)
+    if (!h->hjb_ctl_host) OC_HIP_CHECK(hipHostMalloc(&h->hjb_ctl_host, 4096, hipHostMallocDefault));
+    memcpy(h->hjb_ctl_host, &hc, sizeof(hc));
+    OC_HIP_CHECK(hipMemcpyAsync(ctl, h->hjb_ctl_host, sizeof(hc), hipMemcpyHostToDevice, s));
+    OC_HIP_CHECK(hipMemsetAsync(h->hjb_tail, 0, 64, s));           // (a solve that failed half-way may have left tickets)
+    if (dev_init)
+        hipLaunchKernelGGL(k_init_step<T>, dim3(1), dim3(64), 0, s, ctl, h->red_out, 1, n_rms, std::fabs(tf - t0));
+    volatile double* mb = h->red_host + 2 * OC_MAX_WORLD + 4;      // [0] ticks + 2^32 * done (k_control), [1] listed tiles
     mb[0] = 0.0;
+    mb[1] = 1e9;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     double* mb_dev = (double*)h->red_mailbox_dev + 4;
 
@@ -1921,14 +2131,31 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // longer cover the grid: every tile is computed.
     const bool active_set = !sh && fuse == 0 && nb3 <= 12000 &&
                             (h->hjb_active == 2 || (h->hjb_active == 1 && nb3 >= 1024));
-    if (active_set && h->hjb_flags_n < (size_t)3 * nb3) {     // flags of two attempts + the work list
+    if (active_set && h->hjb_flags_n < (size_t)4 * nb3) {     // flags of two attempts + two work lists (alternating)
         if (h->hjb_flags) OC_HIP_CHECK(hipFree(h->hjb_flags));
         h->hjb_flags = nullptr;
         h->hjb_flags_n = 0;
-        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_flags, sizeof(int32_t) * 3 * (size_t)nb3));
-        h->hjb_flags_n = (size_t)3 * nb3;
+        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_flags, sizeof(int32_t) * 4 * (size_t)nb3));
+        h->hjb_flags_n = (size_t)4 * nb3;
     }
-    int32_t* const work_list = active_set ? h->hjb_flags + 2 * (size_t)nb3 : nullptr;
+    // attempt a reads work list a & 1; the builder after it writes list (a + 1) & 1 (a late block of the attempt's own launch
+    // must never see the next attempt's list: the fused tail builds it while that launch is still draining)
+    auto work_list = [&](int a) -> int32_t* { return active_set ? h->hjb_flags + (2 + (size_t)(a & 1)) * nb3 : nullptr; };
+    // fused tail (ring solves on one GPU): the attempt's last block is its controller and list builder -- one launch per
+    // attempt instead of three.  Every participating block takes a ticket on ONE counter (~90 atomics per us on this chip),
+    // so it pays while few blocks take part: small grids, or the active set's short lists.  The host picks the sequence per
+    // attempt from what the device last posted (mb[1]: listed tiles); any choice is correct, only the speed differs.
+    const int FUSED_MAX = 640;
+    const bool can_fuse = ring != nullptr && !sh && h->hjb_tail_fuse != 0;
+    SA.tail_counter = h->hjb_tail;
+    SA.t_steps = h->hjb_tsteps;
+    SA.att_log = h->hjb_log;
+    SA.t_cap = T_CAP;
+    SA.log_cap = LOG_CAP;
+    SA.mailbox = (volatile double*)mb_dev;
+    SA.active_set = active_set ? 1 : 0;
+    SA.rslots = R.slots;
+    SA.rslices = R.slices;
 
     const size_t lo = (size_t)own_lo * S.Nx, hi = (size_t)own_hi * S.Nx, hn = sh ? (size_t)sh->halo * S.Nx : 0;
     const bool halos = sh && (sh->has_up || sh->has_dn);
@@ -1956,17 +2183,29 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         const bool prof = prof_on && (enq % PROF_EVERY == 0);
         if (prof) ev_attempt.push_back(enq);
         if (prof) event();
+        HjbCtl<T>* const ctl_cur = ctlb[enq & 1];
+        HjbCtl<T>* const ctl_nxt = ctlb[(enq + 1) & 1];
+        SA.ctl = ctl_cur;
+        SA.ctl_out = ctl_nxt;
+        OA.ctl = ctl_nxt;                               // (k_out / the list builder act on the controller's decision)
         if (active_set) {
             SA.flags_cur = h->hjb_flags + (size_t)(enq & 1) * nb3;
             SA.flags_prev = enq > 0 ? h->hjb_flags + (size_t)((enq - 1) & 1) * nb3 : nullptr;
-            SA.work = enq > 0 ? work_list : nullptr;       // (the first attempt looks at every tile: no list yet)
+            SA.work = enq > 0 ? work_list(enq) : nullptr;   // (the first attempt looks at every tile: no list yet)
+            SA.flags_next = h->hjb_flags + (size_t)((enq + 1) & 1) * nb3;
+            SA.work_next = work_list(enq + 1);
             OA.flags = SA.flags_cur;
-            OA.ctl_rw = ctl;
-            OA.flags_next = h->hjb_flags + (size_t)((enq + 1) & 1) * nb3;
-            OA.work = work_list;
+            OA.ctl_rw = ctl_nxt;
+            OA.flags_next = SA.flags_next;
+            OA.work = SA.work_next;
             OA.parts_rw = h->red_partial;
         }
-        if (ring) {
+        // blocks that will take part, as far as the host knows (the device is a few attempts ahead of what it posted)
+        const double seen = active_set ? (enq > 0 ? (double)mb[1] : (double)nb3) : (double)nb3;
+        const bool fused = can_fuse && seen <= (double)FUSED_MAX;
+        if (ring && fused) {
+            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32, true, true>), grid3, dim3(1024), 0, s, SA);
+        } else if (ring) {
             hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32, true>), grid3, dim3(1024), 0, s, SA);
         } else if (fuse == 0) {
             hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32>), grid3, dim3(1024), 0, s, SA);
@@ -1975,37 +2214,40 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             hipLaunchKernelGGL((k_stageV<T, 3, 4, true, 32, 32>), grid3, dim3(1024), 0, s, SA);
         }
         if (prof) event();
-        if (sh) {
+        if (fused) {
+            // (controller and list builder ran inside the stage launch)
+        } else if (sh) {
             hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, nb3, sh->red_local);
             if (sh->allgather_red(sh->user) != 0) {
                 oc_set_error("hjb_solve_rows: the allgather_red callback failed");
                 return OC_ERR_STATE;
             }
-            hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, ctl, (const double*)sh->red_all, sh->world,
-                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev, 0, R.slots, R.slices,
-                               R.cap);
+            hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, (const HjbCtl<T>*)ctl_cur, ctl_nxt,
+                               (const double*)sh->red_all, sh->world, h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP,
+                               (volatile double*)mb_dev, 0, R.slots, R.slices, R.cap);
         } else {
-            hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, ctl, (const double*)h->red_partial, nb3,
-                               h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP, (volatile double*)mb_dev, active_set ? 1 : 0,
-                               R.slots, R.slices, R.cap);
+            hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, (const HjbCtl<T>*)ctl_cur, ctl_nxt,
+                               (const double*)h->red_partial, nb3, h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP,
+                               (volatile double*)mb_dev, active_set ? 1 : 0, R.slots, R.slices, R.cap);
         }
         if (halos) {
             const dim3 gh((unsigned)((4 * hn + 255) / 256));
-            hipLaunchKernelGGL((k_halo_stage<T, true>), gh, dim3(256), 0, s, ctl, Y[0], Y[1], KX[0], KX[1],
+            hipLaunchKernelGGL((k_halo_stage<T, true>), gh, dim3(256), 0, s, (const HjbCtl<T>*)ctl_nxt, Y[0], Y[1], KX[0], KX[1],
                                (T*)sh->send_up, (T*)sh->send_dn, lo, hi, hn, sh->has_up, sh->has_dn);
             if (sh->exchange_halo(sh->user) != 0) {
                 oc_set_error("hjb_solve_rows: the exchange_halo callback failed");
                 return OC_ERR_STATE;
             }
-            hipLaunchKernelGGL((k_halo_stage<T, false>), gh, dim3(256), 0, s, ctl, Y[0], Y[1], KX[0], KX[1],
+            hipLaunchKernelGGL((k_halo_stage<T, false>), gh, dim3(256), 0, s, (const HjbCtl<T>*)ctl_nxt, Y[0], Y[1], KX[0], KX[1],
                                (T*)sh->recv_up, (T*)sh->recv_dn, lo, hi, hn, sh->has_up, sh->has_dn);
         }
         if (prof) event();
         if (!ring) {
             launch_out<T, TO, true>(h->out_tile, S.Nx, S.Ny, s, OA);
-        } else if (active_set) {        // no slice writer beside which the list could be built: its own (one-block) launch
-            hipLaunchKernelGGL(k_list<T>, dim3(1), dim3(256), 0, s, ctl, (const int32_t*)OA.flags, OA.flags_next, OA.work,
-                               OA.parts_rw, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty, R.flags, R.cap);
+        } else if (active_set && !fused) {  // no slice writer beside which the list could be built: its own (one-block) launch
+            hipLaunchKernelGGL(k_list<T>, dim3(1), dim3(256), 0, s, ctl_nxt, (const int32_t*)OA.flags, OA.flags_next, OA.work,
+                               OA.parts_rw, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty, R.flags, R.cap,
+                               (volatile double*)mb_dev);
         }
         if (prof) event();
         ++enq;
@@ -2042,12 +2284,12 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         done = mb[0] >= 4294967296.0;
         if (!done && hipStreamQuery(s) == hipSuccess && mb[0] < (double)enq) {
             // the stream drained but the mailbox did not move: mapped memory is not visible -> read the device copy
-            OC_HIP_CHECK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
+            OC_HIP_CHECK(hipMemcpy(&hc, ctlb[enq & 1], sizeof(hc), hipMemcpyDeviceToHost));
             done = hc.done != 0;
         }
     }
     OC_HIP_CHECK(hipStreamSynchronize(s));
-    OC_HIP_CHECK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
+    OC_HIP_CHECK(hipMemcpy(&hc, ctlb[enq & 1], sizeof(hc), hipMemcpyDeviceToHost));     // (what the last controller left)
     if (hc.status != 0) {
         if (hc.status == OC_ERR_SOLVER - 200) {
             oc_set_error("hjb_solve_ring: more than %d accepted steps (t = %g reached): the ring is too small", R.cap, hc.t);
@@ -2114,6 +2356,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         const int m = std::min(hc.n_tsteps, t_steps_cap - 1);
         if (m > 0) OC_HIP_CHECK(hipMemcpy(t_steps + 1, h->hjb_tsteps, sizeof(double) * m, hipMemcpyDeviceToHost));
     }
+    stats.h_abs0 = hc.h_abs0;
     stats.nfev = S.nfev + 6 * n_real;
     stats.n_attempt = n_real;
     stats.n_accept = hc.n_accept;
@@ -2315,7 +2558,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                 if (use_fused) {
                     // the fused writer of the default path (k_out), its controller block filled in by the host: the
                     // one-launch-per-stage variant stays bit-identical to the default one
-                    if (!h->hjb_ctl) OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 4096));
+                    if (!h->hjb_ctl) OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 8192));
                     if (!h->hjb_ctl_host) OC_HIP_CHECK(hipHostMalloc(&h->hjb_ctl_host, 4096, hipHostMallocDefault));
                     HjbCtl<T>& oc = *(HjbCtl<T>*)h->hjb_ctl_host;
                     memset(&oc, 0, sizeof(oc));
@@ -2583,13 +2826,13 @@ extern "C" int64_t oc_hjb_ring_meta_bytes(const oc_handle* h, int dtype, int32_t
 
 // Accepted steps a solve over [T, 0] will take: the controller drives the explicit pair to its stability limit on this
 // equation (h ~ 3.3 / (8 (sigma^2/2) / dx^2), measured 383 steps at dx = 0.05 and 93 at dx = 0.1 for T = 20),
-// so T / h_stab plus a third and a constant covers it; a ring that turns out too small is reported (OC_ERR_CAPACITY).
+// so T / h_stab plus a quarter and a constant covers it; a ring that turns out too small is reported (OC_ERR_CAPACITY).
 extern "C" int32_t oc_hjb_ring_slots_hint(const oc_handle* h, double T) {
     if (!h) return 0;
     const oc_config& c = h->cfg;
     const double h_stab = 3.3 / (4.0 * c.sigma * c.sigma / (c.dx * c.dy));
     const double n = std::fabs(T) / h_stab;
-    return (int32_t)std::min(1.35 * n + 40.0, 1e6);
+    return (int32_t)std::min(1.25 * n + 16.0, 1e6);
 }
 
 extern "C" int oc_hjb_solve_ring(oc_handle* h, int dtype, const void* coef, double T, int32_t nt, const oc_hjb_ring* ring,

@@ -85,6 +85,7 @@ extern "C" int oc_destroy(oc_handle* h) {
     (void)hipFree(h->hjb_tsteps);
     (void)hipFree(h->hjb_log);
     (void)hipFree(h->hjb_flags);
+    (void)hipFree(h->hjb_tail);
     for (hipEvent_t e : h->hjb_events) (void)hipEventDestroy(e);
     for (auto& w : h->wallmaps) {
         (void)hipFree(w.left);
@@ -93,6 +94,7 @@ extern "C" int oc_destroy(oc_handle* h) {
     }
     (void)hipFree(h->key_tables_dev);
     (void)hipFree(h->rect_tab_dev);
+    (void)hipFree(h->key_steps_dev);
     (void)hipFree(h->gcfm_buf);
     (void)hipFree(h->sort_tmp);
     (void)hipFree(h->dens_buf);
@@ -282,6 +284,9 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     } else if (!strcmp(name, "hjb_active")) {
         OC_REQUIRE(value >= 0 && value <= 2, "hjb_active out of range");
         h->hjb_active = value;
+    } else if (!strcmp(name, "hjb_tail")) {
+        OC_REQUIRE(value >= 0 && value <= 1, "hjb_tail out of range");
+        h->hjb_tail_fuse = value;
     } else if (!strcmp(name, "hjb_fuse")) {
         OC_REQUIRE(value >= 0 && value <= 1, "hjb_fuse out of range");
         h->hjb_fuse = value;

@@ -138,6 +138,8 @@ struct oc_handle {
     double* hjb_tsteps = nullptr;
     int32_t* hjb_log = nullptr;
     std::vector<hipEvent_t> hjb_events;
+    int32_t* hjb_tail = nullptr;     // ticket counter of the fused tail (hjb.hip: k_stageV<.., FUSED>)
+    int hjb_tail_fuse = 1;           // 1: ring solves run controller + list builder inside the stage launch when few blocks take part
     int32_t* hjb_flags = nullptr;    // active-set flags of the stage tiles, two attempts (hjb.hip: k_stageV)
     size_t hjb_flags_n = 0;
     // ---- per-key data
@@ -146,6 +148,9 @@ struct oc_handle {
     std::vector<oc_key_rects> rects;
     void* key_tables_dev = nullptr;  // device copy of per-key descriptors for the step kernels
     void* rect_tab_dev = nullptr;    // compact exit-rectangle table (gcfm.hip: RECT_TAB doubles per key)
+    void* key_steps_dev = nullptr;   // per key: what a ring lookup needs of the current step (gcfm.hip: KeyStep)
+    int64_t ring_step_ready = -1;    // the simulation step key_steps_dev is resolved for (-1: none)
+    bool any_ring = false;           // some key's field is an interpolant ring
     bool key_tables_dirty = true;
     // ---- GCFM scratch
     int32_t resort_every = 32;  // steps between re-sorts (16: 7 500 steps/s at C4, 32: 7 680, 48: 7 710; wider lists beyond)

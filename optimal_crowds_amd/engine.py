@@ -330,6 +330,23 @@ class Engine:
             raise ValueError("key %d is held by another rank group" % key)
         return vx[:, 1:-1, 1:-1], vy[:, 1:-1, 1:-1]
 
+    def field_slice(self, key, s):
+        """(vx_opt[s], vy_opt[s]) of the reference (optimals.py:80-81) as (Ny-2, Nx-2) device tensors, whatever the field
+        mode: a view of the stored slice, or -- ring -- that one slice written by oc_hjb_ring_slices (zeros at and beyond
+        the horizon nt_opt - 1).  For the 4096 x 4096 room, where all slices at once would be 125 GB."""
+        f = self.fields[key]
+        if not f.held:
+            raise ValueError("key %d is held by another rank group" % key)
+        if not 0 <= s < f.nslice:
+            raise IndexError("slice %d of %d" % (s, f.nslice))
+        if f.is_ring and f.vx is None:
+            vx, vy = self.ring_slices(key, s, s + 1)
+            if vx.shape[0] == 0:
+                vx = torch.zeros((1, f.rows, self.Nx), dtype=self.field_tdtype, device=self.device)
+                vy = torch.zeros_like(vx)
+            return vx[0, 1:-1, 1:-1], vy[0, 1:-1, 1:-1]
+        return f.vx[s, 1:-1, 1:-1], f.vy[s, 1:-1, 1:-1]
+
     def make_coef(self, key, m=None, out=None):
         out = self.coef if out is None else out
         if m is not None:

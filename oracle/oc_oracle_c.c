@@ -300,6 +300,24 @@ static double sumsq_scaled(const double* a, const double* b, const double* y, do
     return s;
 }
 
+/* SciPy's quartic dense output at one t_eval point (rk.py:178-180, 560-575): out = y_old + h * (K^T P) [x, x^2, x^3, x^4],
+ * x = (t_eval - t_old) / h.  K: the step's seven stage derivatives (n values each).  Exported so that the CPU baseline can
+ * time it on its own (bench.py), not as the difference of two solves. */
+void occ_dense_output(const double* y, const double* const* K, double hh, double x, size_t n, double* out) {
+    double w[7];
+    for (int j = 0; j < 7; ++j) {
+        double xp = x, acc = 0.0;
+        for (int p = 0; p < 4; ++p) { acc += RKP[j][p] * xp; xp *= x; }
+        w[j] = acc;
+    }
+#pragma omp parallel for schedule(static)
+    for (size_t q = 0; q < n; ++q) {
+        double acc = 0.0;
+        for (int j = 0; j < 7; ++j) acc += K[j][q] * w[j];
+        out[q] = hh * acc + y[q];
+    }
+}
+
 int occ_rk45_solve(const occ_params* P, const double* V, const double* m, double T, int nt, double rtol, double atol,
                    const int32_t* keep_idx, int n_keep, double* phi_keep, const double* forced, int n_forced,
                    double* err_out, double* t_steps, int t_cap, int64_t* stats_out) {
@@ -408,20 +426,7 @@ int occ_rk45_solve(const occ_params* P, const double* V, const double* m, double
             if (!(tek >= t_new)) break;
             const int k = k_next++;
             if (slot[k] < 0) continue;
-            const double x = (tek - t) / hh;
-            double w[7];
-            for (int j = 0; j < 7; ++j) {
-                double xp = x, acc = 0.0;
-                for (int p = 0; p < 4; ++p) { acc += RKP[j][p] * xp; xp *= x; }
-                w[j] = acc;
-            }
-            double* out = phi_keep + (size_t)slot[k] * n;
-#pragma omp parallel for schedule(static)
-            for (size_t q = 0; q < n; ++q) {
-                double acc = 0.0;
-                for (int j = 0; j < 7; ++j) acc += K[j][q] * w[j];
-                out[q] = hh * acc + y[q];
-            }
+            occ_dense_output(y, (const double* const*)K, hh, (tek - t) / hh, n, phi_keep + (size_t)slot[k] * n);
         }
         sw = y; y = ynew; ynew = sw;
         t = t_new;

@@ -130,6 +130,20 @@ def step_sync(P, x, y, vx, vy, vdes, status, key, fields, X0, Y0, wallmaps, rect
     return nx, ny, nvx, nvy, nst
 
 
+def dense_output(y, Ks, hh, x):
+    """SciPy's dense output at one t_eval point (occ_dense_output: rk.py:178-180, 560-575) from a step's y_old and its
+    seven stage derivatives Ks; x = (t_eval - t_old) / h."""
+    y = f64(y)
+    Ks = [f64(k) for k in Ks]
+    assert len(Ks) == 7
+    out = np.empty_like(y)
+    arr = (C.c_void_p * 7)(*[k.ctypes.data for k in Ks])
+    lib = load()
+    lib.occ_dense_output.restype = None
+    lib.occ_dense_output(_p(y), arr, C.c_double(hh), C.c_double(x), C.c_size_t(y.size), _p(out))
+    return out
+
+
 def rk45_solve(P, V, m, T, nt, keep=(), forced=None, rtol=1e-3, atol=1e-6):
     """The whole HJB solve of optimals.py:193-196 in C (occ_rk45_solve).  Returns (phi_keep (len(keep), Ny*Nx), stats);
     forced: step end times to take instead of the controller's (stats['err'] = the error norm of each forced step)."""

@@ -26,9 +26,17 @@ def test_bench_line_has_the_contract_fields():
     assert d["unit"] == "steps/s" and d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-6 * 1e3
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
+    # `roofline` = the kernel class with the largest share of the timed region's GPU time: an HBM-bound HJB kernel, or the
+    # step's force kernel (bound by vector-instruction issue: SURVEY 8d's fp32-vector fraction, HBM fraction beside it --
+    # then `roofline_hbm` carries the HBM-bound kernel that matters most)
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    assert d["dominant_kernel_class"] in ("hjb_stage", "hjb_out", "hjb_list", "gcfm_forces", "gcfm_finish", "density")
+    assert r["bound"] in ("hbm", "valu") and "traffic" in r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    rh = r if r["bound"] == "hbm" else d["roofline_hbm"]
+    assert rh["bound"] == "hbm" and rh["unit"] == "GB/s" and rh["peak"] == 8000.0
+    assert abs(rh["frac"] - rh["achieved"] / rh["peak"]) < 1e-12 and 0 < rh["frac"] < 1
+    assert d["config"]["hjb_field"].startswith("ring")
     assert "roofline_valu" not in d      # priced from the committed PMC passes of the default workload only
     assert "room_test" in d["metric"] and d["config"]["mode"] == "single"
     c = d["cpu_baseline"]

@@ -26,8 +26,8 @@ os.makedirs(P, exist_ok=True)
 
 def short(name):
     for k in ("k_out", "k_forces", "k_finish", "k_pack", "k_tile_lists", "k_cell_keys", "k_edt", "k_wallmap", "k_reduce_final",
-              "k_rhs", "k_lincomb", "k_scale", "k_fill", "k_make_coef", "k_norm_scaled", "k_density", "k_control",
-              "k_halo_stage", "k_seq_pairs"):
+              "k_rhs", "k_lincomb", "k_scale", "k_fill", "k_make_coef", "k_norm_scaled", "k_density", "k_control", "k_list",
+              "k_ring_fill", "k_ring_ctl", "k_halo_stage", "k_seq_pairs", "k_seq_step"):
         if k + "<" in name or k + "(" in name:
             return k
     if "k_stageV<" in name:
@@ -73,25 +73,28 @@ for d, cname in ((tag + sfx + "_pmc_fetch", "FETCH_SIZE"), (tag + sfx + "_pmc_wr
 if traffic:
     # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a
     # wide (16 B/lane) coalesced read -> doubled; WRITE_SIZE is exact for 16 B/lane streaming stores.
-    ko_f = traffic.get("FETCH_SIZE", {}).get("k_out")
-    ko_w = traffic.get("WRITE_SIZE", {}).get("k_out")
-    if ko_f and ko_w:
-        traffic["k_out_hbm_bytes_per_launch"] = 2 * ko_f["avg_KB_per_launch"] * 1024 + ko_w["avg_KB_per_launch"] * 1024
-        traffic["note"] = ("k_out: 2 x FETCH_SIZE (gfx950 correction for 16 B/lane reads) + WRITE_SIZE, KB -> bytes, "
-                           "average over the launches of a --steps 20 run (separate --pmc passes)")
+    for kname, key in (("k_out", "k_out"), ("k_stageV(all six)", "k_stageV"), ("k_forces", "k_forces"), ("k_density", "k_density")):
+        kf_ = traffic.get("FETCH_SIZE", {}).get(kname)
+        kw_ = traffic.get("WRITE_SIZE", {}).get(kname)
+        if kf_ and kw_:
+            traffic[key + "_hbm_bytes_per_launch"] = 2 * kf_["avg_KB_per_launch"] * 1024 + kw_["avg_KB_per_launch"] * 1024
+    traffic["note"] = ("<kernel>_hbm_bytes_per_launch = 2 x FETCH_SIZE (gfx950 correction for 16 B/lane reads) + WRITE_SIZE, "
+                       "KB -> bytes, average over the launches of a --steps 20 run (separate --pmc passes); k_forces reads "
+                       "mostly 4-16 B per lane through scattered gathers, so for it the doubled figure is an upper bound")
     traffic["csrc_sha"] = bench.csrc_hash()         # bench.py quotes the file only for the kernels it was taken with
     traffic["workload"] = workload
     json.dump(traffic, open(os.path.join(P, tag + "_pmc_traffic" + ("" if workload == "metro_station" else "_" + workload)
                                          + ".json"), "w"), indent=1)
 # SQ counters of the step kernels (tools/pmc_step.sh): mean per launch -> JSON with the same stamp
-hjb_txt = os.path.join(G, tag + "_pmc_hjb.txt")
+# (one file per workload, like the traffic passes: the stamp is the workload the counters were TAKEN on)
+hjb_txt = os.path.join(G, tag + sfx + "_pmc_hjb.txt")
 if os.path.exists(hjb_txt):
-    shutil.copy(hjb_txt, os.path.join(P, tag + "_pmc_hjb_kernels.txt"))
-step_txt = os.path.join(G, tag + "_pmc_step.txt")
+    shutil.copy(hjb_txt, os.path.join(P, tag + sfx + "_pmc_hjb_kernels.txt"))
+step_txt = os.path.join(G, tag + sfx + "_pmc_step.txt")
 if os.path.exists(step_txt):
     import re
     txt = open(step_txt).read()
-    shutil.copy(step_txt, os.path.join(P, tag + "_pmc_step_kernels.txt"))
+    shutil.copy(step_txt, os.path.join(P, tag + sfx + "_pmc_step_kernels.txt"))
     step = {"csrc_sha": bench.csrc_hash(), "workload": workload}
     for kn in ("k_forces", "k_finish"):
         if kn in txt:
@@ -99,7 +102,7 @@ if os.path.exists(step_txt):
             nxt = [blk.index(o) for o in ("k_forces", "k_finish") if o != kn and o in blk[1:]]
             blk = blk[:min(nxt)] if nxt else blk
             step[kn] = {m.group(1): float(m.group(2)) for m in re.finditer(r"(\w+)\s+n=\d+\s+mean=([0-9.e+]+)", blk)}
-    json.dump(step, open(os.path.join(P, tag + "_pmc_step.json"), "w"), indent=1)
+    json.dump(step, open(os.path.join(P, tag + sfx + "_pmc_step.json"), "w"), indent=1)
 print("profiles:", sorted(os.listdir(P)))
 
 # bench lines of all BASELINE workloads (tools/run_workloads.sh): one compact JSON

@@ -20,7 +20,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        kn = next((k for k in ('k_forces', 'k_finish', 'k_stageV', 'k_stage3', 'k_stage6', 'k_out', 'k_control', 'k_density') if k in n), None)
+        kn = next((k for k in ('k_forces', 'k_finish', 'k_stageV', 'k_stage3', 'k_stage6', 'k_out', 'k_control', 'k_list', 'k_density') if k in n), None)
         if kn in ('k_stageV', 'k_stage3'):
             kn += ' B' if 'true' in n else ' A'
         if kn == 'k_stageV A' and 'Li6E' in n or (kn and 'k_stageV' in kn and ', 6,' in n): kn = 'k_stageV all6' 
