@@ -305,6 +305,26 @@ def measure(sim, args, nt, world, dist, red_dev, keep_state=False):
     return parallel.max_over_ranks(elapsed, device=red_dev), stats, state0
 
 
+def launch_ranks(n):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port <free> bench.py
+    <the same arguments>` as a child process; its stdout (rank 0's JSON line) is relayed.  Returns its exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (dmabuf IPC: RCCL across processes needs it on this host driver)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in p.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return p.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,12 +353,17 @@ def main():
                     help="HJB state: float32 (BASELINE's configs, default), mixed (float64 state, float32 field), float64")
     args = ap.parse_args()
 
-    import torch
-    from optimal_crowds_amd import parallel
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+            raise SystemExit("--gpus %d under a launcher of %d ranks" % (args.gpus, world))
+        # `python bench.py --gpus N` without a launcher: start the ranks ourselves -- a CHILD process (this one has not
+        # touched the GPU: nothing is re-executed from a process that has) running torch.distributed.run with one rank per
+        # GPU, whose single JSON line and exit code are passed on
+        sys.exit(launch_ranks(args.gpus))
+    import torch
+    from optimal_crowds_amd import parallel
     # OC_BENCH_ONE_DEVICE=1 (rehearsal on a 1-GPU box): every rank uses cuda:0 and the collectives run over gloo
     one_dev = os.environ.get("OC_BENCH_ONE_DEVICE") == "1"
     torch.cuda.set_device(0 if one_dev else local_rank)
@@ -513,9 +538,14 @@ def main():
         result["rccl"] = {
             "backend": backend, "ranks": world, "mode": "sharded" if sharded else "ensemble",
             "hjb_key_plan": [list(p) for p in getattr(eng, "key_plan", [])] if sharded else None,
+            "step_allgathers": sc.n_allgather if (sharded and sc) else 0,
+            "step_allgather_bytes": sc.bytes_allgather if (sharded and sc) else 0,
             "step_allreduces": sc.n_allreduce if (sharded and sc) else 0,
-            "step_allreduce_bytes": (eng._xchg.numel() * 8 if sharded and getattr(eng, "_xchg", None) is not None else 0),
-            "collectives_per_step": 1 if sharded else 0,
+            "step_allreduce_bytes": sc.bytes_allreduce if (sharded and sc) else 0,
+            "step_exchange": ("one all-gather of the ranks' tile shares (pair sums + wall forces, 32 B per agent slot); the "
+                              "desired velocities by a sum of their own (16 B per slot) where the floor fields are sharded, "
+                              "inside the all-gather (48 B per slot) where every rank holds them") if sharded else None,
+            "collectives_per_step": ((1 + (1 if sc and sc.n_allreduce else 0)) if sharded else 0),
             "hjb_allgathers_this_rank": sum(c.n_allgather for c in rowc),
             "hjb_halo_exchanges_this_rank": sum(c.n_exchange for c in rowc),
             "hjb_halo_message_bytes": (rowc[0].halo_bytes if rowc and hasattr(rowc[0], "halo_bytes") else 0),

@@ -242,21 +242,32 @@ int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step, const doub
 int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t simu_step, const int32_t* perm, const double* noise,
                             uint64_t seed, int32_t* counters, int32_t* rounds_out, void* stream);
 /* The step on `world` GPUs with REPLICATED agents: every rank holds the whole agent state and calls this
- * with the same arguments.  Rank r computes the pair forces and the wall forces of its contiguous share of the tiles
- * (against all agents) and the desired velocities of the agents whose floor-field rows it holds (oc_set_field_rows;
- * with oc_set_field every rank holds everything and rank 0 answers), writes them -- zeros elsewhere -- into `xchg`
- * (float64, oc_xchg_doubles(N) = 6 * oc_padded_agents(N) + OC_MAX_WORLD values, caller-owned: three double2 per slot,
- * then one IndexError-band word per rank), calls `allreduce_sum(user, xchg, count)`, which must SUM
- * the buffer over the ranks in place on `stream` (RCCL all-reduce; every element has one non-zero contribution, so the
- * result does not depend on the reduction order), and then every rank finishes ALL agents from the reduced buffer:
- * the replicated states stay bit-identical without another exchange, and counters[1] (IndexError band) is the same on
- * every rank.  A key whose field this rank does not hold (no oc_set_field / oc_set_field_rows for it: keys dealt to
- * different ranks, SURVEY 8e "partition by key first") is answered by the rank(s) that do. */
+ * with the same arguments.  Rank r computes the pair forces and the wall forces of ITS SHARE of the tiles (tile = 64 agents
+ * of the spatial order; share = ceil(tiles / world) consecutive tiles) against all agents, and the desired velocities of
+ * the agents whose floor field it can answer.  The results travel through the caller's exchange buffer `xchg`
+ * (oc_xchg_doubles(N, world) float64 values):
+ *   - `world` blocks, one per rank, of the share's tiles: per tile [pair sum x 64][wall force x 64]([desired velocity
+ *     x 64]) double2, then 8 doubles whose first is the rank's IndexError-band word.  `allgather(user, xchg, n)` must
+ *     gather them IN PLACE on `stream`: block r (n doubles at xchg + r * n) is rank r's -- one RCCL all-gather, 32 or 48
+ *     bytes per agent in total (the zero-padded sum-all-reduce of round 2 moved 48 B per agent TWICE over the wire);
+ *   - when the floor fields are sharded -- row blocks (oc_set_field_rows / oc_set_field_ring with a row block) or keys
+ *     dealt to different ranks (no field registered here for some key) -- a desired velocity is answered by the rank that
+ *     holds the field rows, not by the tile's owner: those 16 bytes per agent go through `allreduce_sum(user, buf, count)`
+ *     (in place SUM on `stream`; one non-zero contribution per element, so the order of the sum does not matter).  With
+ *     every field whole on every rank the tile's owner answers, they ride in its block and allreduce_sum is not called.
+ * Then every rank finishes ALL agents from the gathered buffer: the replicated states stay bit-identical without another
+ * exchange, and counters[1] (IndexError band) is the same on every rank. */
+typedef struct oc_step_comm {
+    int32_t rank, world;
+    double* xchg;
+    int (*allgather)(void* user, double* buf, int64_t doubles_per_rank);
+    int (*allreduce_sum)(void* user, double* buf, int64_t count);
+    void* user;
+} oc_step_comm;
 int64_t oc_padded_agents(int32_t N);
-int64_t oc_xchg_doubles(int32_t N);
+int64_t oc_xchg_doubles(int32_t N, int32_t world);
 int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise, uint64_t seed,
-                         int32_t* counters, int32_t rank, int32_t world, double* xchg,
-                         int (*allreduce_sum)(void* user, double* buf, int64_t count), void* user, void* stream);
+                         int32_t* counters, const oc_step_comm* comm, void* stream);
 /* For a driver that does not read `counters` after every step (run() enqueues steps and looks every 16th):
  * out4 (host) = { active agents now, 1 + the step in which the last active agent left (0: somebody is inside),
  * 1 + index of an agent that was in the IndexError band (0: none), the first step in which it was }.  Synchronises;

@@ -46,6 +46,13 @@ class OcHjbStats(C.Structure):
 
 HALO_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)     # int (*)(void* user)
 ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)     # int (*)(void* user, double* buf, int64 n)
+ALLGATHER_CB = ALLREDUCE_CB                                                 # (same shape: n = doubles per rank block)
+
+
+class OcStepComm(C.Structure):
+    """oc_hip.h: oc_step_comm -- the sharded step's exchange buffer and its two collectives"""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("xchg", C.c_void_p),
+                ("allgather", ALLGATHER_CB), ("allreduce_sum", ALLREDUCE_CB), ("user", C.c_void_p)]
 
 
 class OcHjbShard(C.Structure):
@@ -118,9 +125,9 @@ SIGNATURES = {
     "oc_gcfm_step_sequential": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64,
                                           C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "oc_padded_agents": (C.c_int64, [C.c_int32]),
-    "oc_xchg_doubles": (C.c_int64, [C.c_int32]),
+    "oc_xchg_doubles": (C.c_int64, [C.c_int32, C.c_int32]),
     "oc_gcfm_step_sharded": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p,
-                                       C.c_int32, C.c_int32, C.c_void_p, ALLREDUCE_CB, C.c_void_p, C.c_void_p]),
+                                       C.POINTER(OcStepComm), C.c_void_p]),
     "oc_run_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "oc_set_resort_every": (C.c_int, [C.c_void_p, C.c_int32]),
     "oc_agents_changed": (C.c_int, [C.c_void_p]),

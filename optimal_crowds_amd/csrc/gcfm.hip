@@ -56,6 +56,7 @@ struct KeyStep {
     double h[4], lim_s, u;
 };
 
+
 struct GcfmParams {
     int32_t Ny, Nx;
     double dx, dy, L, H, dt;
@@ -118,7 +119,12 @@ struct Scratch {
     int32_t* nb_list;       // [ntiles][NB_MAX + 1]: count (or -1 = overflow) then tile ids
     int32_t* tile_work;     // candidate-list entries each tile processed in the last step (its pair work)
     int32_t* tile_order;    // tiles by decreasing work: k_forces dispatches the heavy ones first
-    double2 *f_pair, *f_wall, *des;     // single-shot diagnostic exports only
+    // per-slot results of k_forces for k_finish: element of slot k at base[(k >> 6) * ts + (k & 63)] (xs()): plain arrays
+    // (ts = 64), or -- sharded step -- the caller's exchange buffer, blocked by tile so that a rank's share of the tiles is
+    // ONE contiguous block for the all-gather: [pair sums x 64][wall forces x 64]([desired velocities x 64]) per tile
+    double2 *f_pair, *f_wall, *des;
+    int32_t ts_pair, ts_wall, ts_des;   // double2 per tile (64: plain arrays)
+    int32_t x_tpr, x_blk;               // exchange buffer: tiles per rank block (0: no blocks), double2 per block
     long long* widx;
     int32_t* ctrl;
     int32_t* seq_rank;      // sequential mode: position of the slot's agent in the step's permutation
@@ -126,6 +132,18 @@ struct Scratch {
     int32_t* seq_ctl;       // [0..3]: agents still pending after round r (slot r & 3); [4]: displacement-bound violations
     int32_t Np, ntiles;
 };
+
+// element of slot k of one of the per-slot result arrays (Scratch::f_pair ...); ts = that array's tile stride.  In the
+// sharded step's exchange buffer the tiles of rank r form block r (x_tpr tiles + the block's 8-double tail).
+__device__ __forceinline__ double2& xs(const Scratch& S, double2* base, int ts, int k) {
+    const int t = k >> 6;
+    if (S.x_tpr != 0 && ts != 64) {
+        const int r = t / S.x_tpr;
+        return base[(size_t)r * S.x_blk + (size_t)(t - r * S.x_tpr) * ts + (k & 63)];
+    }
+    return base[(size_t)t * ts + (k & 63)];
+}
+
 
 // A grid axis.  The reference builds both with np.linspace(0, len, n) (simulations.py:69-70), whose elements are
 // fl(j * step), step = len / (n - 1), the last one set to len; when the caller's arrays are exactly that (checked in
@@ -1000,7 +1018,7 @@ __global__ void __launch_bounds__(256) k_pair(GcfmParams P, Scratch S) {
     __syncthreads();
     if (live) pair_share<1>(P, S, C, L, it, w, 0, w, lane);
     __syncthreads();
-    if (live) S.f_pair[it * 64 + lane] = make_double2(L.accx[w][lane], L.accy[w][lane]);
+    if (live) xs(S, S.f_pair, S.ts_pair, it * 64 + lane) = make_double2(L.accx[w][lane], L.accy[w][lane]);
 }
 
 // ---------------------------------------------------------------------------------- lookup
@@ -1107,6 +1125,20 @@ __device__ __forceinline__ T ring_phi(const RingCtx<T>& c, int r, int cc) {
     return (ph > c.lim_s) ? ph : ((ph < c.lim_s) ? c.lim_s : (T)0);
 }
 
+// clip (optimals.py:172) and the direction from five clipped values (optimals.py:174-186), as in k_out
+template <typename T>
+__device__ __forceinline__ T ring_clip(const RingCtx<T>& c, T ph) {
+    return (ph > c.lim_s) ? ph : ((ph < c.lim_s) ? c.lim_s : (T)0);
+}
+template <typename T, typename TO>
+__device__ __forceinline__ double2 ring_vels(const RingCtx<T>& c, T pw, T pe, T ps, T pn, T p0) {
+    const T pc = ring_clip(c, p0);                  // the reference clips the centre twice (:177)
+    const T gx = (pe - pw) * c.inv2dx, gy = (pn - ps) * c.inv2dy;
+    T ox, oy;
+    direction_of<T>(gx, gy, c.mu * pc, c.lim, ox, oy);
+    return make_double2((double)(TO)ox, (double)(TO)oy);
+}
+
 // the direction field's value at padded grid cell (global row gr, column gc), as float64 of what a slice of type TO holds
 template <typename T, typename TO>
 __device__ __forceinline__ double2 ring_dir(const RingCtx<T>& c, int Ny, int gr, int gc) {
@@ -1115,11 +1147,7 @@ __device__ __forceinline__ double2 ring_dir(const RingCtx<T>& c, int Ny, int gr,
     const T pw = ring_phi(c, r, gc - 1), pe = ring_phi(c, r, gc + 1);
     const T ps = ring_phi(c, r - 1, gc), pn = ring_phi(c, r + 1, gc);
     const T p0 = ring_phi(c, r, gc);
-    const T pc = (p0 > c.lim_s) ? p0 : ((p0 < c.lim_s) ? c.lim_s : (T)0);     // the reference clips the centre twice (:177)
-    const T gx = (pe - pw) * c.inv2dx, gy = (pn - ps) * c.inv2dy;
-    T ox, oy;
-    direction_of<T>(gx, gy, c.mu * pc, c.lim, ox, oy);
-    return make_double2((double)(TO)ox, (double)(TO)oy);
+    return ring_vels<T, TO>(c, pw, pe, ps, pn, p0);
 }
 
 template <typename T, typename TO>
@@ -1127,6 +1155,28 @@ __device__ __forceinline__ double2 ring_fetch(const GcfmParams& P, const KeyDev&
                                               int j1) {
     // interior index i of the reference's (Ny-2, Nx-2) array is grid row i + 1 (field_fetch)
     const RingCtx<T> c = ring_open<T>(P, kd, ks);
+    const int r0 = i0 + 1 - c.row0, r1 = i1 + 1 - c.row0, c0 = j0 + 1, c1 = j1 + 1;      // local rows, columns
+    const bool inner = r0 >= 1 && r1 + 1 < c.rows && c0 >= 1 && c1 + 1 < c.Nx && r0 <= r1 && c0 <= c1;
+    // Far field first: the cells a lookup reads lie in the box rows r0-1 .. r1+1, columns c0-1 .. c1+1 -- smaller than a stage
+    // tile, so at most the four tiles of its corners.  If all of them were trivial in the slice's step, phi is one constant
+    // on the whole box: every difference is zero and so is the direction (what k_out writes there) -- four flag bytes
+    // instead of fifty values.  At 2048 x 2048 that is ~90 % of the cells at any time of an m = 0 solve.
+    if (inner && c.flags != nullptr) {
+        const int ta = ((r0 - 1) / OC_RING_STY) * c.tnbx, tb = ((r1 + 1) / OC_RING_STY) * c.tnbx;
+        const int ua = (c0 - 1) / OC_RING_STX, ub = (c1 + 1) / OC_RING_STX;
+        const uint8_t f0 = c.flags[ta + ua], f1 = c.flags[ta + ub], f2 = c.flags[tb + ua], f3 = c.flags[tb + ub];
+        if (f0 != 0 && f1 != 0 && f2 != 0 && f3 != 0) return make_double2(0.0, 0.0);
+    }
+    if (inner && r1 == r0 + 1 && c1 == c0 + 1) {
+        // the usual case, the diagonal pair (r0, c0), (r0 + 1, c0 + 1) (quirk Q7): the two crosses share two cells
+        const T a_w = ring_phi(c, r0, c0 - 1), a_c = ring_phi(c, r0, c0), a_s = ring_phi(c, r0 - 1, c0);
+        const T sh_e = ring_phi(c, r0, c1);         // east of A = south of B
+        const T sh_n = ring_phi(c, r1, c0);         // north of A = west of B
+        const T b_c = ring_phi(c, r1, c1), b_e = ring_phi(c, r1, c1 + 1), b_n = ring_phi(c, r1 + 1, c1);
+        const double2 a = ring_vels<T, TO>(c, a_w, sh_e, a_s, sh_n, a_c);
+        const double2 b = ring_vels<T, TO>(c, sh_n, b_e, sh_e, b_n, b_c);
+        return make_double2((a.x + b.x) / 2, (a.y + b.y) / 2);
+    }
     const double2 a = ring_dir<T, TO>(c, P.Ny, i0 + 1, j0 + 1), b = ring_dir<T, TO>(c, P.Ny, i1 + 1, j1 + 1);
     return make_double2((a.x + b.x) / 2, (a.y + b.y) / 2);
 }
@@ -1288,7 +1338,7 @@ __device__ __forceinline__ void prep_tile(const GcfmParams& P, const Scratch& S,
     if (do_lookup) {
         double2 ds = make_double2(0.0, 0.0);
         if (act) ds = lookup(P, kd, ksteps[dk.key], p.x, p.y, dk.v_des, step, i, err);     // its loads fly during the search
-        S.des[k] = ds;
+        xs(S, S.des, S.ts_des, k) = ds;
     }
     if (do_wall) {
         WEntry we = {};
@@ -1296,7 +1346,7 @@ __device__ __forceinline__ void prep_tile(const GcfmParams& P, const Scratch& S,
         const long long widx = wall_search(P, we, need, X0, Y0);
         double2 fw = make_double2(0.0, 0.0);
         if (act) fw = wall_force_of(P, widx, p.x, p.y, v.x, v.y, dk.v_des, X0, Y0);
-        S.f_wall[k] = fw;
+        xs(S, S.f_wall, S.ts_wall, k) = fw;
     }
 }
 
@@ -1304,6 +1354,8 @@ struct TileShare {              // which tiles this launch works on (the whole s
     int32_t lo, hi;             // pair forces and wall forces: tiles lo .. hi - 1
     int32_t by_work;            // dispatch the pair blocks by decreasing work (tile_order) instead of by index
     int32_t lookup_all;         // do the floor-field lookup of every tile (the field's row blocks decide who answers)
+    int32_t prep_lookup;        // 1: the prep blocks do the lookups (every tile when lookup_all, else lo .. hi - 1);
+                                // 0: each pair block looks up its own tile's agents (single GPU, the default)
 };
 
 // The step's force kernel.  Blocks of 4 wavefronts.  The first `nprep` blocks sweep the tiles with prep_tile (they
@@ -1331,7 +1383,8 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
         for (int t = blockIdx.x * 4 + w; t < S.ntiles; t += nprep * 4) {
             const bool mine = t >= sh.lo && t < sh.hi;
             if ((mine || sh.lookup_all) && !(P.diag & 2u))
-                prep_tile(P, S, C, keys, ksteps, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8], mine, mine || sh.lookup_all);
+                prep_tile(P, S, C, keys, ksteps, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8], mine,
+                          sh.prep_lookup != 0 && (mine || sh.lookup_all) && !(P.diag & 8u));
         }
         return;
     }
@@ -1346,7 +1399,22 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
     __syncthreads();
     if (live) pair_share<NS>(P, S, C, L, it, tl, sub, w, lane);
     __syncthreads();
-    if (live && sub == 0) S.f_pair[it * 64 + lane] = make_double2(L.accx[tl][lane], L.accy[tl][lane]);
+    if (live && sub == 0) xs(S, S.f_pair, S.ts_pair, it * 64 + lane) = make_double2(L.accx[tl][lane], L.accy[tl][lane]);
+    // The tile's floor-field lookups (optimals.py:212-250; through the interpolant ring: five cells' values and `vels` per
+    // looked-up cell), one lane per agent, by the tile's last wavefront once its pair share is done.  In the prep blocks the
+    // lookup sat on the launch's critical chain -- the prep wavefronts' dependent loads ARE the launch's length -- and cost
+    // 11 us per launch with slices, 27 us through the ring; here its latency hides behind the other blocks' arithmetic.
+    if (live && sub == NS - 1 && sh.prep_lookup == 0 && !(P.diag & 8u)) {
+        const int k = it * 64 + lane;
+        const int i = C.pidx[k];
+        double2 ds = make_double2(0.0, 0.0);
+        if (i >= 0) {
+            const double2 p = C.ppos[k];
+            const PDK dk = S.pdk[k];
+            ds = lookup(P, keys[dk.key], ksteps[dk.key], p.x, p.y, dk.v_des, step, i, &S.ctrl[C_ERR + 8]);
+        }
+        xs(S, S.des, S.ts_des, k) = ds;
+    }
 }
 
 #define RECT_TAB (1 + 4 * OC_MAX_TARGET_RECTS)      // doubles per key in the exit-rectangle table: count, then (cx,cy,w,h)
@@ -1360,7 +1428,7 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
 template <bool SEQ>
 __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const double* __restrict__ rect_tab, int nkeys,
                                                StepArgs A, int seq_round, double seq_margin,
-                                               const double* __restrict__ err_slots, int n_err_slots,
+                                               const double* __restrict__ err_slots, int n_err_slots, int64_t err_stride,
                                                const KeyDev* __restrict__ keys, KeyStep* __restrict__ ksteps) {
     __shared__ double l_rect[RECT_KEYS_LDS * RECT_TAB];
     const Snap& C = S.snap;
@@ -1376,7 +1444,8 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     const bool live = i >= 0;                       // an agent sits in this slot
     const bool act = live && sstate == 1;           // ... and is advanced by this launch
     bool out = false;
-    const double2 p = C.ppos[k], v = S.pvd[k], ds = S.des[k], fw = S.f_wall[k], fp = S.f_pair[k];
+    const double2 p = C.ppos[k], v = S.pvd[k], ds = xs(S, S.des, S.ts_des, k), fw = xs(S, S.f_wall, S.ts_wall, k),
+                  fp = xs(S, S.f_pair, S.ts_pair, k);
     double nx = (SEQ && live) ? p.x : 1e300, ny = (SEQ && live) ? p.y : 1e300;
     const PDK dk = S.pdk[k];
     // (needed only at the very end, by lane 0: fetched with the rest so that the tail holds no memory round trip)
@@ -1386,7 +1455,7 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     int err0 = 0;
     if (it == 0) {
         err0 = S.ctrl[C_ERR + 8];
-        for (int r = 0; r < n_err_slots; ++r) err0 = max(err0, (int)err_slots[r]);
+        for (int r = 0; r < n_err_slots; ++r) err0 = max(err0, (int)err_slots[(size_t)r * err_stride]);
     }
     const double at0 = (act && A.agent_time) ? A.agent_time[i] : 0.0;
     double n0 = 0.0, n1 = 0.0;
@@ -1593,7 +1662,7 @@ __global__ void __launch_bounds__(64) k_seq_pairs(GcfmParams P, Scratch S, int r
         }
     }
     if (i >= 0 && st_i == 0 && !blocked) {
-        S.f_pair[k] = make_double2(fx, fy);
+        xs(S, S.f_pair, S.ts_pair, k) = make_double2(fx, fy);
         S.seq_state[k] = 1;
     }
 }
@@ -1750,6 +1819,8 @@ int carve(oc_handle* h, int N, Scratch* S, bool diag = false) {
     S->f_pair = (double2*)take(sizeof(double2) * Np);
     S->f_wall = (double2*)take(sizeof(double2) * Np);
     S->des = (double2*)take(sizeof(double2) * Np);
+    S->ts_pair = S->ts_wall = S->ts_des = 64;
+    S->x_tpr = S->x_blk = 0;
     S->tile_box0 = (double4*)take(sizeof(double4) * nt);
     S->widx = (long long*)take(sizeof(long long) * Np);
     S->keys_a = (uint32_t*)take(sizeof(uint32_t) * Np);
@@ -1989,15 +2060,32 @@ extern "C" int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out
     return OC_OK;
 }
 
-__global__ void k_err_publish(const int32_t* __restrict__ ctrl, double* __restrict__ slots, int rank) {
-    slots[rank] = (double)ctrl[C_ERR + 8];          // (the other ranks' slots stay zero for the sum)
+__global__ void k_err_publish(const int32_t* __restrict__ ctrl, double* __restrict__ slot) {
+    slot[0] = (double)ctrl[C_ERR + 8];              // (the tail of this rank's block of the exchange buffer)
+}
+
+// layout of the sharded step's exchange buffer (oc_hip.h: oc_step_comm): `world` blocks of XB doubles -- a rank's share of
+// the tiles, [pair x 64][wall x 64]([des x 64]) double2 per tile, then 8 doubles of which the first is the rank's
+// IndexError-band word -- followed by one double2 per slot: the desired velocities when the floor fields are sharded
+struct XchgLayout {
+    int tpr;            // tiles per rank
+    int td;             // doubles per tile in a block: 384 with the desired velocities, 256 without
+    int64_t block;      // doubles per rank as exchanged (tpr * td + 8)
+    int64_t block_max;  // doubles between two ranks' blocks in memory (tpr * 384 + 8)
+};
+static XchgLayout xchg_layout(int ntiles, int world, bool des_separate) {
+    XchgLayout x;
+    x.tpr = (ntiles + world - 1) / world;
+    x.td = des_separate ? 256 : 384;
+    x.block = (int64_t)x.tpr * x.td + 8;
+    x.block_max = (int64_t)x.tpr * 384 + 8;
+    return x;
 }
 
 // one step, or one rank's part of it: k_forces on the tiles of `share`, [the caller's sum over the ranks], k_finish
 static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmParams& P, int32_t simu_step,
                        const double* noise, uint64_t seed, int32_t* counters, TileShare share,
-                       int (*allreduce_sum)(void*, double*, int64_t), void* user, double* xchg, int rank,
-                       hipStream_t s) {
+                       const oc_step_comm* comm, bool des_separate, hipStream_t s) {
     StepArgs A;
     A.x = a->x; A.y = a->y; A.vx = a->vx; A.vy = a->vy;
     A.status = a->status;
@@ -2034,18 +2122,31 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
     h->work_tiles = S.ntiles;
     const double* err_slots = nullptr;
     int n_err_slots = 0;
-    if (allreduce_sum) {
-        err_slots = xchg + 6 * (size_t)S.Np;
-        n_err_slots = OC_MAX_WORLD;
-        hipLaunchKernelGGL(k_err_publish, dim3(1), dim3(1), 0, s, S.ctrl, xchg + 6 * (size_t)S.Np, rank);
-        if (allreduce_sum(user, xchg, 6 * (int64_t)S.Np + OC_MAX_WORLD) != 0) {
-            oc_set_error("oc_gcfm_step_sharded: the allreduce_sum callback failed");
+    int64_t err_stride = 1;
+    if (comm) {
+        // the ranks' shares: ONE all-gather of equal blocks (a rank sends its block once and receives the others': the bytes
+        // of the whole buffer cross the wire once, against twice for the sum-all-reduce of a zero-padded buffer it replaces)
+        const XchgLayout X = xchg_layout(S.ntiles, comm->world, des_separate);
+        err_slots = comm->xchg + (int64_t)X.tpr * X.td;
+        err_stride = X.block;
+        n_err_slots = comm->world;
+        hipLaunchKernelGGL(k_err_publish, dim3(1), dim3(1), 0, s, S.ctrl,
+                           comm->xchg + (int64_t)comm->rank * X.block + (int64_t)X.tpr * X.td);
+        if (comm->allgather(comm->user, comm->xchg, X.block) != 0) {
+            oc_set_error("oc_gcfm_step_sharded: the allgather callback failed");
             return OC_ERR_STATE;
+        }
+        if (des_separate) {     // desired velocities answered by the holders of the field rows: zero elsewhere, summed
+            if (comm->allreduce_sum(comm->user, (double*)S.des, 2 * (int64_t)S.Np) != 0) {
+                oc_set_error("oc_gcfm_step_sharded: the allreduce_sum callback failed");
+                return OC_ERR_STATE;
+            }
         }
     }
     oc_timer_begin(h, "gcfm_finish", s);
     hipLaunchKernelGGL(k_finish<false>, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
-                       (int)h->fields.size(), A, 0, 0.0, err_slots, n_err_slots, kd, h->any_ring ? ksteps : (KeyStep*)nullptr);
+                       (int)h->fields.size(), A, 0, 0.0, err_slots, n_err_slots, err_stride, kd,
+                       h->any_ring ? ksteps : (KeyStep*)nullptr);
     if (h->any_ring) h->ring_step_ready = (int64_t)simu_step + 1;
     oc_timer_end(h, "gcfm_finish", s);
     OC_HIP_CHECK(hipGetLastError());
@@ -2071,8 +2172,8 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
     if (!h->packed_valid || h->packed_x != a->x || h->packed_N != a->N || h->steps_since_sort >= h->resort_every) {
         if ((rc = repack(h, a, &S, P, s))) return rc;
     }
-    const TileShare all = {0, S.ntiles, 1, 0};
-    return launch_step(h, a, S, P, simu_step, noise, seed, counters, all, nullptr, nullptr, nullptr, 0, s);
+    const TileShare all = {0, S.ntiles, 1, 0, 0};
+    return launch_step(h, a, S, P, simu_step, noise, seed, counters, all, nullptr, false, s);
 }
 
 
@@ -2118,7 +2219,7 @@ extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t
     // does not change before its turn (the prep blocks of k_forces alone; they also reset the step's counters)
     {
         const int nprep = std::max((S.ntiles + 3) / 4, 1);
-        const TileShare all = {0, S.ntiles, 0, 0};
+        const TileShare all = {0, S.ntiles, 0, 0, 1};      // (prep blocks only: they do the lookups)
         auto kf = P.fix ? k_forces<4, true> : k_forces<4, false>;
         if (h->any_ring && h->ring_step_ready != (int64_t)simu_step) {
             hipLaunchKernelGGL(k_ring_step, dim3(1), dim3(64 * (((int)h->fields.size() + 63) / 64)), 0, s, kd,
@@ -2137,7 +2238,8 @@ extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t
         for (int b = 0; b < burst; ++b, ++rounds) {
             hipLaunchKernelGGL(k_seq_pairs, dim3(S.ntiles), dim3(64), 0, s, P, S, rounds, margin);
             hipLaunchKernelGGL((k_finish<true>), dim3(S.ntiles), dim3(64), 0, s, Pf, S, (const double*)h->rect_tab_dev,
-                               (int)h->fields.size(), A, rounds, margin, (const double*)nullptr, 0, kd, (KeyStep*)nullptr);
+                               (int)h->fields.size(), A, rounds, margin, (const double*)nullptr, 0, (int64_t)1, kd,
+                               (KeyStep*)nullptr);
         }
         OC_HIP_CHECK(hipMemcpyAsync(ctl, S.seq_ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
         OC_HIP_CHECK(hipStreamSynchronize(s));
@@ -2190,16 +2292,21 @@ extern "C" int64_t oc_padded_agents(int32_t N) {
     return Np == 0 ? 64 : Np;
 }
 
-extern "C" int64_t oc_xchg_doubles(int32_t N) { return 6 * oc_padded_agents(N) + OC_MAX_WORLD; }
+static int64_t xchg_total(int32_t N, int32_t world) {
+    const int64_t Np = oc_padded_agents(N);
+    const XchgLayout X = xchg_layout((int)(Np / 64), world > 0 ? world : 1, false);
+    return (int64_t)(world > 0 ? world : 1) * X.block_max + 2 * Np;
+}
+
+extern "C" int64_t oc_xchg_doubles(int32_t N, int32_t world) { return xchg_total(N, world); }
 
 extern "C" int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise,
-                                    uint64_t seed, int32_t* counters, int32_t rank, int32_t world, double* xchg,
-                                    int (*allreduce_sum)(void* user, double* buf, int64_t count), void* user,
-                                    void* stream) {
+                                    uint64_t seed, int32_t* counters, const oc_step_comm* comm, void* stream) {
     int rc = check_agents(h, a);
     if (rc) return rc;
     if ((rc = require_wallmaps(h))) return rc;
-    OC_REQUIRE(world >= 1 && rank >= 0 && rank < world && xchg && allreduce_sum, "bad shard arguments");
+    OC_REQUIRE(comm && comm->world >= 1 && comm->world <= OC_MAX_WORLD && comm->rank >= 0 && comm->rank < comm->world &&
+               comm->xchg && comm->allgather, "bad oc_step_comm");
     OC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     Scratch S;
@@ -2210,17 +2317,30 @@ extern "C" int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t si
     if (!h->packed_valid || h->packed_x != a->x || h->packed_N != a->N || h->steps_since_sort >= h->resort_every) {
         if ((rc = repack(h, a, &S, P, s))) return rc;
     }
-    // pair sums, wall forces and desired velocities live in the caller's exchange buffer: zero, then each rank's part
-    S.f_pair = (double2*)xchg;
-    S.f_wall = S.f_pair + S.Np;
-    S.des = S.f_wall + S.Np;
-    OC_HIP_CHECK(hipMemsetAsync(xchg, 0, sizeof(double) * (6 * (size_t)S.Np + OC_MAX_WORLD), s));
     // who answers a lookup: with row blocks -- or with keys dealt to different ranks, where this rank holds no field of
-    // some key -- every rank walks all tiles and the holder of the field rows answers; with every field whole on every
-    // rank the tile's owner does
+    // some key -- every rank walks all tiles and the holder of the field rows answers (the desired velocities then travel
+    // by their own zero-padded sum); with every field whole on every rank the tile's owner does, and they ride in its block
     bool rows = false;
     for (const auto& f : h->fields) rows = rows || f.rows >= 0 || (f.vx == nullptr && f.ring_data == nullptr);
-    const TileShare mine = {(int32_t)((int64_t)S.ntiles * rank / world), (int32_t)((int64_t)S.ntiles * (rank + 1) / world), 0,
-                            rows ? 1 : 0};
-    return launch_step(h, a, S, P, simu_step, noise, seed, counters, mine, allreduce_sum, user, xchg, rank, s);
+    OC_REQUIRE(!rows || comm->allreduce_sum, "sharded floor fields need the allreduce_sum callback");
+    const XchgLayout X = xchg_layout(S.ntiles, comm->world, rows);
+    // pair sums, wall forces (and desired velocities) of tile t live in the block of the rank that owns t
+    double* base = comm->xchg;
+    S.f_pair = (double2*)base;
+    S.f_wall = S.f_pair + 64;
+    S.ts_pair = S.ts_wall = X.td / 2;                   // (double2 units)
+    S.x_tpr = X.tpr;
+    S.x_blk = (int32_t)(X.block / 2);
+    if (rows) {
+        S.des = (double2*)(base + (int64_t)comm->world * X.block_max);
+        S.ts_des = 64;
+        OC_HIP_CHECK(hipMemsetAsync(S.des, 0, sizeof(double2) * (size_t)S.Np, s));
+    } else {
+        S.des = S.f_pair + 128;
+        S.ts_des = X.td / 2;
+    }
+    // (tile t belongs to rank t / tpr and sits at r * X.block + (t % tpr) * td doubles: xs())
+    const TileShare mine = {std::min(comm->rank * X.tpr, S.ntiles), std::min((comm->rank + 1) * X.tpr, S.ntiles), 0,
+                            rows ? 1 : 0, rows ? 1 : 0};
+    return launch_step(h, a, S, P, simu_step, noise, seed, counters, mine, comm, rows, s);
 }

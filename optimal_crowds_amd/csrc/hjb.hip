@@ -1362,8 +1362,18 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
     const int t_lo = worker ? min((int)threadIdx.x * per_thr, ntile) : ntile, t_hi = min(t_lo + per_thr, ntile);
     uint32_t listed = 0xFFFFFFFFu, listed_hi = 0xFFFFFFFFu;     // bit q: tile t_lo + q goes on the list (per_thr <= 64)
     if (skip_ok) {
-        if (worker)
-            for (int t = threadIdx.x; t < ntile; t += nth) sflag[t] = ld_flag<SC1>(flags_cur + t) != 0 ? 1 : 0;
+        if (worker) {
+            // (eight independent loads in flight per thread: as sc1 loads in a one-load-per-trip loop each trip waited for
+            // its own round trip to the L2)
+            for (int t0 = threadIdx.x; t0 < ntile; t0 += 8 * nth) {
+                int32_t f[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) f[u] = (t0 + u * nth < ntile) ? ld_flag<SC1>(flags_cur + t0 + u * nth) : 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (t0 + u * nth < ntile) sflag[t0 + u * nth] = f[u] != 0 ? 1 : 0;
+            }
+        }
         __syncthreads();
         int bi = t_lo / tnbx, bj = t_lo % tnbx;
         for (int t = t_lo; t < t_hi; ++t) {
@@ -2316,7 +2326,9 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         }
     }
     const int n_real = hc.n_attempt;
-    std::vector<int32_t> log((size_t)std::min(enq, LOG_CAP));
+    // (the controller's ticks, not the attempts enqueued: with the fused tail an attempt past the end of the solve returns
+    // before anything is logged, and its slot holds an older solve's word)
+    std::vector<int32_t> log((size_t)std::max(std::min(std::min(enq, (int)hc.ticks), LOG_CAP), 0));
     if (!log.empty()) OC_HIP_CHECK(hipMemcpy(log.data(), h->hjb_log, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost));
     for (size_t a = 0; a < log.size(); ++a)
         if (log[a] & 2) stats.n_slices_written += log[a] >> 8;

@@ -576,13 +576,13 @@ class Engine:
         .DistStepComm or ThreadStepComm) sums the exchange buffer over the ranks, every rank finishes all agents."""
         if noise is not None and not torch.is_tensor(noise):
             noise = torch.as_tensor(np.ascontiguousarray(noise, dtype=np.float64)).to(self.device)
-        n = int(self.lib.oc_xchg_doubles(int(self.agents["N"])))
+        n = int(self.lib.oc_xchg_doubles(int(self.agents["N"]), int(comm.world)))
         if getattr(self, "_xchg", None) is None or self._xchg.numel() != n:
             self._xchg = torch.zeros(n, dtype=torch.float64, device=self.device)
         comm.bind(self._xchg)
+        st = comm.struct()
         rc = self.lib.oc_gcfm_step_sharded(self.h, C.byref(self._astruct), int(simu_step), _ptr(noise),
-                                           C.c_uint64(int(seed)), _ptr(self.counters), int(comm.rank), int(comm.world),
-                                           _ptr(self._xchg), comm.callback, None, self.stream())
+                                           C.c_uint64(int(seed)), _ptr(self.counters), C.byref(st), self.stream())
         if comm.error is not None:
             err, comm.error = comm.error, None
             raise err

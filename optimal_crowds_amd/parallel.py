@@ -5,7 +5,8 @@ workloads):
 * keys first, then the HJB grid in row blocks: `key_row_plan` deals the keys to groups of ranks, `RowShard` is the
   geometry of one rank's block, `DistHaloComm` carries the two collectives of `oc_hjb_solve_rows` (include/oc_hip.h) --
   halo rows to the neighbours, all-gather of the error norm -- enqueued on the launch stream, no host synchronisation;
-* replicated agents: `DistStepComm` carries the one sum-all-reduce per step of `oc_gcfm_step_sharded`;
+* replicated agents: `DistStepComm` carries the step's exchange of `oc_gcfm_step_sharded` -- one all-gather of the ranks'
+  tile shares, plus a sum of the desired velocities when the floor fields are sharded;
 * `dist_sharding()` is the `sharding=` argument that switches a whole `simulations.simulation` to this mode;
 * `ThreadHaloComm` / `ThreadStepComm` / `thread_sharding` run several virtual ranks inside one process on one GPU (tests).
 Over nccl the collectives move device tensors (RCCL over xGMI) on the launch stream; over gloo they are staged through
@@ -18,7 +19,7 @@ import threading
 import torch
 import torch.distributed as dist
 
-from ._lib import ALLREDUCE_CB, HALO_CB, OcHjbShard
+from ._lib import ALLGATHER_CB, ALLREDUCE_CB, HALO_CB, OcHjbShard, OcStepComm
 
 
 def init_distributed(backend=None):
@@ -232,69 +233,111 @@ class ThreadHaloComm(_HaloComm):
 
 # ---------------------------------------------------------------------------------------------- sharded agent step
 class _StepComm:
-    """The one collective of oc_gcfm_step_sharded: a SUM of the exchange buffer (pair sums, wall forces, desired
-    velocities per slot; every element has exactly one non-zero contribution) over the ranks, in place, enqueued on
-    the current stream.  Subclasses implement allreduce()."""
+    """The collectives of oc_gcfm_step_sharded (oc_hip.h: oc_step_comm), both in place on the exchange buffer and enqueued
+    on the current stream: ONE all-gather per step of the ranks' blocks (each rank's share of the tiles: pair sums, wall
+    forces and -- when every rank holds every floor field -- desired velocities: 32 or 48 bytes per agent in total), and,
+    only when the floor fields are sharded, a SUM of the desired velocities (16 bytes per agent, one non-zero contribution
+    per element).  Subclasses implement allgather(per) and allreduce(view)."""
 
     def __init__(self, rank, world):
         self.rank, self.world = int(rank), int(world)
         self.buf = None
         self.error = None
-        self.n_allreduce = 0
-        self.callback = ALLREDUCE_CB(self._cb)
+        self.n_allgather = self.n_allreduce = 0
+        self.bytes_allgather = self.bytes_allreduce = 0         # payload of the last step (all ranks' blocks / the sum)
+        self._cb_ag = ALLGATHER_CB(self._ag)
+        self._cb_ar = ALLREDUCE_CB(self._ar)
 
     def bind(self, buf):
         self.buf = buf
 
-    def _cb(self, user, ptr, count):
+    def struct(self):
+        st = OcStepComm()
+        st.rank, st.world = self.rank, self.world
+        st.xchg = self.buf.data_ptr()
+        st.allgather, st.allreduce_sum, st.user = self._cb_ag, self._cb_ar, None
+        return st
+
+    def _view(self, ptr, count):
+        off = (ptr - self.buf.data_ptr()) // 8
+        assert self.buf is not None and 0 <= off and off + count <= self.buf.numel()
+        return self.buf[off:off + count]
+
+    def _ag(self, user, ptr, per):
         try:
-            assert self.buf is not None and self.buf.data_ptr() == ptr and self.buf.numel() == count
-            self.allreduce()
-            self.n_allreduce += 1
+            assert ptr == self.buf.data_ptr() and per * self.world <= self.buf.numel()
+            self.allgather(int(per))
+            self.n_allgather += 1
+            self.bytes_allgather = 8 * int(per) * self.world
             return 0
         except BaseException as e:        # an exception must not unwind through the C frames
             self.error = e
             return -1
 
+    def _ar(self, user, ptr, count):
+        try:
+            self.allreduce(self._view(ptr, int(count)))
+            self.n_allreduce += 1
+            self.bytes_allreduce = 8 * int(count)
+            return 0
+        except BaseException as e:
+            self.error = e
+            return -1
+
 
 class DistStepComm(_StepComm):
-    """torch.distributed: backend nccl (= RCCL) all-reduces the device tensor over xGMI on the current stream
-    (1.7 MB at 100 000 agents, 24 MB at 500 000: one collective per step); gloo stages through host memory (tests)."""
+    """torch.distributed: backend nccl (= RCCL) gathers / sums the device tensor over xGMI on the current stream, in place
+    (C4: 100 000 agents -> 3.2 MB all-gather + 1.6 MB sum with sharded fields, 4.8 MB all-gather without); gloo stages
+    through host memory (tests)."""
 
     def __init__(self, group=None):
         super().__init__(dist.get_rank(group), dist.get_world_size(group))
         self.group = group
         self.host_staged = dist.get_backend(group) != "nccl"
-        self._h = None
 
-    def allreduce(self):
+    def allgather(self, per):
+        mine = self.buf[self.rank * per:(self.rank + 1) * per]
         if self.host_staged:
-            if self._h is None or self._h.numel() != self.buf.numel():
-                self._h = torch.empty(self.buf.numel(), dtype=self.buf.dtype)
-            self._h.copy_(self.buf)
-            dist.all_reduce(self._h, op=dist.ReduceOp.SUM, group=self.group)
-            self.buf.copy_(self._h)
+            parts = [torch.empty(per, dtype=self.buf.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, mine.cpu(), group=self.group)
+            self.buf[:per * self.world].copy_(torch.cat(parts))
+        else:       # (in place: rank r's input IS block r of the output)
+            dist.all_gather_into_tensor(self.buf[:per * self.world], mine, group=self.group)
+
+    def allreduce(self, view):
+        if self.host_staged:
+            hbuf = view.cpu()
+            dist.all_reduce(hbuf, op=dist.ReduceOp.SUM, group=self.group)
+            view.copy_(hbuf)
         else:
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
 
 
 class ThreadStepComm(_StepComm):
-    """Virtual ranks in threads of one process on one GPU (tests): rank 0 sums everybody's buffer."""
+    """Virtual ranks in threads of one process on one GPU (tests): device copies between the ranks' buffers."""
 
     def __init__(self, rank, tworld):
         super().__init__(rank, tworld.world)
         self.tw = tworld
         tworld.comms[rank] = self
 
-    def allreduce(self):
+    def allgather(self, per):
+        self.tw.sync()                                  # every rank's block is written
+        for r, c in enumerate(self.tw.comms):
+            if r != self.rank:
+                self.buf[r * per:(r + 1) * per].copy_(c.buf[r * per:(r + 1) * per])
+        self.tw.sync()                                  # nobody rewrites its block before it was read
+
+    def allreduce(self, view):
+        self._view_now = view
         self.tw.sync()                                  # every rank's part is written
         if self.rank == 0:
-            total = torch.zeros_like(self.buf)
+            total = torch.zeros_like(view)
             for c in self.tw.comms:
-                total += c.buf
+                total += c._view_now
             self._total = total
         self.tw.sync()
-        self.buf.copy_(self.tw.comms[0]._total)
+        view.copy_(self.tw.comms[0]._total)
         self.tw.sync()                                  # rank 0 keeps _total until everybody has copied it
 
 

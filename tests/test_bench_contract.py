@@ -47,6 +47,27 @@ def test_bench_line_has_the_contract_fields():
     assert b["gcfm_kernel_ms_per_step"] > 0
 
 
+def _launcherless_bench(workload, extra=()):
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher (the shape of the driver's single-GPU command with N = 2): bench.py
+    starts torch.distributed.run itself as a child process and relays rank 0's line"""
+    env = dict(os.environ, OC_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--workload", workload, "--no-cpu-baseline", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_without_a_launcher():
+    d = _launcherless_bench("exit_opposite", ("--mode", "sharded", "--no-ensemble-line"))
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["mode"] == "sharded" and d["value"] > 0
+    assert d["rccl"]["ranks"] == 2 and d["rccl"]["hjb_key_plan"] == [[0], [1]]
+
+
 def _torchrun_bench(workload, extra=()):
     """the driver's N > 1 command (one rank per GPU) rehearsed on this one-GPU box: both ranks on cuda:0, collectives
     over gloo (OC_BENCH_ONE_DEVICE=1) -- the same bench.py code path, communicators and library calls as over RCCL"""
@@ -72,8 +93,11 @@ def test_bench_two_ranks_sharded_keys_first():
     d = _torchrun_bench("exit_opposite", ("--mode", "sharded"))
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["mode"] == "sharded" and d["value"] > 0
     r = d["rccl"]
-    assert r["ranks"] == 2 and r["hjb_key_plan"] == [[0], [1]] and r["collectives_per_step"] == 1
-    assert r["step_allreduces"] == 25 and r["step_allreduce_bytes"] == 8 * (6 * 5056 + 64)       # 5000 agents -> 79 tiles
+    # keys on different ranks: the forces by the all-gather of tile shares (5000 agents -> 79 tiles, 40 per rank, 32 B per
+    # slot + the block tails), the desired velocities by their own sum (16 B per slot)
+    assert r["ranks"] == 2 and r["hjb_key_plan"] == [[0], [1]] and r["collectives_per_step"] == 2
+    assert r["step_allgathers"] == 25 and r["step_allgather_bytes"] == 8 * 2 * (40 * 256 + 8)
+    assert r["step_allreduces"] == 25 and r["step_allreduce_bytes"] == 16 * 5056
     assert r["hjb_allgathers_this_rank"] == 0 and r["hjb_halo_exchanges_this_rank"] == 0
     assert d["breakdown"]["hjb_solves_this_rank"] == 1
     e = d["ensemble"]
@@ -85,7 +109,7 @@ def test_bench_two_ranks_sharded_row_blocks():
     d = _torchrun_bench("slalom", ("--mode", "sharded", "--no-ensemble-line"))
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "ensemble" not in d
     r = d["rccl"]
-    assert r["hjb_key_plan"] == [[0, 1]] and r["step_allreduces"] == 25
+    assert r["hjb_key_plan"] == [[0, 1]] and r["step_allreduces"] == 25 and r["step_allgathers"] == 25
     assert r["hjb_halo_exchanges_this_rank"] >= 2 * d["breakdown"]["rk_attempts"]                 # warm-up + timed solve
     assert r["hjb_allgathers_this_rank"] == r["hjb_halo_exchanges_this_rank"] + 6
     assert r["hjb_halo_message_bytes"] == 2 * 8 * 1024 * 4

@@ -257,18 +257,29 @@ def _step_comm_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from optimal_crowds_amd import parallel
     parallel.init_distributed("gloo")
-    # the exchange buffer of oc_gcfm_step_sharded: every element is written by exactly one rank, zeros elsewhere
-    n = 6 * 128
-    owner = np.arange(n) % world
-    vals = np.random.RandomState(5).normal(size=n)
-    buf = torch.as_tensor(np.where(owner == rank, vals, 0.0))
+    # the exchange buffer of oc_gcfm_step_sharded (oc_hip.h: oc_step_comm): `world` blocks -- a rank writes its own, the
+    # in-place all-gather brings the others' -- and, behind them, the values that are summed (one writer per element)
+    per, nsum = 100, 6 * 16
+    rs = np.random.RandomState(5)
+    blocks = rs.normal(size=(world, per))
+    vals = rs.normal(size=nsum)
+    owner = np.arange(nsum) % world
+    buf = torch.zeros(world * per + 7 + nsum, dtype=torch.float64)         # (7 values between the two areas stay untouched)
+    buf[rank * per:(rank + 1) * per] = torch.as_tensor(blocks[rank])
+    buf[world * per + 7:] = torch.as_tensor(np.where(owner == rank, vals, 0.0))
     comm = parallel.DistStepComm()
     comm.bind(buf)
-    rc = comm._cb(None, buf.data_ptr(), n)                      # what the library's callback does
-    ok = rc == 0 and comm.error is None and comm.n_allreduce == 1 and np.array_equal(buf.numpy(), vals)
+    st = comm.struct()
+    assert st.rank == rank and st.world == world and st.xchg == buf.data_ptr()
+    rc = comm._ag(None, buf.data_ptr(), per)                    # what the library's callbacks do
+    rc_b = comm._ar(None, buf.data_ptr() + 8 * (world * per + 7), nsum)
+    ok = (rc == 0 and rc_b == 0 and comm.error is None and comm.n_allgather == 1 and comm.n_allreduce == 1
+          and np.array_equal(buf[:world * per].numpy(), blocks.reshape(-1)) and not buf[world * per:world * per + 7].any()
+          and np.array_equal(buf[world * per + 7:].numpy(), vals)
+          and comm.bytes_allgather == 8 * per * world and comm.bytes_allreduce == 8 * nsum)
     # a buffer the library did not announce is refused (and must not raise through the C frames)
     other = torch.zeros(4, dtype=torch.float64)
-    rc2 = comm._cb(None, other.data_ptr(), 4)
+    rc2 = comm._ar(None, other.data_ptr(), 4)
     refused = rc2 == -1 and isinstance(comm.error, AssertionError)
     # row-block geometry the sharded lookup relies on: the owned rows tile the grid, halo >= 8 leaves a margin row
     sh = parallel.RowShard(64, rank, world, halo=8)

@@ -111,11 +111,15 @@ def test_sharded_step_with_replicated_fields(world, fixes):
         outs = [eng.step_sharded(s, comm, noise=noise[s]) for s in range(steps)]
         st = eng.get_state()
         eng.close()
-        return st, outs, comm.n_allreduce
+        return st, outs, (comm.n_allgather, comm.n_allreduce, comm.bytes_allgather)
 
     res = _run_ranks(world, body)
     for st, outs, nred in res:
-        assert nred == steps
+        # every field whole on every rank: ONE all-gather per step and nothing else; 48 bytes per (padded) agent slot +
+        # the ranks' block tails
+        assert nred[:2] == (steps, 0)
+        tiles = -(-n // 64)
+        assert nred[2] == 8 * world * (-(-tiles // world) * 384 + 8)
         assert [(o[0], o[2]) for o in outs] == [(o[0], o[2]) for o in ref_out]        # exits, active agents
         assert np.array_equal(st["status"], ref["status"])
         for f in ("x", "y", "vx", "vy"):
@@ -200,7 +204,8 @@ def _dist_worker(rank, world, port, q):
         eng.set_agents(x, y, vx, vy, vdes, key, status=status)
         comm = parallel.DistStepComm()
         outs = [eng.step_sharded(s, comm, noise=noise[s]) for s in range(steps)]
-        res = dict(rank=rank, st=eng.get_state(), outs=outs, nred=comm.n_allreduce)
+        res = dict(rank=rank, st=eng.get_state(), outs=outs, nred=comm.n_allreduce, ngat=comm.n_allgather,
+                   bytes=(comm.bytes_allgather, comm.bytes_allreduce))
         if rank == 0:
             ref, ref_out = _reference("exit_opposite", state, noise, steps)
             res.update(ref=ref, ref_out=ref_out)
@@ -229,7 +234,10 @@ def test_sharded_step_two_processes_gloo():
     res.sort(key=lambda r: r["rank"])
     ref = res[0]["ref"]
     for r in res:
-        assert r["nred"] == 3
+        # row blocks: the desired velocities go by their own sum (16 B per slot), the forces by the all-gather (32 B)
+        assert r["nred"] == 3 and r["ngat"] == 3
+        n_slots = 64 * -(-len(ref["x"]) // 64)
+        assert r["bytes"][1] == 16 * n_slots and r["bytes"][0] == 8 * world * (-(-(n_slots // 64) // world) * 256 + 8)
         assert np.array_equal(r["st"]["status"], ref["status"])
         for f in ("x", "y", "vx", "vy"):
             assert np.array_equal(r["st"][f], res[0]["st"][f])                       # replicas bit-identical
