@@ -41,7 +41,7 @@ struct KeyDev {
     const void* ring_data;                  // NULL: slices (vx, vy)
     const void* ring_slots;                 // OcRingSlot<T> [slots]
     const void* ring_slices;                // OcRingSlice<T> [nslice]
-    const uint8_t* ring_flags;              // [slots][ring_ntile]
+    const int32_t* ring_first;              // [ring_ntile]: first slot in which each stage tile holds data
     int64_t ring_slot_elems;
     int32_t ring_state_dtype, ring_ntile, ring_tnbx, ring_pad;
     double rect[OC_MAX_TARGET_RECTS][4];
@@ -52,8 +52,9 @@ struct KeyDev {
 // step that follows it.  Values of the ring's type T are held as doubles (exact for float).
 struct KeyStep {
     const void* slot;           // the slot's data, or NULL: no ring / the step lies beyond the horizon
-    const uint8_t* flags;       // its tile flags, or NULL: every stage tile holds data
+    const int32_t* first;       // per stage tile the first slot that holds data for it, or NULL: every tile does
     double h[4], lim_s, u;
+    int32_t slot_index, pad;
 };
 
 
@@ -68,8 +69,15 @@ struct GcfmParams {
     int32_t ncx, ncy, horder;
     double mu, lim;     // hjb mu and the clip level lim (optimals.py:95): `vels` evaluated from the interpolant ring
     uint32_t fix;       // OC_FIX_* bits (oc_set_fix_flags); 0 = the reference's behaviour
-    uint32_t diag;      // diagnostic builds of k_forces (oc_set_tuning "diag"): 1 = no phase 2, 2 = no prep work, 4 = no compaction either
+    uint32_t diag;      // OC_DIAG_BUILD only (liboc_hip_diag.so, `make diag`): cuts parts out of k_forces to time the rest --
+                        // 1 = no phase 2, 2 = no prep work, 4 = no compaction either, 8 = no lookups; the results are WRONG
 };
+// The release library has no diagnostic cuts: the tests compile to constants and the hot kernel carries no branch for them.
+#ifdef OC_DIAG_BUILD
+#define OC_DIAG(P, bit) (((P).diag & (bit)) != 0u)
+#else
+#define OC_DIAG(P, bit) false
+#endif
 
 #define NB_MAX 63
 // ctrl words
@@ -676,7 +684,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
             // tile pairs do not fit the list: rounds of 32 j each (64 agents x 16 entries = PAIR_LIST_CAP always fit)
             // (whether the rounds are needed is known from the first pass's own prefix sum: no separate reduction)
             int nround = 1;
-            if (P.diag & 4u) nround = 0;
+            if (OC_DIAG(P, 4u)) nround = 0;
             for (int rd = 0; rd < nround; ++rd) {
                 uint32_t m[NW];
 #pragma unroll
@@ -726,7 +734,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 // the chunk's sums are float64: every pair's float32 force is added exactly, so the result does not
                 // depend on how the launch shape (pair_split, chunk boundaries) groups the pairs
                 double sfx = 0.0, sfy = 0.0;
-                for (int tt = e_beg; tt < ((P.diag & 1u) ? e_beg : e_end); ++tt) {
+                for (int tt = e_beg; tt < (OC_DIAG(P, 1u) ? e_beg : e_end); ++tt) {
                     const uint32_t e = lst[tt];
                     const int il = e >> 16, jA = e & 127, jB = (e >> 7) & 127;
                     const double2 pbA = L.l_pos[w][jA], pbB = L.l_pos[w][jB];
@@ -1064,7 +1072,8 @@ __device__ __forceinline__ double2 field_fetch(const KeyDev& kd, int step, int i
 template <typename T>
 struct RingCtx {
     const T* slot;              // the slot's data
-    const uint8_t* flags;       // its tile flags, or NULL (every tile holds data)
+    const int32_t* first;       // tile t is trivial in this slot <=> slot_index < first[t]; NULL: every tile holds data
+    int slot_index;
     T h1, h2, h3, h4, lim_s, u;
     T lim, mu, inv2dx, inv2dy;
     int rows, row0, Nx, tnbx;
@@ -1074,7 +1083,8 @@ template <typename T>
 __device__ __forceinline__ RingCtx<T> ring_open(const GcfmParams& P, const KeyDev& kd, const KeyStep& ks) {
     RingCtx<T> c;
     c.slot = (const T*)ks.slot;
-    c.flags = ks.flags;
+    c.first = ks.first;
+    c.slot_index = ks.slot_index;
     c.h1 = (T)ks.h[0]; c.h2 = (T)ks.h[1]; c.h3 = (T)ks.h[2]; c.h4 = (T)ks.h[3];
     c.lim_s = (T)ks.lim_s;
     c.u = (T)ks.u;
@@ -1095,14 +1105,16 @@ __device__ __forceinline__ void ring_step_of(const KeyDev& kd, int step, KeyStep
     const OcRingSlice<T> sl = ((const OcRingSlice<T>*)kd.ring_slices)[step];
     const OcRingSlot<T> rs = ((const OcRingSlot<T>*)kd.ring_slots)[sl.slot];
     out.slot = (const T*)kd.ring_data + (size_t)sl.slot * (size_t)kd.ring_slot_elems;
-    out.flags = rs.dense ? nullptr : kd.ring_flags + (size_t)sl.slot * kd.ring_ntile;
+    out.first = rs.dense ? nullptr : kd.ring_first;
+    out.slot_index = sl.slot;
     for (int q = 0; q < 4; ++q) out.h[q] = (double)sl.h[q];
     out.lim_s = (double)rs.lim_s;
     out.u = (double)rs.u;
 }
 __device__ __forceinline__ void ring_step_prepare(const KeyDev& kd, int step, KeyStep& out) {
     out.slot = nullptr;
-    out.flags = nullptr;
+    out.first = nullptr;
+    out.slot_index = 0;
     if (kd.ring_data == nullptr || step < 0 || step >= kd.nt_opt - 1 || step >= kd.nslice_alloc) return;
     if (kd.ring_state_dtype == OC_F32) ring_step_of<float>(kd, step, out);
     else ring_step_of<double>(kd, step, out);
@@ -1119,7 +1131,7 @@ __device__ __forceinline__ T ring_phi(const RingCtx<T>& c, int r, int cc) {
     // so that the five cells' flags and values of a lookup are all in flight together: one level of latency)
     const T* b = c.slot + ((size_t)r * c.Nx + cc >> 2) * (4 * OC_RING_VALS) + (cc & 3);
     const T y = b[0], q0 = b[4], q1 = b[8], q2 = b[12], q3 = b[16];
-    const bool triv = c.flags != nullptr && c.flags[(r / OC_RING_STY) * c.tnbx + cc / OC_RING_STX] != 0;
+    const bool triv = c.first != nullptr && c.slot_index < c.first[(r / OC_RING_STY) * c.tnbx + cc / OC_RING_STX];
     T ph = y + fma_t(q3, c.h4, fma_t(q2, c.h3, fma_t(q1, c.h2, q0 * c.h1)));
     ph = triv ? c.u : ph;               // (u + h (0 x + 0 x^2 + ...) = u)
     return (ph > c.lim_s) ? ph : ((ph < c.lim_s) ? c.lim_s : (T)0);
@@ -1161,11 +1173,12 @@ __device__ __forceinline__ double2 ring_fetch(const GcfmParams& P, const KeyDev&
     // tile, so at most the four tiles of its corners.  If all of them were trivial in the slice's step, phi is one constant
     // on the whole box: every difference is zero and so is the direction (what k_out writes there) -- four flag bytes
     // instead of fifty values.  At 2048 x 2048 that is ~90 % of the cells at any time of an m = 0 solve.
-    if (inner && c.flags != nullptr) {
+    if (inner && c.first != nullptr) {
         const int ta = ((r0 - 1) / OC_RING_STY) * c.tnbx, tb = ((r1 + 1) / OC_RING_STY) * c.tnbx;
         const int ua = (c0 - 1) / OC_RING_STX, ub = (c1 + 1) / OC_RING_STX;
-        const uint8_t f0 = c.flags[ta + ua], f1 = c.flags[ta + ub], f2 = c.flags[tb + ua], f3 = c.flags[tb + ub];
-        if (f0 != 0 && f1 != 0 && f2 != 0 && f3 != 0) return make_double2(0.0, 0.0);
+        const int32_t f0 = c.first[ta + ua], f1 = c.first[ta + ub], f2 = c.first[tb + ua], f3 = c.first[tb + ub];
+        const int si = c.slot_index;
+        if (si < f0 && si < f1 && si < f2 && si < f3) return make_double2(0.0, 0.0);
     }
     if (inner && r1 == r0 + 1 && c1 == c0 + 1) {
         // the usual case, the diagonal pair (r0, c0), (r0 + 1, c0 + 1) (quirk Q7): the two crosses share two cells
@@ -1382,9 +1395,9 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
         __builtin_amdgcn_s_setprio(3);
         for (int t = blockIdx.x * 4 + w; t < S.ntiles; t += nprep * 4) {
             const bool mine = t >= sh.lo && t < sh.hi;
-            if ((mine || sh.lookup_all) && !(P.diag & 2u))
+            if ((mine || sh.lookup_all) && !OC_DIAG(P, 2u))
                 prep_tile(P, S, C, keys, ksteps, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8], mine,
-                          sh.prep_lookup != 0 && (mine || sh.lookup_all) && !(P.diag & 8u));
+                          sh.prep_lookup != 0 && (mine || sh.lookup_all) && !OC_DIAG(P, 8u));
         }
         return;
     }
@@ -1404,7 +1417,7 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
     // looked-up cell), one lane per agent, by the tile's last wavefront once its pair share is done.  In the prep blocks the
     // lookup sat on the launch's critical chain -- the prep wavefronts' dependent loads ARE the launch's length -- and cost
     // 11 us per launch with slices, 27 us through the ring; here its latency hides behind the other blocks' arithmetic.
-    if (live && sub == NS - 1 && sh.prep_lookup == 0 && !(P.diag & 8u)) {
+    if (live && sub == NS - 1 && sh.prep_lookup == 0 && !OC_DIAG(P, 8u)) {
         const int k = it * 64 + lane;
         const int i = C.pidx[k];
         double2 ds = make_double2(0.0, 0.0);
@@ -1857,7 +1870,7 @@ int upload_keys(oc_handle* h, hipStream_t s) {
             d.ring_data = f.ring_data;
             d.ring_slots = m + oc_ring_slots_off();
             d.ring_slices = m + oc_ring_slices_off(ts, f.ring_slots);
-            d.ring_flags = (const uint8_t*)(m + oc_ring_flags_off(ts, f.ring_slots, f.nslice_alloc));
+            d.ring_first = (const int32_t*)(m + oc_ring_flags_off(ts, f.ring_slots, f.nslice_alloc));
             d.ring_slot_elems = (int64_t)OC_RING_VALS * rows * h->cfg.Nx;
             d.ring_state_dtype = f.ring_state_dtype;
             d.ring_ntile = oc_ring_ntile(rows, h->cfg.Nx);

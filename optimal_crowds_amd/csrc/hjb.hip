@@ -367,7 +367,7 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
                                              int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox,
                                              int active_set, OcRingSlot<T>* __restrict__ rslots,
                                              OcRingSlice<T>* __restrict__ rslices, int ring_cap, CtlLds<T>& L,
-                                             bool store_out = true) {
+                                             bool store_out = true, bool ctl_loaded = false) {
     HjbCtl<T>& c = L.c;
     double (&ls)[4] = L.ls, (&lm)[4] = L.lm, (&la)[4] = L.la;
     int& all_active = L.all_active;
@@ -376,7 +376,7 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
     if (threadIdx.x == 0) all_active = 0;
     constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
     static_assert(sizeof(HjbCtl<T>) % 4 == 0, "controller block must be a whole number of words");
-    if (worker) {
+    if (worker && !ctl_loaded) {        // (the fused tail finds it in LDS already: copied when the block started)
         const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl_in);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&c);
         for (int i = threadIdx.x; i < NW32; i += nth) dst[i] = src[i];
@@ -504,7 +504,7 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
         }
         const int tk = ++c.ticks;
         if (tk - 1 < log_cap) att_log[tk - 1] = logw;
-        mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
+        if (mailbox) mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
     }
     __syncthreads();
     // what does not depend on anything but the decision's scalars is dealt to the lanes: the next attempt's 43
@@ -853,7 +853,7 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     // cells, oc_internal.h) instead of Q1 .. Q3 to KM -- an attempt that is rejected is overwritten by the next one
     T* ring;
     size_t ring_slot_elems;         // 5 * rows * Nx
-    uint8_t* ring_flags;            // [cap][ntile]: 1 = the tile was trivial in the slot's attempt (nothing stored for it)
+    int32_t* ring_first;            // [ntile]: the first slot in which the tile was computed (OC_RING_NEVER: not yet)
     int32_t ring_cap, ring_ntile;
     // fused tail (FUSED kernels): the LAST block of the launch to finish is the attempt's step controller and list builder
     // -- one launch per attempt instead of three.  Every participating block stores its words for the controller `sc1`,
@@ -902,6 +902,12 @@ __device__ __forceinline__ bool is_pow2(double v) {
     return (b & 0x000FFFFFFFFFFFFFull) == 0ull && e != 0ull && e != 0x7FFull;
 }
 
+template <typename T, bool SC1>
+__device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __restrict__ flags_cur,
+                                                int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
+                                                double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* sflag, int nbytes,
+                                                volatile double* mailbox, bool flags_ready);
+
 // ---- lean multi-stage kernel: four cells of a row per thread, no per-cell index arithmetic ------------------------
 // (Round 1's multi-stage kernels dealt the region's cells to the threads round-robin; that cost ~100 instructions of
 // index and predicate arithmetic per cell and stage -- 450 SIMD cycles per wavefront-cell-stage, the launch time scaled
@@ -922,6 +928,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     static_assert(!RING || (NQ == 6 && FINAL), "the ring is written by the one-launch attempt");
     static_assert(!FUSED || RING, "the fused tail belongs to the ring path");
     __shared__ int s_last;
+    __shared__ CtlLds<T> s_tail;        // FUSED: the controller's LDS block (unreferenced, hence absent, otherwise)
     constexpr int HX = 4 * ((NQ + 3) / 4), HY = NQ, RW = 4 * RWV, NT = RWV * RH;
     constexpr int TX = RW - 2 * HX, TY = RH - 2 * HY, LS = RW + 8;
     constexpr int NK = S0 + NQ;                     // stage derivatives alive at the end of the launch
@@ -960,6 +967,14 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *p = v;
     };
+    // FUSED: every participating block copies the controller block into LDS as it starts (1 KB out of the L2, nobody waits
+    // for it): the block that turns out to be the last one has it at hand instead of behind another round trip
+    if (FUSED && threadIdx.x < 256) {
+        constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tail.c);
+        for (int i = threadIdx.x; i < NW32; i += 256) dst[i] = src[i];
+    }
     auto fused_tail = [&]() {                           // called by every thread of a participating block, at its end
         if (threadIdx.x == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this block's sc1 words have left
@@ -969,25 +984,46 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         __syncthreads();
         if (!s_last) return;
         if (threadIdx.x == 0) __hip_atomic_store(A.tail_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the tile buffers are free now: the controller's LDS block, then the builder's flag bytes
-        CtlLds<T>& L = *reinterpret_cast<CtlLds<T>*>(&buf[0][0][0]);
-        static_assert(sizeof(CtlLds<T>) <= 4096 && sizeof(buf) >= 4096 + 12000, "the tail's scratch fits the tile buffers");
-        control_body<T, true>(ctl, A.ctl_out, A.partial, nb, A.t_steps, A.t_cap, A.att_log, A.log_cap, A.mailbox, A.active_set,
-                              A.rslots, A.rslices, A.ring_cap, L, false);
+        // Everything the tail reads of the other blocks goes out in ONE batch: the tiles' flags for the list builder here,
+        // the error partials inside control_body right behind them -- two dependent round trips to the L2 otherwise.
+        // (the flags by wavefronts 4 .. 7, idle otherwise, straight into the builder's LDS bytes, while wavefronts 0 .. 3 run
+        // the controller: its error partials and the flags are in flight together)
+        uint8_t* const sflag = reinterpret_cast<uint8_t*>(&buf[0][0][0]);
+        static_assert(NT >= 512, "the tail's helper wavefronts");
+        const bool pre_ok = A.active_set != 0 && nb <= (int)sizeof(buf);
+        if (pre_ok && threadIdx.x >= 256 && threadIdx.x < 512) {
+            for (int t0 = (int)threadIdx.x - 256; t0 < nb; t0 += 8 * 256) {
+                int32_t f[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) f[u] = (t0 + u * 256 < nb) ? ld_flag<true>(A.flags_cur + t0 + u * 256) : 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (t0 + u * 256 < nb) sflag[t0 + u * 256] = f[u] != 0 ? 1 : 0;
+            }
+        }
+        control_body<T, true>(ctl, A.ctl_out, A.partial, nb, A.t_steps, A.t_cap, A.att_log, A.log_cap, nullptr, A.active_set,
+                              A.rslots, A.rslices, A.ring_cap, s_tail, false, true);
+        // (the tile buffers are free: the builder's flag bytes)
+        static_assert(sizeof(buf) >= 12000, "the builder's flag bytes fit the tile buffers");
         if (A.active_set)
-            build_work_list<T, true>(&L.c, A.flags_cur, A.flags_next, A.work_next, A.partial, nbx, nby,
-                                     reinterpret_cast<uint8_t*>(&buf[0][0][0]) + 4096, (int)sizeof(buf) - 4096, A.ring_flags,
-                                     A.ring_cap, A.mailbox);
+            build_work_list<T, true>(&s_tail.c, A.flags_cur, A.flags_next, A.work_next, A.partial, nbx, nby, sflag,
+                                     (int)sizeof(buf), nullptr, pre_ok);
         __syncthreads();
         if (threadIdx.x < 256) {
             constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(&L.c);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_tail.c);
             uint32_t* dst = reinterpret_cast<uint32_t*>(A.ctl_out);
             for (int i = threadIdx.x; i < NW32; i += 256) dst[i] = src[i];
-            if (L.c.done) {             // (both blocks: see control_body)
+            if (s_tail.c.done) {        // (both blocks: see control_body)
                 uint32_t* dst2 = reinterpret_cast<uint32_t*>(const_cast<HjbCtl<T>*>(ctl));
                 for (int i = threadIdx.x; i < NW32; i += 256) dst2[i] = src[i];
             }
+        }
+        // the host's mailbox last (pinned host memory: posted writes over PCIe, nothing of the tail waits behind them)
+        if (threadIdx.x == 0) {
+            const HjbCtl<T>& c = s_tail.c;
+            A.mailbox[1] = A.active_set ? (c.dense_mode ? (double)nb : (double)c.work_count) : (double)nb;
+            A.mailbox[0] = (double)c.ticks + (c.done ? 4294967296.0 : 0.0);
         }
     };
     if (sparse && A.work != nullptr) {              // active set: entry `logical` of the work list, or nothing to do
@@ -1068,7 +1104,10 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         return r;
     };
     if (track) {
-        if (need_test) trivial = __syncthreads_and((cell_trivial && is_pow2(u_raw)) ? 1 : 0) != 0;
+        // (u_raw == the controller's far-field value: every trivial tile then provably holds ONE and the same power of two --
+        // what k_control's ymax for the tiles off the list and the ring's per-slot `u` assume; a tile that is constant at
+        // any other value is simply computed)
+        if (need_test) trivial = __syncthreads_and((cell_trivial && is_pow2(u_raw) && u_raw == ctl->u_bg) ? 1 : 0) != 0;
         if (trivial) {
             const T un = u_raw * in_scale;
             const bool can_skip = own_prev && (ctl->rejected != 0 || (in_scale == (T)1 && ctl->out_in_scale == (T)1));
@@ -1092,14 +1131,15 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                 st_part(A.partial + 2 * logical, 0.0);
                 st_part(A.partial + 2 * logical + 1, (r_hi > A.row_lo && r_lo < A.row_hi) ? (double)fabs(un) : 0.0);
                 st_flag(A.flags_cur + logical, 1);
-                if (ring_ok) A.ring_flags[(size_t)rslot * A.ring_ntile + logical] = 1;
             }
             if (FUSED) fused_tail();
             return;
         }
         if (threadIdx.x == 0) {
             st_flag(A.flags_cur + logical, 0);
-            if (ring_ok) A.ring_flags[(size_t)rslot * A.ring_ntile + logical] = 0;
+            // (ring: the tile holds data from this slot on -- it was tested just now, so it was trivial until here; a tile
+            // that skips the test has been computed before and is on record)
+            if (RING && need_test && rslot < A.ring_first[logical]) A.ring_first[logical] = rslot;
         }
     }
     T* const slot0 = &buf[0][ry + 1][4 + 4 * vx];
@@ -1333,17 +1373,18 @@ __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* 
 // was trivial in the attempt just run, with all 8 neighbours, is trivial in the next one whatever the decision was; if the
 // target buffers hold the trivial values already (the attempt was rejected, or no rescale lies between the buffers) it needs
 // no block at all: its flag and error share are set here.  sflag: the block's LDS (nbytes of it).
-template <typename T, bool SC1 = false>
+template <typename T, bool SC1>
 __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __restrict__ flags_cur,
                                                 int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
                                                 double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* sflag, int nbytes,
-                                                uint8_t* __restrict__ ring_flags = nullptr, int ring_cap = 0,
-                                                volatile double* mailbox = nullptr) {
-    // Called by every thread of the block (barriers inside); threads 0 .. 255 do the work.  SC1: flags_cur was written by
+                                                volatile double* mailbox, bool flags_ready) {
+    // Called by every thread of the block (barriers inside), and every thread works: the builder is a chain of dependent
+    // integer and LDS instructions per tile, so its length is the tiles per THREAD (8 per thread with 256 threads at
+    // 2048 x 2048 took 8 us of the fused tail; 2 per thread with the stage block's 1024).  SC1: flags_cur was written by
     // other blocks of this very launch (fused tail) -- sc1 loads, see ld_part.
-    __shared__ int32_t wsum[4];
-    const int todo = ctl->list_todo, nth = 256;
-    const bool worker = threadIdx.x < 256;
+    // flags_ready: sflag[] already holds the tiles' flags (the fused tail's idle wavefronts fetched them meanwhile)
+    __shared__ int32_t wsum[16];
+    const int todo = ctl->list_todo, nth = (int)blockDim.x;
     const int ntile = tnbx * tnby;
     if (todo == 0) return;
     if (todo == 2) {                                // every tile is active and stays so: no flags, no list from now on
@@ -1353,16 +1394,13 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
         }
         return;
     }
-    // (interpolant ring: a tile left off the list is trivial in the next attempt -- flagged in that attempt's slot here,
-    // since no block will look at it)
-    uint8_t* const rf = (ring_flags != nullptr && ctl->n_accept < ring_cap) ? ring_flags + (size_t)ctl->n_accept * ntile : nullptr;
     const bool skip_ok = (ctl->rejected != 0 || (ctl->in_scale == (T)1 && ctl->out_in_scale == (T)1)) && ntile <= nbytes;
     // every thread owns a contiguous run of tiles (an ordered list keeps neighbouring tiles in neighbouring blocks)
     const int per_thr = (ntile + nth - 1) / nth;
-    const int t_lo = worker ? min((int)threadIdx.x * per_thr, ntile) : ntile, t_hi = min(t_lo + per_thr, ntile);
+    const int t_lo = min((int)threadIdx.x * per_thr, ntile), t_hi = min(t_lo + per_thr, ntile);
     uint32_t listed = 0xFFFFFFFFu, listed_hi = 0xFFFFFFFFu;     // bit q: tile t_lo + q goes on the list (per_thr <= 64)
     if (skip_ok) {
-        if (worker) {
+        if (!flags_ready) {
             // (eight independent loads in flight per thread: as sc1 loads in a one-load-per-trip loop each trip waited for
             // its own round trip to the L2)
             for (int t0 = threadIdx.x; t0 < ntile; t0 += 8 * nth) {
@@ -1404,44 +1442,56 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
     listed_hi &= m_hi;
     const int mine = __popc(listed) + __popc(listed_hi);
     int incl = mine;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (nth + 63) >> 6;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(incl, o, 64);
         if (lane >= o) incl += v;
     }
-    if (lane == 63 && worker) wsum[wv] = incl;
+    if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    int off = incl - mine;
-    for (int q = 0; q < wv && q < 4; ++q) off += wsum[q];
+    int off = incl - mine, total = 0;
+    for (int q = 0; q < nwv; ++q) {
+        off += q < wv ? wsum[q] : 0;
+        total += wsum[q];
+    }
+    // A tile off the list needs its flag (and a zero error share) in the NEXT attempt's buffers.  The active set only grows
+    // and every change of scale lists every tile twice, so from the third build of a solve on both flag buffers and the
+    // partials already hold exactly that for every tile that can be off the list: only the solve's first builds write them.
+    const bool write_unlisted = ctl->n_attempt <= 2;
     for (int t = t_lo; t < t_hi; ++t) {
         const int q = t - t_lo;
         const bool on = q < 32 ? ((listed >> q) & 1u) != 0 : ((listed_hi >> (q - 32)) & 1u) != 0;
         if (on) {
             work[off++] = t;
-        } else {
+        } else if (write_unlisted) {
             flags_next[t] = 1;
             parts_rw[2 * t] = 0.0;
             parts_rw[2 * t + 1] = 0.0;
-            if (rf) rf[t] = 1;
         }
     }
     if (threadIdx.x == 0) {
-        const int wc = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        ctl->work_count = wc;
-        if (mailbox) mailbox[1] = (double)wc;        // (the host picks the launch sequence by it: fused tail or not)
+        ctl->work_count = total;
+        if (mailbox) mailbox[1] = (double)total;     // (the host picks the launch sequence by it: fused tail or not)
     }
+}
+
+template <typename T>
+__device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __restrict__ flags_cur,
+                                                int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
+                                                double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* sflag, int nbytes,
+                                                volatile double* mailbox = nullptr) {
+    build_work_list<T, false>(ctl, flags_cur, flags_next, work, parts_rw, tnbx, tnby, sflag, nbytes, mailbox, false);
 }
 
 // With the interpolant ring no k_out launch follows an attempt: the list builder is a launch of its own (one block).
 template <typename T>
 __global__ void __launch_bounds__(256) k_list(HjbCtl<T>* ctl, const int32_t* __restrict__ flags_cur,
                                               int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
-                                              double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* ring_flags,
-                                              int ring_cap, volatile double* mailbox) {
+                                              double* __restrict__ parts_rw, int tnbx, int tnby,
+                                              volatile double* mailbox) {
     __shared__ uint8_t sflag[16384];
-    build_work_list<T>(ctl, flags_cur, flags_next, work, parts_rw, tnbx, tnby, sflag, (int)sizeof(sflag), ring_flags, ring_cap,
-                       mailbox);
+    build_work_list<T>(ctl, flags_cur, flags_next, work, parts_rw, tnbx, tnby, sflag, (int)sizeof(sflag), mailbox);
 }
 
 // ---- slices from the ring (oc_hjb_ring_slices; the audit output phi_keep of a ring solve) ---------------------------
@@ -1480,10 +1530,10 @@ __global__ void k_ring_ctl(const OcRingHead* __restrict__ rh, const OcRingSlot<T
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_ring_fill(const HjbCtl<T>* __restrict__ ctl, T* __restrict__ slot_data,
-                                                   const uint8_t* __restrict__ slot_flags, int Ny, int Nx) {
+                                                   const int32_t* __restrict__ first, int slot, int Ny, int Nx) {
     if (!ctl->accepted || ctl->work_count != 0) return;
     const int t = blockIdx.x;
-    if (slot_flags[t] == 0) return;
+    if (slot >= first[t]) return;                   // the tile holds data in this slot
     const int tnbx = (Nx + OC_RING_STX - 1) / OC_RING_STX;
     const int r0 = (t / tnbx) * OC_RING_STY, c0 = (t % tnbx) * OC_RING_STX;
     const T u = ctl->u_bg;
@@ -1717,7 +1767,7 @@ struct RingView {
     OcRingHead* head;
     OcRingSlot<T>* slots;
     OcRingSlice<T>* slices;
-    uint8_t* flags;
+    int32_t* first;             // [ntile]
     size_t slot_elems;
     int cap, nslice, rows, ntile;
 };
@@ -1729,7 +1779,7 @@ RingView<T> ring_view(const oc_hjb_ring* r, int Nx) {
     v.head = (OcRingHead*)m;
     v.slots = (OcRingSlot<T>*)(m + oc_ring_slots_off());
     v.slices = (OcRingSlice<T>*)(m + oc_ring_slices_off(sizeof(T), r->slots));
-    v.flags = (uint8_t*)(m + oc_ring_flags_off(sizeof(T), r->slots, r->nslice));
+    v.first = (int32_t*)(m + oc_ring_flags_off(sizeof(T), r->slots, r->nslice));
     v.slot_elems = (size_t)OC_RING_VALS * r->rows * Nx;
     v.cap = r->slots;
     v.nslice = r->nslice;
@@ -1769,8 +1819,8 @@ int ring_emit(oc_handle* h, const RingView<T>& R, int n_slots, int s_lo, int s_h
         T* sd = R.data + (size_t)slot * R.slot_elems;
         hipLaunchKernelGGL(k_ring_ctl<T>, dim3(1), dim3(1), 0, s, (const OcRingHead*)R.head, (const OcRingSlot<T>*)R.slots, slot,
                            s_lo, s_hi, ctl);
-        hipLaunchKernelGGL(k_ring_fill<T>, dim3(R.ntile), dim3(256), 0, s, (const HjbCtl<T>*)ctl, sd,
-                           (const uint8_t*)(R.flags + (size_t)slot * R.ntile), Ny, Nx);
+        hipLaunchKernelGGL(k_ring_fill<T>, dim3(R.ntile), dim3(256), 0, s, (const HjbCtl<T>*)ctl, sd, (const int32_t*)R.first,
+                           slot, Ny, Nx);
         OA.ring_slot = sd;
         launch_out<T, TO, true, true>(h->out_tile, Nx, Ny, s, OA);
     }
@@ -2098,7 +2148,9 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         R = ring_view<T>(ring, S.Nx);
         SA.ring = R.data;
         SA.ring_slot_elems = R.slot_elems;
-        SA.ring_flags = R.flags;
+        SA.ring_first = R.first;
+        // (nothing has been computed yet: the stage launches record each tile's first slot)
+        OC_HIP_CHECK(hipMemsetAsync(R.first, 0x7F, sizeof(int32_t) * (size_t)R.ntile, s));
         SA.ring_cap = R.cap;
         SA.ring_ntile = R.ntile;
     }
@@ -2256,8 +2308,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             launch_out<T, TO, true>(h->out_tile, S.Nx, S.Ny, s, OA);
         } else if (active_set && !fused) {  // no slice writer beside which the list could be built: its own (one-block) launch
             hipLaunchKernelGGL(k_list<T>, dim3(1), dim3(256), 0, s, ctl_nxt, (const int32_t*)OA.flags, OA.flags_next, OA.work,
-                               OA.parts_rw, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty, R.flags, R.cap,
-                               (volatile double*)mb_dev);
+                               OA.parts_rw, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty, (volatile double*)mb_dev);
         }
         if (prof) event();
         ++enq;
@@ -2277,6 +2328,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             OC_HIP_CHECK(hipStreamSynchronize(s));
         } else {
             // let the device catch up to within LAG attempts of what is enqueued (or finish)
+            double w_seen = -1.0;
+            auto t_seen = std::chrono::steady_clock::now();
             for (long spin = 0;; ++spin) {
                 const double w = mb[0];
                 if (w >= 4294967296.0 || w >= (double)(enq - LAG)) break;
@@ -2285,6 +2338,18 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                     if (q == hipSuccess) break;
                     if (q != hipErrorNotReady) {
                         oc_set_error("hjb_solve: %s", hipGetErrorString(q));
+                        return OC_ERR_HIP;
+                    }
+                    // no tick for 10 s while the stream is busy: a kernel hangs.  One blocking wait (it returns when the
+                    // runtime gives the stream up), an error, no retry.
+                    const auto now = std::chrono::steady_clock::now();
+                    if (w != w_seen) {
+                        w_seen = w;
+                        t_seen = now;
+                    } else if (std::chrono::duration<double>(now - t_seen).count() > 10.0) {
+                        const hipError_t e = hipStreamSynchronize(s);
+                        oc_set_error("hjb_solve: the controller did not advance for 10 s at attempt %d of %d enqueued (%s)",
+                                     (int)w, enq, hipGetErrorString(e));
                         return OC_ERR_HIP;
                     }
                 }

@@ -277,7 +277,13 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
         OC_REQUIRE(value >= 1 && value <= 4096, "resort_every out of range");
         h->resort_every = value;
     } else if (!strcmp(name, "diag")) {
-        h->diag = value;
+#ifdef OC_DIAG_BUILD
+        OC_REQUIRE(value >= 0 && value <= 15, "diag out of range");
+        h->diag = value;        // liboc_hip_diag.so only: parts of k_forces cut out to time the rest -- results are WRONG
+#else
+        oc_set_error("oc_set_tuning: 'diag' exists only in the diagnostic build (make -C csrc diag; OC_HIP_LIB=.../liboc_hip_diag.so)");
+        return OC_ERR_ARG;
+#endif
     } else if (!strcmp(name, "out_tile")) {
         OC_REQUIRE(value >= -1 && value <= 2, "out_tile out of range");
         h->out_tile = value;

@@ -38,8 +38,10 @@ void oc_set_error(const char* fmt, ...);
 //   data   per slot (= accepted step) rows x Nx/4 blocks of 20 values: y[4], K0[4], Q1[4], Q2[4], Q3[4] of four
 //          consecutive cells of a row (one lookup cell's five values share one or two cache lines; the stage kernel
 //          stores five natural 16-byte vectors per thread).  Only the stage tiles that were COMPUTED in the accepted
-//          attempt are written (exact active set); the others are flagged and read as (u, 0, 0, 0, 0).
-//   meta   OcRingHead | OcRingSlot<T> x slots | OcRingSlice<T> x nslice | uint8 flags [slots][stage tiles]
+//          attempt are written (exact active set); the others read as (u, 0, 0, 0, 0).  The active set only grows during
+//          a solve (a tile that was computed once is computed in every later attempt), so ONE word per tile says it all:
+//          first[t] = the first slot in which tile t was computed (INT_MAX-like: never) -- trivial in slot s <=> s < first[t].
+//   meta   OcRingHead | OcRingSlot<T> x slots | OcRingSlice<T> x nslice | int32 first[stage tiles]
 #define OC_RING_VALS 5
 #define OC_RING_STX 112          // stage tile of the product path (k_stageV<T, 6, 1, true, 32, 32>): 112 x 20 cells
 #define OC_RING_STY 20
@@ -54,7 +56,7 @@ template <typename T>
 struct OcRingSlot {
     double out_t, out_hh, out_unscale;      // the step: start time, signed length, 2^expo of its scale
     int32_t k_lo, k_hi;                     // t_eval indices [k_lo, k_hi) lie in the step
-    int32_t dense, pad;                     // 1: every stage tile of the slot holds data (no flags)
+    int32_t dense, pad;                     // 1: every stage tile of the slot holds data (first[] is not consulted)
     T lim_s, u;                             // the clip level in the slot's scale; the far field's constant value of y
 };
 template <typename T>
@@ -62,6 +64,7 @@ struct OcRingSlice {
     int32_t slot, pad;
     T h[4];                                 // h x, h x^2, h x^3, h x^4 of the slice's t_eval point in its step
 };
+#define OC_RING_NEVER 0x7F7F7F7F            // first[t] of a tile that was never computed (memset 0x7F)
 inline size_t oc_ring_align(size_t v) { return (v + 255) & ~(size_t)255; }
 inline int oc_ring_ntile(int rows, int Nx) {
     return ((Nx + OC_RING_STX - 1) / OC_RING_STX) * ((rows + OC_RING_STY - 1) / OC_RING_STY);
@@ -75,7 +78,7 @@ inline size_t oc_ring_flags_off(size_t tsize, int slots, int nslice) {
            oc_ring_align((tsize == 4 ? sizeof(OcRingSlice<float>) : sizeof(OcRingSlice<double>)) * (size_t)std::max(nslice, 1));
 }
 inline size_t oc_ring_meta_size(size_t tsize, int slots, int nslice, int rows, int Nx) {
-    return oc_ring_flags_off(tsize, slots, nslice) + oc_ring_align((size_t)slots * oc_ring_ntile(rows, Nx));
+    return oc_ring_flags_off(tsize, slots, nslice) + oc_ring_align(sizeof(int32_t) * (size_t)oc_ring_ntile(rows, Nx));
 }
 
 struct oc_field_desc {

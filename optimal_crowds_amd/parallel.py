@@ -80,8 +80,9 @@ def row_blocks(Ny, world):
 # ---------------------------------------------------------------------------------------------- row-block HJB solve
 class RowShard:
     """One rank's row block of the (Ny, Nx) grid plus `halo` rows of each neighbour (oc_hip.h: oc_hjb_shard).
-    halo >= 7 (one RK step applies the stencil 6 times, and the interpolant's coefficients are formed from the LOCAL K6 one
-    row beyond the block); the direction field is exact on owned rows +- (halo - 7)."""
+    halo >= 7 for the solve alone (one RK step applies the stencil 6 times, and the interpolant's coefficients are formed
+    from the LOCAL K6 one row beyond the block); the direction field is exact on owned rows +- (halo - 7) = field_margin,
+    and a sharded LOOKUP needs field_margin >= 1, i.e. halo >= 8 (Engine.enable_sharding, dist_sharding enforce it)."""
 
     def __init__(self, Ny, rank, world, halo=8):
         r0, r1 = row_blocks(Ny, world)[rank]
@@ -342,18 +343,37 @@ class ThreadStepComm(_StepComm):
 
 
 # ---------------------------------------------------------------------------------------------- one call for a façade
+_SUBGROUPS = {}         # rank tuple -> process group: a simulation built twice in one process reuses its sub-groups
+
+
+def _subgroup(ranks):
+    """the process group of `ranks` (None: the whole world); created once per process and rank set, since communicators
+    are never freed behind a simulation's back (every rank must call this with the same rank sets in the same order)"""
+    ranks = tuple(ranks)
+    if len(ranks) <= 1 or len(ranks) >= dist.get_world_size():
+        return None
+    if ranks not in _SUBGROUPS:
+        _SUBGROUPS[ranks] = dist.new_group(list(ranks))
+    return _SUBGROUPS[ranks]
+
+
 def dist_sharding(halo=8, by_key=True):
     """`sharding=` argument of simulations.simulation for a torch.distributed job (one process per GPU): ONE simulation
     on all ranks.  HJB: keys first, then row blocks (key_row_plan; by_key=False: every key over all ranks) with `halo`
-    rows (>= 7), each key's collectives on its own sub-group (nccl = RCCL over xGMI, or gloo); agents replicated, one
-    all-reduce per step over the whole world.  Returns engine -> ({key: halo comm or None}, step comm)."""
+    rows -- at least 8 here: 7 for the solve itself (RowShard) and one more so that the floor field is exact on the row
+    beyond the block, which a lookup's second cell may read -- each key's collectives on its own sub-group (nccl = RCCL over
+    xGMI, or gloo); agents replicated, the step's exchange over the whole world (DistStepComm).
+    Returns engine -> ({key: halo comm or None}, step comm)."""
+    if halo < 8:
+        raise ValueError("sharded lookups need halo >= 8 (the field is exact halo - 7 rows beyond a block)")
+
     def make(eng):
         world, rank = dist.get_world_size(), dist.get_rank()
         plan = key_row_plan(eng.n_keys, world) if by_key else [tuple(range(world))] * eng.n_keys
         comms = {}
         for k, ranks in enumerate(plan):
-            # (every rank creates every group, member or not, in the same order: torch.distributed requires it)
-            grp = dist.new_group(list(ranks)) if 1 < len(ranks) < world else None
+            # (every rank asks for every group, member or not, in the same order: torch.distributed requires it)
+            grp = _subgroup(ranks) if len(ranks) > 1 else None
             if rank in ranks:
                 sh = RowShard(eng.Ny, ranks.index(rank), len(ranks), halo)
                 comms[k] = DistHaloComm(sh, eng.Nx, eng.tdtype, eng.device, group=grp, ranks=ranks)
@@ -366,8 +386,11 @@ def dist_sharding(halo=8, by_key=True):
 
 def thread_sharding(rank, tw_solve, tw_step, halo=8, plan=None):
     """The same for virtual ranks in threads of one process (tests): tw_step = ThreadWorld of all ranks (the step's
-    all-reduce); tw_solve = ThreadWorld of all ranks (every key in row blocks over all of them), or -- with `plan`
+    exchange); tw_solve = ThreadWorld of all ranks (every key in row blocks over all of them), or -- with `plan`
     (key_row_plan) -- a list with one ThreadWorld per key, sized to the key's rank group."""
+    if halo < 8:
+        raise ValueError("sharded lookups need halo >= 8 (the field is exact halo - 7 rows beyond a block)")
+
     def make(eng):
         if plan is None:
             sh = RowShard(eng.Ny, rank, tw_solve.world, halo)

@@ -1,3 +1,5 @@
+# needs the diagnostic build: make -C optimal_crowds_amd/csrc diag   (the release library rejects the "diag" knob)
+export OC_HIP_LIB=$PWD/optimal_crowds_amd/liboc_hip_diag.so
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null; mkdir -p gpurun_out
 for v in "ring:--field ring" "ringnolook:--field ring --tune diag=8" "slices:--field slices" "slicesnolook:--field slices --tune diag=8"; do
   name=${v%%:*}; args=${v#*:}

@@ -1,3 +1,5 @@
+# needs the diagnostic build: make -C optimal_crowds_amd/csrc diag   (the release library rejects the "diag" knob)
+export OC_HIP_LIB=$PWD/optimal_crowds_amd/liboc_hip_diag.so
 # where k_forces' instructions go: VALU / LDS counts and time with parts of the kernel cut out (results are wrong in these runs)
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 for d in 0 1 2 3 5 7; do
