@@ -80,7 +80,10 @@ def solve_round(sim):
     return stats
 
 
-def run_steps(sim, K, nt, timed_stats=None):
+def run_steps(sim, K, nt, timed_stats=None, update="synchronous", levels=None):
+    """update='sequential': the reference's own one-by-one order (simulations.py:271; oc_gcfm_step_sequential) -- a fresh
+    random permutation per step (drawn on the device), level-scheduled by the library; `levels` collects each step's depth"""
+    import torch
     eng = sim._engine
     done = 0
     while done < K:
@@ -96,7 +99,13 @@ def run_steps(sim, K, nt, timed_stats=None):
             st = [eng.solve(k, sim.T, round((sim.T - s * sim.dt) / sim.dt), m=m)[0] for k in range(len(sim._key_names))]
             if timed_stats is not None:
                 timed_stats.append(st)
-        eng.step(s, noise=None, seed=sim._seed + done // nt, sync=False)
+        if update == "sequential":
+            perm = torch.randperm(sim.N, device=eng.device, dtype=torch.int32)
+            out = eng.step_sequential(s, perm, noise=None, seed=sim._seed + done // nt)
+            if levels is not None:
+                levels.append(out[3])
+        else:
+            eng.step(s, noise=None, seed=sim._seed + done // nt, sync=False)
         done += 1
 
 
@@ -279,7 +288,7 @@ def pmc_step(workload):
     return d.get("k_forces") if d else None
 
 
-def measure(sim, args, nt, world, dist, red_dev, keep_state=False):
+def measure(sim, args, nt, world, dist, red_dev, keep_state=False, levels=None):
     """W warmup steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks."""
     import torch
     from optimal_crowds_amd import parallel
@@ -290,8 +299,9 @@ def measure(sim, args, nt, world, dist, red_dev, keep_state=False):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+    upd = getattr(args, "update", "synchronous")
     if W > 0:
-        run_steps(sim, W, nt)
+        run_steps(sim, W, nt, update=upd)
     barrier()
     eng.set_profiling(1 | 4)        # HJB kernels on every 8th attempt, GCFM kernels on every 16th step (events cost gaps)
     eng.reset_kernel_stats()
@@ -299,7 +309,7 @@ def measure(sim, args, nt, world, dist, red_dev, keep_state=False):
     state0 = eng.get_state() if keep_state else None        # the crowd the timed region starts from (CPU baseline's input)
     barrier()
     t0 = time.perf_counter()
-    run_steps(sim, K, nt, stats)
+    run_steps(sim, K, nt, stats, update=upd, levels=levels)
     barrier()
     elapsed = time.perf_counter() - t0
     return parallel.max_over_ranks(elapsed, device=red_dev), stats, state0
@@ -349,6 +359,10 @@ def main():
                     help="what an HJB solve leaves in HBM: ring = the accepted steps' interpolants, lookups evaluate the "
                          "direction from them (default, the product path); slices = every slice of vx_opt / vy_opt is written "
                          "like the reference does (optimals.py:200-204)")
+    ap.add_argument("--update", default="synchronous", choices=["synchronous", "sequential"],
+                    help="agent update order: synchronous (frozen snapshot, the fast path and the default) or sequential = the "
+                         "reference's one-by-one order in a fresh random permutation per step (simulations.py:271), "
+                         "level-scheduled on the device: what trajectory-level parity with the reference costs (single GPU)")
     ap.add_argument("--hjb-dtype", default="float32", choices=["float32", "mixed", "float64"],
                     help="HJB state: float32 (BASELINE's configs, default), mixed (float64 state, float32 field), float64")
     args = ap.parse_args()
@@ -411,7 +425,10 @@ def main():
     rows_split = sharded and any(len(p) > 1 for p in getattr(eng, "key_plan", []))
     active_set = (active_knob == 2 or (active_knob == 1 and n_stage_tiles >= 1024)) and n_stage_tiles <= 12000 and not rows_split
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    elapsed, stats, state0 = measure(sim, args, nt, world, dist, red_dev, keep_state=want_cpu)
+    if args.update == "sequential" and (world > 1 or sharded):
+        raise SystemExit("--update sequential is a single-GPU mode")
+    seq_levels = [] if args.update == "sequential" else None
+    elapsed, stats, state0 = measure(sim, args, nt, world, dist, red_dev, keep_state=want_cpu, levels=seq_levels)
 
     # ---- breakdown (untimed extras for the report)
     mine = [s for rnd in stats for s in rnd if s is not None]
@@ -512,6 +529,9 @@ def main():
                    + (", recompute=True" if sim.recompute else ""),
                    "parallelism": parallelism, "mode": "sharded" if sharded else ("ensemble" if world > 1 else "single"),
                    "noise": "device Philox", "agent_state": "f64", "pair_math": "f32",
+                   "update": ("sequential: the reference's one-by-one order in a fresh permutation per step, level-scheduled "
+                              "(mean %.1f levels per step, max %d)" % (float(np.mean(seq_levels)), max(seq_levels))
+                              if seq_levels else "synchronous (frozen snapshot)"),
                    "hjb_state": {"float32": "f32", "mixed": "f64", "float64": "f64"}[sim.hjb_dtype],
                    "hjb_field_type": "f64" if sim.hjb_dtype == "float64" else "f32",
                    "hjb_field": ("ring: the accepted steps' interpolants stay in HBM, lookups evaluate the direction from them "
@@ -537,6 +557,9 @@ def main():
         rowc = [c for c in comms if c.shard.world > 1]
         result["rccl"] = {
             "backend": backend, "ranks": world, "mode": "sharded" if sharded else "ensemble",
+            "issued_by": ("the library itself over its own RCCL communicators (oc_comm_create: no host callback; the "
+                          "callback counters below stay 0)") if getattr(eng, "rccl_native", False)
+            else "callbacks into torch.distributed, enqueued on the launch stream",
             "hjb_key_plan": [list(p) for p in getattr(eng, "key_plan", [])] if sharded else None,
             "step_allgathers": sc.n_allgather if (sharded and sc) else 0,
             "step_allgather_bytes": sc.bytes_allgather if (sharded and sc) else 0,

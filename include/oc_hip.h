@@ -124,6 +124,9 @@ typedef struct oc_hjb_shard {
     int (*allgather_red)(void* user);
     int (*exchange_halo)(void* user);
     void* user;
+    /* >= 0: the two collectives are issued by the library itself over the RCCL communicator of this slot (oc_comm_create;
+     * its ranks = the row blocks in order, this rank = block `own` index) and the callbacks are not called; -1: callbacks */
+    int32_t comm_slot, reserved;
 } oc_hjb_shard;
 int oc_hjb_solve_rows(oc_handle* h, int dtype, const void* coef_rows, double T, int32_t nt,
                       void* vx_out, void* vy_out, const oc_hjb_shard* shard,
@@ -219,6 +222,9 @@ typedef struct oc_agents {
 int oc_field_lookup(oc_handle* h, const oc_agents* a, int32_t simu_step, double* des, int32_t* err_flag, void* stream);
 /* index of the reference's argmin (flat row-major, int64 (N)) and wall force float64 (N,2): pedestrians.py:282-334 */
 int oc_wall_force(oc_handle* h, const oc_agents* a, int64_t* index_out, double* force_out, void* stream);
+/* the cell the LAST step's (warm-started) search found for each agent: int32 (N), -1 = none within its search radius / no
+ * step yet.  Introspection for tests: equals oc_wall_force's index at the positions that step started from. */
+int oc_wall_last_index(oc_handle* h, const oc_agents* a, int32_t* index_out, void* stream);
 /* sum of agents_repulsion over active j != i within the cutoff: float64 (N,2).  simulations.py:285-295 */
 int oc_pair_force(oc_handle* h, const oc_agents* a, double* force_out, void* stream);
 
@@ -237,8 +243,10 @@ int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step, const doub
  * default 250 mm, a bound on one step's displacement that every round verifies; a violation is OC_ERR_STATE), one pair
  * of launches per level, so the result equals the one-by-one loop up to float32 pair arithmetic and summation order.
  * noise as in oc_gcfm_step (noise[i] = agent i's draw, whatever its place in the permutation).  rounds_out (host, may be
- * NULL): number of levels.  Synchronises (the host watches the pending count).  For trajectory-level parity with the
- * reference; oc_gcfm_step (synchronous) is the fast path. */
+ * NULL): number of levels.  The levels are looped on the device: the host enqueues as many rounds as the previous step
+ * needed (plus a margin), rounds past the last level return at once, and it synchronises ONCE per step (again only if the
+ * step turns out deeper than the last one).  For trajectory-level parity with the reference; oc_gcfm_step (synchronous)
+ * is the fast path. */
 int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t simu_step, const int32_t* perm, const double* noise,
                             uint64_t seed, int32_t* counters, int32_t* rounds_out, void* stream);
 /* The step on `world` GPUs with REPLICATED agents: every rank holds the whole agent state and calls this
@@ -263,11 +271,26 @@ typedef struct oc_step_comm {
     int (*allgather)(void* user, double* buf, int64_t doubles_per_rank);
     int (*allreduce_sum)(void* user, double* buf, int64_t count);
     void* user;
+    /* >= 0: both collectives are issued by the library itself over the RCCL communicator of this slot (oc_comm_create:
+     * rank / world must be the communicator's) and the callbacks may be NULL; -1: the callbacks */
+    int32_t comm_slot, reserved;
 } oc_step_comm;
 int64_t oc_padded_agents(int32_t N);
 int64_t oc_xchg_doubles(int32_t N, int32_t world);
 int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t simu_step, const double* noise, uint64_t seed,
                          int32_t* counters, const oc_step_comm* comm, void* stream);
+/* ---- RCCL inside the library -------------------------------------------------------------------------
+ * Communicators the library owns, so that the collectives above leave from C on the launch stream -- no host callback on
+ * the launch path.  RCCL is bound at run time (dlopen librccl.so.1); a single-GPU user never needs it.  Per group of
+ * ranks: one of them calls oc_comm_unique_id and hands the 128 bytes to the others by any means (torch.distributed
+ * broadcast, MPI, a file); then EVERY member calls oc_comm_create (collective) with its rank in the group.  `slot`
+ * (0 .. 15) names the communicator in oc_hjb_shard.comm_slot / oc_step_comm.comm_slot.  Halo rows go as one grouped
+ * send/recv pair per neighbour (xGMI is point-to-point). */
+#define OC_COMM_ID_BYTES 128
+int oc_comm_unique_id(void* id_out);
+int oc_comm_create(oc_handle* h, int slot, const void* id, int rank, int world);
+int oc_comm_destroy(oc_handle* h, int slot);
+
 /* For a driver that does not read `counters` after every step (run() enqueues steps and looks every 16th):
  * out4 (host) = { active agents now, 1 + the step in which the last active agent left (0: somebody is inside),
  * 1 + index of an agent that was in the IndexError band (0: none), the first step in which it was }.  Synchronises;
@@ -309,6 +332,8 @@ int oc_set_hjb_variant(oc_handle* h, int variant);
  *                  1 = 128 x 8, 2 = 256 x 4 cells
  *   "hjb_fuse"     stage launches of an RK attempt of the product path: 0 = one launch of six stages (default),
  *                  1 = two launches of three
+ *   "wall_warm"    1 (default) = the exact nearest-wall search of an agent (pedestrians.py:311-315) starts from the cell the
+ *                  previous step's search found -- a valid candidate, so the result is the same cell; 0 = always cold
  *   "hjb_tail"     ring solves (oc_hjb_solve_ring): 1 (default) = while few blocks take part in an attempt -- small grids, or
  *                  the active set's short lists -- the LAST block of the stage launch to finish is the attempt's step
  *                  controller and list builder (one launch per attempt instead of three); 0 = always separate launches.

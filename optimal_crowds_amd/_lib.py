@@ -52,7 +52,8 @@ ALLGATHER_CB = ALLREDUCE_CB                                                 # (s
 class OcStepComm(C.Structure):
     """oc_hip.h: oc_step_comm -- the sharded step's exchange buffer and its two collectives"""
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("xchg", C.c_void_p),
-                ("allgather", ALLGATHER_CB), ("allreduce_sum", ALLREDUCE_CB), ("user", C.c_void_p)]
+                ("allgather", ALLGATHER_CB), ("allreduce_sum", ALLREDUCE_CB), ("user", C.c_void_p),
+                ("comm_slot", C.c_int32), ("reserved", C.c_int32)]
 
 
 class OcHjbShard(C.Structure):
@@ -64,6 +65,7 @@ class OcHjbShard(C.Structure):
         ("red_local", C.c_void_p), ("red_all", C.c_void_p),
         ("allgather_red", HALO_CB), ("exchange_halo", HALO_CB),
         ("user", C.c_void_p),
+        ("comm_slot", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -119,6 +121,7 @@ SIGNATURES = {
     "oc_wallmap_build": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
     "oc_field_lookup": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "oc_wall_force": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "oc_wall_last_index": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_void_p, C.c_void_p]),
     "oc_pair_force": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_void_p, C.c_void_p]),
     "oc_gcfm_step": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p,
                                C.c_void_p]),
@@ -128,6 +131,9 @@ SIGNATURES = {
     "oc_xchg_doubles": (C.c_int64, [C.c_int32, C.c_int32]),
     "oc_gcfm_step_sharded": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.POINTER(OcStepComm), C.c_void_p]),
+    "oc_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "oc_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "oc_comm_destroy": (C.c_int, [C.c_void_p, C.c_int]),
     "oc_run_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "oc_set_resort_every": (C.c_int, [C.c_void_p, C.c_int32]),
     "oc_agents_changed": (C.c_int, [C.c_void_p]),

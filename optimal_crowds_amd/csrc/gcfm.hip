@@ -134,10 +134,13 @@ struct Scratch {
     int32_t ts_pair, ts_wall, ts_des;   // double2 per tile (64: plain arrays)
     int32_t x_tpr, x_blk;               // exchange buffer: tiles per rank block (0: no blocks), double2 per block
     long long* widx;
+    int32_t* wprev;         // per AGENT: the nearest-wall cell the last step's search found (-1: none) -- the next search's
+                            // incumbent (an agent moves a few centimetres per step; the sites do not move at all)
     int32_t* ctrl;
     int32_t* seq_rank;      // sequential mode: position of the slot's agent in the step's permutation
     int32_t* seq_state;     // 0 = not yet updated this step, 1 = being updated in this round, 2 = updated (or no agent)
-    int32_t* seq_ctl;       // [0..3]: agents still pending after round r (slot r & 3); [4]: displacement-bound violations
+    int32_t* seq_ctl;       // [0..3]: agents still pending after round r (slot r & 3); [4]: displacement-bound violations;
+                            // [5]: rounds that advanced somebody (= the permutation's dependency levels)
     int32_t Np, ntiles;
 };
 
@@ -877,8 +880,11 @@ __device__ __forceinline__ void wall_block_eval(double px, double py, int blk, c
 
 // Called by all 64 lanes (`go` false for lanes without a search).  Returns the flat index of the cell the reference's
 // np.argmin(distances + V*10e3) selects (pedestrians.py:311-315), or -1 when nothing lies within we.lim2.
+// prev_flat (>= 0): a cell of the agent's site set -- where the previous step's search ended -- taken as the incumbent: the
+// search then only has to look where something can still beat or tie it (exactly the reference's cell either way: an
+// incumbent is one more candidate, met again when its block is visited).
 __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEntry& we, bool go, const Axis X0,
-                                                 const Axis Y0) {
+                                                 const Axis Y0, long long prev_flat = -1) {
     const double px = we.px, py = we.py;
     const int Nx = P.Nx, Ny = P.Ny, nb8 = (Ny + 7) >> 3;
     const double hx = P.L / (Nx - 1);
@@ -889,6 +895,16 @@ __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEnt
     const bool prune_ok = we.prune_ok != 0;
     double best_f = INFINITY, best_d2 = INFINITY, thr = INFINITY;
     long long best_flat = -1;
+    if (go && prev_flat >= 0) {
+        const int pr = (int)(prev_flat / Nx), pc = (int)(prev_flat % Nx);
+        const double ddx = X0[pc] - px, ddy = Y0[pr] - py, d2 = ddx * ddx + ddy * ddy;
+        if (!(d2 > lim2)) {
+            best_d2 = d2;
+            thr = d2 + 4.8e-10 * sqrt(d2) + 1e-19;
+            best_f = sqrt(d2) + off;
+            best_flat = prev_flat;
+        }
+    }
     bool up = go, dn = go;
     for (int o = 0; __any(up || dn); o += 8) {
         // ---- this round's 16 blocks: slot 2q = up-block b0 + o + q, slot 2q + 1 = down-block b0 - 1 - o - q
@@ -1356,7 +1372,8 @@ __device__ __forceinline__ void prep_tile(const GcfmParams& P, const Scratch& S,
     if (do_wall) {
         WEntry we = {};
         const bool need = act && wall_prepare(P, kd, X0, Y0, p.x, p.y, (double)C.pvel[k].z, we);
-        const long long widx = wall_search(P, we, need, X0, Y0);
+        const long long widx = wall_search(P, we, need, X0, Y0, (need && S.wprev != nullptr) ? (long long)S.wprev[i] : -1);
+        if (act && S.wprev != nullptr) S.wprev[i] = need ? (int32_t)widx : -1;
         double2 fw = make_double2(0.0, 0.0);
         if (act) fw = wall_force_of(P, widx, p.x, p.y, v.x, v.y, dk.v_des, X0, Y0);
         xs(S, S.f_wall, S.ts_wall, k) = fw;
@@ -1446,6 +1463,8 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     __shared__ double l_rect[RECT_KEYS_LDS * RECT_TAB];
     const Snap& C = S.snap;
     const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
+    if (SEQ && seq_round > 0 && S.seq_ctl[(seq_round - 1) & 3] == 0) return;      // (a round enqueued past the last level)
+    if (SEQ && it == 0 && lane == 0) S.seq_ctl[5] = seq_round + 1;
     // the NEXT step's ring lookups (interpolant ring: slice -> slot, factors): resolved here, once per key, off every path
     if (ksteps != nullptr && it == (int)gridDim.x - 1)
         for (int q = lane; q < nkeys; q += 64) ring_step_prepare(keys[q], A.step + 1, ksteps[q]);
@@ -1587,7 +1606,7 @@ __global__ void k_seq_invperm(const int32_t* __restrict__ perm, int N, int32_t* 
 
 __global__ void k_seq_init(Scratch S, const int32_t* __restrict__ inv) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) S.seq_ctl[0] = S.seq_ctl[1] = S.seq_ctl[2] = S.seq_ctl[3] = S.seq_ctl[4] = 0;
+    if (k == 0) S.seq_ctl[0] = S.seq_ctl[1] = S.seq_ctl[2] = S.seq_ctl[3] = S.seq_ctl[4] = S.seq_ctl[5] = 0;
     if (k >= S.Np) return;
     const int i = S.snap.pidx[k];
     S.seq_rank[k] = (i >= 0) ? inv[i] : 0x7FFFFFFF;
@@ -1608,6 +1627,9 @@ __global__ void __launch_bounds__(64) k_seq_pairs(GcfmParams P, Scratch S, int r
     const Snap& C = S.snap;
     const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
     if (it == 0 && lane == 0) S.seq_ctl[(round + 1) & 3] = 0;          // next round's pending counter
+    // the levels are looped on the DEVICE: the host enqueues rounds a whole step ahead, and a round that finds nobody
+    // pending after the one before it returns at once (one load per wavefront) -- no host round trip per level
+    if (round > 0 && S.seq_ctl[(round - 1) & 3] == 0) return;
     const int st_i = S.seq_state[k];
     if (!__any(st_i == 0)) return;                                      // the whole tile has been advanced
     const int i = C.pidx[k];
@@ -1633,43 +1655,60 @@ __global__ void __launch_bounds__(64) k_seq_pairs(GcfmParams P, Scratch S, int r
     const int nb_cnt = nb[0];
     const bool use_list = (nb_cnt >= 0) && (S.ctrl[C_INVALID] == 0);
     const int nchunk = use_list ? 1 : (S.ntiles + 63) / 64;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        int t;
-        if (use_list) t = (lane < nb_cnt) ? nb[1 + lane] : -1;
-        else t = (ch * 64 + lane < S.ntiles) ? ch * 64 + lane : -1;
-        // (live boxes: read while other tiles may be advancing; a box only ever matters through agents that are within
-        // reach, and those are not being advanced in this round -- see the header)
-        const bool hit = (t >= 0) && box_hit(bi, C.tile_box[t], reach + margin);
-        unsigned long long tmask = __ballot(hit);
-        while (tmask) {
-            const int jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
-            tmask &= tmask - 1;
-            __syncthreads();
-            L.pos[lane] = C.ppos[jt * 64 + lane];
-            L.vel[lane] = C.pvel[jt * 64 + lane];
-            L.head[lane] = C.phead[jt * 64 + lane];
-            L.rank[lane] = S.seq_rank[jt * 64 + lane];
-            L.state[lane] = S.seq_state[jt * 64 + lane];
-            __syncthreads();
-            if (i >= 0 && st_i == 0)
-            for (int q = 0; q < 64; q += 2) {
-                const double2 pa = L.pos[q], pb = L.pos[q + 1];
-                const double dxA = pa.x - pi.x, dyA = pa.y - pi.y, dxB = pb.x - pi.x, dyB = pb.y - pi.y;
-                const double d2A = dxA * dxA + dyA * dyA, d2B = dxB * dxB + dyB * dyB;
-                // an earlier neighbour that has not moved yet: wait for it
-                blocked = blocked || (L.state[q] != 2 && L.rank[q] < rank_i && d2A < reach2) ||
-                          (L.state[q + 1] != 2 && L.rank[q + 1] < rank_i && d2B < reach2);
-                const bool okA = d2A <= P.cut_d2max && d2A > 0.0, okB = d2B <= P.cut_d2max && d2B > 0.0;
-                if (okA || okB) {
-                    const float4 va = L.vel[q], vb = L.vel[q + 1];
-                    const float2 ha = L.head[q], hb = L.head[q + 1];
-                    f2v gx, gy;
-                    pair_term2((f2v){(float)dxA, (float)dxB}, (f2v){(float)dyA, (float)dyB}, vi.x, vi.y, vi.z, hi.x, hi.y,
-                               vi.w, ib2_i, inv_vdes, (f2v){va.x, vb.x}, (f2v){va.y, vb.y}, (f2v){va.z, vb.z},
-                               (f2v){va.w, vb.w}, (f2v){ha.x, hb.x}, (f2v){ha.y, hb.y}, b_max, db, neg_inv_eta_log2e,
-                               unit_dir, gx, gy);
-                    if (okA) { fx += (double)gx.x; fy += (double)gy.x; }
-                    if (okB) { fx += (double)gx.y; fy += (double)gy.y; }
+    // Two passes over the candidate tiles.  Pass 0: who is free to go -- positions, ranks and states only, a handful of
+    // instructions per pair.  Pass 1: the pair sums of the agents that ARE free -- in a round of a deep permutation that is
+    // one agent in a few tiles (5 000 agents at 2.5 / m^2: ~220 levels, ~23 agents per round), so most wavefronts leave
+    // after pass 0.  (One pass doing both recomputed every pending agent's whole pair sum in every round.)
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool mine = i >= 0 && st_i == 0 && !blocked;         // pass 1: free agents only
+        if (pass == 1 && !__any(mine)) return;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            int t;
+            if (use_list) t = (lane < nb_cnt) ? nb[1 + lane] : -1;
+            else t = (ch * 64 + lane < S.ntiles) ? ch * 64 + lane : -1;
+            // (live boxes: read while other tiles may be advancing; a box only ever matters through agents that are within
+            // reach, and those are not being advanced in this round -- see the header)
+            const bool hit = (t >= 0) && box_hit(bi, C.tile_box[t], reach + margin);
+            unsigned long long tmask = __ballot(hit);
+            while (tmask) {
+                const int jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
+                tmask &= tmask - 1;
+                __syncthreads();
+                L.pos[lane] = C.ppos[jt * 64 + lane];
+                if (pass == 0) {
+                    L.rank[lane] = S.seq_rank[jt * 64 + lane];
+                    L.state[lane] = S.seq_state[jt * 64 + lane];
+                } else {
+                    L.vel[lane] = C.pvel[jt * 64 + lane];
+                    L.head[lane] = C.phead[jt * 64 + lane];
+                }
+                __syncthreads();
+                if (!mine) continue;
+                if (pass == 0) {
+                    for (int q = 0; q < 64; ++q) {
+                        const double2 pa = L.pos[q];
+                        const double dxA = pa.x - pi.x, dyA = pa.y - pi.y;
+                        // an earlier neighbour that has not moved yet: wait for it
+                        blocked = blocked || (L.state[q] != 2 && L.rank[q] < rank_i && dxA * dxA + dyA * dyA < reach2);
+                    }
+                } else {
+                    for (int q = 0; q < 64; q += 2) {
+                        const double2 pa = L.pos[q], pb = L.pos[q + 1];
+                        const double dxA = pa.x - pi.x, dyA = pa.y - pi.y, dxB = pb.x - pi.x, dyB = pb.y - pi.y;
+                        const double d2A = dxA * dxA + dyA * dyA, d2B = dxB * dxB + dyB * dyB;
+                        const bool okA = d2A <= P.cut_d2max && d2A > 0.0, okB = d2B <= P.cut_d2max && d2B > 0.0;
+                        if (okA || okB) {
+                            const float4 va = L.vel[q], vb = L.vel[q + 1];
+                            const float2 ha = L.head[q], hb = L.head[q + 1];
+                            f2v gx, gy;
+                            pair_term2((f2v){(float)dxA, (float)dxB}, (f2v){(float)dyA, (float)dyB}, vi.x, vi.y, vi.z, hi.x, hi.y,
+                                       vi.w, ib2_i, inv_vdes, (f2v){va.x, vb.x}, (f2v){va.y, vb.y}, (f2v){va.z, vb.z},
+                                       (f2v){va.w, vb.w}, (f2v){ha.x, hb.x}, (f2v){ha.y, hb.y}, b_max, db, neg_inv_eta_log2e,
+                                       unit_dir, gx, gy);
+                            if (okA) { fx += (double)gx.x; fy += (double)gy.x; }
+                            if (okB) { fx += (double)gx.y; fy += (double)gy.y; }
+                        }
+                    }
                 }
             }
         }
@@ -1797,7 +1836,7 @@ int carve(oc_handle* h, int N, Scratch* S, bool diag = false) {
     const int nt = Np / 64;
     const size_t per_snap = sizeof(double2) + sizeof(float4) + sizeof(float2) + sizeof(int32_t);
     const size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + per_snap + sizeof(double2) + sizeof(PDK) +
-                       3 * sizeof(double2) + sizeof(long long);
+                       3 * sizeof(double2) + sizeof(long long) + sizeof(int32_t);
     size_t need = (per + 2 * sizeof(int32_t)) * (size_t)Np + (6 * sizeof(double4) + (NB_MAX + 3) * sizeof(int32_t)) * (size_t)nt +
                   1024 + 16384;
     if (need > h->gcfm_bytes) {
@@ -1808,6 +1847,7 @@ int carve(oc_handle* h, int N, Scratch* S, bool diag = false) {
         h->gcfm_bytes = need;
         h->packed_valid = false;
         h->work_valid = false;
+        h->wprev_valid = false;
     }
     char* p = (char*)h->gcfm_buf;
     auto take = [&](size_t bytes) {
@@ -1836,6 +1876,8 @@ int carve(oc_handle* h, int N, Scratch* S, bool diag = false) {
     S->x_tpr = S->x_blk = 0;
     S->tile_box0 = (double4*)take(sizeof(double4) * nt);
     S->widx = (long long*)take(sizeof(long long) * Np);
+    S->wprev = (int32_t*)take(sizeof(int32_t) * Np);
+    if (diag || !h->wall_warm) S->wprev = nullptr;      // (single-shot exports search cold; "wall_warm" = 0 switches it off)
     S->keys_a = (uint32_t*)take(sizeof(uint32_t) * Np);
     S->keys_b = (uint32_t*)take(sizeof(uint32_t) * Np);
     S->vals_a = (int32_t*)take(sizeof(int32_t) * Np);
@@ -1926,6 +1968,12 @@ bool wallmaps_ready(const oc_handle* h) {
 // re-sort + full pack of the current state + neighbour lists + dispatch order
 int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hipStream_t s) {
     const int N = a->N;
+    // the searches' incumbents belong to THESE agents, arrays and wall maps: anything else starts cold (a plain re-sort of
+    // the same agents keeps them: they are indexed by agent)
+    if (S->wprev != nullptr && (!h->wprev_valid || h->packed_x != a->x || h->packed_N != N)) {
+        OC_HIP_CHECK(hipMemsetAsync(S->wprev, 0xFF, sizeof(int32_t) * (size_t)S->Np, s));
+        h->wprev_valid = true;
+    }
     OC_HIP_CHECK(hipMemsetAsync(S->ctrl, 0, CTRL_VOLATILE_BYTES, s));
     if (N > 0) {
         hipLaunchKernelGGL(k_cell_keys, dim3((N + 255) / 256), dim3(256), 0, s, a->x, a->y, a->status, N, P, S->keys_a,
@@ -1984,6 +2032,7 @@ extern "C" int oc_wallmap_build(oc_handle* h, int key, const float* V, float vmi
     w.built = true;
     h->key_tables_dirty = true;
     h->packed_valid = false;
+    h->wprev_valid = false;
     return OC_OK;
 }
 
@@ -1999,6 +2048,7 @@ static int require_wallmaps(oc_handle* h) {
 extern "C" int oc_agents_changed(oc_handle* h) {
     OC_REQUIRE(h, "null handle");
     h->packed_valid = false;
+    h->wprev_valid = false;
     return OC_OK;
 }
 
@@ -2145,12 +2195,18 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
         n_err_slots = comm->world;
         hipLaunchKernelGGL(k_err_publish, dim3(1), dim3(1), 0, s, S.ctrl,
                            comm->xchg + (int64_t)comm->rank * X.block + (int64_t)X.tpr * X.td);
-        if (comm->allgather(comm->user, comm->xchg, X.block) != 0) {
+        if (comm->comm_slot >= 0) {     // RCCL from here, on the launch stream (comm.hip): no host callback
+            int rcc = oc_comm_allgather_f64(h, comm->comm_slot, comm->xchg, X.block, s);
+            if (rcc) return rcc;
+        } else if (comm->allgather(comm->user, comm->xchg, X.block) != 0) {
             oc_set_error("oc_gcfm_step_sharded: the allgather callback failed");
             return OC_ERR_STATE;
         }
         if (des_separate) {     // desired velocities answered by the holders of the field rows: zero elsewhere, summed
-            if (comm->allreduce_sum(comm->user, (double*)S.des, 2 * (int64_t)S.Np) != 0) {
+            if (comm->comm_slot >= 0) {
+                int rcc = oc_comm_allreduce_sum_f64(h, comm->comm_slot, (double*)S.des, 2 * (int64_t)S.Np, s);
+                if (rcc) return rcc;
+            } else if (comm->allreduce_sum(comm->user, (double*)S.des, 2 * (int64_t)S.Np) != 0) {
                 oc_set_error("oc_gcfm_step_sharded: the allreduce_sum callback failed");
                 return OC_ERR_STATE;
             }
@@ -2244,11 +2300,14 @@ extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t
     }
     GcfmParams Pf = P;
     Pf.drift = P.drift - margin;            // validity bound of the neighbour lists in this mode (see above)
-    int rounds = 0, pending = N > 0 ? 1 : 0;
+    // ONE host synchronisation per step: as many rounds as the last step needed (+ a margin) are enqueued at once; rounds
+    // past the last level return at once on the device.  Only if agents are still pending after them -- the permutation
+    // of this step is deeper than the last one's -- more rounds follow.
+    int rounds = 0, pending = N > 0 ? 1 : 0, levels = 0;
     int32_t ctl[8];
+    int batch = std::max(8, h->seq_rounds_hint + std::max(4, h->seq_rounds_hint / 8));
     while (pending > 0) {
-        const int burst = 4;                // rounds between two looks at the pending counter
-        for (int b = 0; b < burst; ++b, ++rounds) {
+        for (int b = 0; b < batch; ++b, ++rounds) {
             hipLaunchKernelGGL(k_seq_pairs, dim3(S.ntiles), dim3(64), 0, s, P, S, rounds, margin);
             hipLaunchKernelGGL((k_finish<true>), dim3(S.ntiles), dim3(64), 0, s, Pf, S, (const double*)h->rect_tab_dev,
                                (int)h->fields.size(), A, rounds, margin, (const double*)nullptr, 0, (int64_t)1, kd,
@@ -2257,18 +2316,22 @@ extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t
         OC_HIP_CHECK(hipMemcpyAsync(ctl, S.seq_ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
         OC_HIP_CHECK(hipStreamSynchronize(s));
         pending = ctl[(rounds - 1) & 3];
+        levels = ctl[5];
         if (ctl[4]) {
             oc_set_error("sequential step %d: an agent moved farther than seq_margin = %g m in one step; the level "
                          "schedule is not valid (raise it with oc_set_tuning(\"seq_margin_mm\"))", simu_step, margin);
             h->packed_valid = false;
             return OC_ERR_STATE;
         }
-        if (rounds > N + burst) {
+        if (rounds > N + batch) {
             oc_set_error("sequential step %d did not drain (%d agents pending)", simu_step, pending);
             h->packed_valid = false;
             return OC_ERR_STATE;
         }
+        batch = std::max(8, rounds / 2);
     }
+    h->seq_rounds_hint = levels;
+    rounds = levels;                        // (what the caller is told: the levels, not the rounds enqueued)
     OC_HIP_CHECK(hipGetLastError());
     if (rounds_out) *rounds_out = rounds;
     h->packed_valid = true;
@@ -2319,7 +2382,11 @@ extern "C" int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t si
     if (rc) return rc;
     if ((rc = require_wallmaps(h))) return rc;
     OC_REQUIRE(comm && comm->world >= 1 && comm->world <= OC_MAX_WORLD && comm->rank >= 0 && comm->rank < comm->world &&
-               comm->xchg && comm->allgather, "bad oc_step_comm");
+               comm->xchg && (comm->allgather || comm->comm_slot >= 0), "bad oc_step_comm");
+    OC_REQUIRE(comm->comm_slot < 0 || (comm->comm_slot < OC_MAX_COMMS && h->comms[comm->comm_slot].comm != nullptr &&
+                                      h->comms[comm->comm_slot].rank == comm->rank &&
+                                      h->comms[comm->comm_slot].world == comm->world),
+               "oc_step_comm.comm_slot names no communicator of this rank / world (oc_comm_create)");
     OC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     Scratch S;
@@ -2335,7 +2402,7 @@ extern "C" int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t si
     // by their own zero-padded sum); with every field whole on every rank the tile's owner does, and they ride in its block
     bool rows = false;
     for (const auto& f : h->fields) rows = rows || f.rows >= 0 || (f.vx == nullptr && f.ring_data == nullptr);
-    OC_REQUIRE(!rows || comm->allreduce_sum, "sharded floor fields need the allreduce_sum callback");
+    OC_REQUIRE(!rows || comm->allreduce_sum || comm->comm_slot >= 0, "sharded floor fields need the allreduce_sum callback");
     const XchgLayout X = xchg_layout(S.ntiles, comm->world, rows);
     // pair sums, wall forces (and desired velocities) of tile t live in the block of the rank that owns t
     double* base = comm->xchg;
@@ -2357,3 +2424,23 @@ extern "C" int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t si
                             rows ? 1 : 0, rows ? 1 : 0};
     return launch_step(h, a, S, P, simu_step, noise, seed, counters, mine, comm, rows, s);
 }
+
+// The nearest-wall cell each agent's last step used (the warm-started search's result, kept as the next step's incumbent):
+// int32 (N), -1 where nothing lay within the agent's search radius or no step has run.  For tests: it must equal what the
+// cold search of oc_wall_force finds at the positions that step started from.
+extern "C" int oc_wall_last_index(oc_handle* h, const oc_agents* a, int32_t* index_out, void* stream) {
+    int rc = check_agents(h, a);
+    if (rc) return rc;
+    OC_REQUIRE(index_out, "null output");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scratch S;
+    if ((rc = carve(h, a->N, &S))) return rc;
+    if (S.wprev == nullptr || !h->wprev_valid || h->packed_x != a->x || h->packed_N != a->N) {
+        OC_HIP_CHECK(hipMemsetAsync(index_out, 0xFF, sizeof(int32_t) * (size_t)a->N, s));
+        return OC_OK;
+    }
+    OC_HIP_CHECK(hipMemcpyAsync(index_out, S.wprev, sizeof(int32_t) * (size_t)a->N, hipMemcpyDeviceToDevice, s));
+    return OC_OK;
+}
+

@@ -1872,7 +1872,10 @@ struct Solver {
             // every rank contributes (sum, max) of its owned rows; the caller's collective gathers them (on `s`) and
             // every rank adds them up in rank order, so all ranks take bit-identical controller decisions
             hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, nblocks, sh->red_local);
-            if (sh->allgather_red(sh->user) != 0) {
+            if (sh->comm_slot >= 0) {
+                int rcc = oc_comm_allgather_f64_oop(h, sh->comm_slot, sh->red_local, sh->red_all, 2, s);
+                if (rcc) return rcc;
+            } else if (sh->allgather_red(sh->user) != 0) {
                 oc_set_error("hjb_solve_rows: the allgather_red callback failed");
                 return OC_ERR_STATE;
             }
@@ -2280,7 +2283,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             // (controller and list builder ran inside the stage launch)
         } else if (sh) {
             hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, nb3, sh->red_local);
-            if (sh->allgather_red(sh->user) != 0) {
+            if (sh->comm_slot >= 0) {       // RCCL from here, on the launch stream (comm.hip)
+                int rcc = oc_comm_allgather_f64_oop(h, sh->comm_slot, sh->red_local, sh->red_all, 2, s);
+                if (rcc) return rcc;
+            } else if (sh->allgather_red(sh->user) != 0) {
                 oc_set_error("hjb_solve_rows: the allgather_red callback failed");
                 return OC_ERR_STATE;
             }
@@ -2296,7 +2302,11 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             const dim3 gh((unsigned)((4 * hn + 255) / 256));
             hipLaunchKernelGGL((k_halo_stage<T, true>), gh, dim3(256), 0, s, (const HjbCtl<T>*)ctl_nxt, Y[0], Y[1], KX[0], KX[1],
                                (T*)sh->send_up, (T*)sh->send_dn, lo, hi, hn, sh->has_up, sh->has_dn);
-            if (sh->exchange_halo(sh->user) != 0) {
+            if (sh->comm_slot >= 0) {
+                int rcc = oc_comm_exchange_halo(h, sh->comm_slot, sh->send_up, sh->recv_up, sh->send_dn, sh->recv_dn,
+                                                2 * hn * sizeof(T), sh->has_up, sh->has_dn, s);
+                if (rcc) return rcc;
+            } else if (sh->exchange_halo(sh->user) != 0) {
                 oc_set_error("hjb_solve_rows: the exchange_halo callback failed");
                 return OC_ERR_STATE;
             }
@@ -2851,8 +2861,8 @@ extern "C" int oc_hjb_solve_rows(oc_handle* h, int dtype, const void* coef_rows,
     OC_REQUIRE(sh->own_hi > sh->own_lo && sh->Ny_local == sh->own_hi + (sh->has_dn ? sh->halo : 0), "bad row window");
     OC_REQUIRE(!(sh->has_up || sh->has_dn) || sh->own_hi - sh->own_lo >= sh->halo, "owned block thinner than the halo");
     OC_REQUIRE(sh->Ny_local >= 3 && sh->Ny_local <= sh->Ny_global && sh->Ny_global <= h->cfg.Ny, "bad row counts");
-    OC_REQUIRE(sh->red_local && sh->red_all && sh->allgather_red, "missing reduction buffers / callback");
-    OC_REQUIRE(!(sh->has_up || sh->has_dn) || sh->exchange_halo, "missing halo callback");
+    OC_REQUIRE(sh->red_local && sh->red_all && (sh->allgather_red || sh->comm_slot >= 0), "missing reduction buffers / callback");
+    OC_REQUIRE(!(sh->has_up || sh->has_dn) || sh->exchange_halo || sh->comm_slot >= 0, "missing halo callback");
     OC_REQUIRE(!sh->has_up || (sh->send_up && sh->recv_up), "missing upper staging buffers");
     OC_REQUIRE(!sh->has_dn || (sh->send_dn && sh->recv_dn), "missing lower staging buffers");
     OC_HIP_CHECK(hipSetDevice(h->device));
@@ -2957,8 +2967,8 @@ extern "C" int oc_hjb_solve_rows_ring(oc_handle* h, int dtype, const void* coef_
     OC_REQUIRE(sh->own_hi > sh->own_lo && sh->Ny_local == sh->own_hi + (sh->has_dn ? sh->halo : 0), "bad row window");
     OC_REQUIRE(!(sh->has_up || sh->has_dn) || sh->own_hi - sh->own_lo >= sh->halo, "owned block thinner than the halo");
     OC_REQUIRE(sh->Ny_local >= 3 && sh->Ny_local <= sh->Ny_global && sh->Ny_global <= h->cfg.Ny, "bad row counts");
-    OC_REQUIRE(sh->red_local && sh->red_all && sh->allgather_red, "missing reduction buffers / callback");
-    OC_REQUIRE(!(sh->has_up || sh->has_dn) || sh->exchange_halo, "missing halo callback");
+    OC_REQUIRE(sh->red_local && sh->red_all && (sh->allgather_red || sh->comm_slot >= 0), "missing reduction buffers / callback");
+    OC_REQUIRE(!(sh->has_up || sh->has_dn) || sh->exchange_halo || sh->comm_slot >= 0, "missing halo callback");
     OC_REQUIRE(!sh->has_up || (sh->send_up && sh->recv_up), "missing upper staging buffers");
     OC_REQUIRE(!sh->has_dn || (sh->send_dn && sh->recv_dn), "missing lower staging buffers");
     OC_HIP_CHECK(hipSetDevice(h->device));

@@ -74,6 +74,7 @@ extern "C" int oc_destroy(oc_handle* h) {
     if (!h) return OC_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    oc_comm_destroy_all(h);
     (void)hipFree(h->X0);
     (void)hipFree(h->Y0);
     (void)hipFree(h->hjb_buf);
@@ -290,6 +291,10 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     } else if (!strcmp(name, "hjb_active")) {
         OC_REQUIRE(value >= 0 && value <= 2, "hjb_active out of range");
         h->hjb_active = value;
+    } else if (!strcmp(name, "wall_warm")) {
+        OC_REQUIRE(value >= 0 && value <= 1, "wall_warm out of range");
+        h->wall_warm = value;
+        h->wprev_valid = false;
     } else if (!strcmp(name, "hjb_tail")) {
         OC_REQUIRE(value >= 0 && value <= 1, "hjb_tail out of range");
         h->hjb_tail_fuse = value;
@@ -311,6 +316,7 @@ extern "C" int oc_set_fix_flags(oc_handle* h, uint32_t flags) {
     OC_REQUIRE((flags & ~(uint32_t)OC_FIX_ALL) == 0, "unknown OC_FIX_* bit");
     h->fix_flags = flags;
     h->packed_valid = false;        // (the per-agent wall search radius depends on OC_FIX_WALL_FORCE)
+    h->wprev_valid = false;
     return OC_OK;
 }
 

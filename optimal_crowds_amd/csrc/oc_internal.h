@@ -120,8 +120,15 @@ struct oc_timer {
     int64_t add_n = 0;
 };
 
+#define OC_MAX_COMMS 16
+struct oc_comm {                // an RCCL communicator the library owns (comm.hip)
+    void* comm = nullptr;       // ncclComm_t
+    int rank = 0, world = 0;
+};
+
 struct oc_handle {
     int device = 0;
+    oc_comm comms[OC_MAX_COMMS];
     oc_config cfg;
     int64_t ncell = 0;
     double* X0 = nullptr;       // device (Nx)
@@ -162,7 +169,10 @@ struct oc_handle {
     bool packed_valid = false;  // the packed snapshot matches the caller's state arrays
     const void* packed_x = nullptr;
     int32_t packed_N = -1;
+    bool wprev_valid = false;   // the wall searches' incumbents (gcfm.hip: Scratch::wprev) belong to the packed agents
+    int wall_warm = 1;          // 1: a wall search starts from the cell the previous step found (oc_set_tuning "wall_warm")
     bool packed_seq = false;    // the snapshot has only been advanced by sequential steps since its re-sort
+    int seq_rounds_hint = 8;    // sequential mode: dependency levels of the last step (rounds to enqueue before looking)
     double seq_margin = 0.25;   // sequential mode: bound on one step's displacement (m), checked every round
     int pair_split = 4;         // pair wavefronts per tile (1, 2 or 4): occupancy / balance of k_forces (gcfm.hip)
     int diag = 0;               // diagnostic builds of k_forces (gcfm.hip: GcfmParams::diag) -- results are WRONG with it
@@ -224,6 +234,14 @@ __device__ __forceinline__ void direction_of(T gx, T gy, T mupc, T lim, T& ox, T
         oy = m;
     }
 }
+
+// RCCL collectives issued by the library itself (comm.hip)
+int oc_comm_allgather_f64(oc_handle* h, int slot, double* buf, int64_t count, hipStream_t s);
+int oc_comm_allgather_f64_oop(oc_handle* h, int slot, const double* in, double* out, int64_t count, hipStream_t s);
+int oc_comm_allreduce_sum_f64(oc_handle* h, int slot, double* buf, int64_t count, hipStream_t s);
+int oc_comm_exchange_halo(oc_handle* h, int slot, const void* send_up, void* recv_up, const void* send_dn, void* recv_dn,
+                          size_t bytes, int has_up, int has_dn, hipStream_t s);
+void oc_comm_destroy_all(oc_handle* h);
 
 // timers (oc_api.hip)
 void oc_timer_begin(oc_handle* h, const char* name, hipStream_t s);

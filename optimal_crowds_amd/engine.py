@@ -533,6 +533,13 @@ class Engine:
         check(self.lib.oc_wall_force(self.h, C.byref(self._astruct), _ptr(idx), _ptr(f), self.stream()))
         return idx, f
 
+    def wall_last_index(self):
+        """the nearest-wall cell each agent's LAST step used (oc_wall_last_index; -1: none within its search radius)"""
+        N = self.agents["N"]
+        idx = torch.empty(N, dtype=torch.int32, device=self.device)
+        check(self.lib.oc_wall_last_index(self.h, C.byref(self._astruct), _ptr(idx), self.stream()))
+        return idx
+
     def pair_force(self):
         N = self.agents["N"]
         f = torch.empty((N, 2), dtype=torch.float64, device=self.device)
@@ -560,7 +567,10 @@ class Engine:
             raise ValueError("the sequential step is a single-GPU mode")
         if noise is not None and not torch.is_tensor(noise):
             noise = torch.as_tensor(np.ascontiguousarray(noise, dtype=np.float64)).to(self.device)
-        perm = torch.as_tensor(np.ascontiguousarray(perm, dtype=np.int32)).to(self.device)
+        if torch.is_tensor(perm):
+            perm = perm.to(device=self.device, dtype=torch.int32).contiguous()
+        else:
+            perm = torch.as_tensor(np.ascontiguousarray(perm, dtype=np.int32)).to(self.device)
         if perm.numel() != self.agents["N"]:
             raise ValueError("the permutation must list every agent once")
         rounds = C.c_int32(0)

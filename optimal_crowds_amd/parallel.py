@@ -113,6 +113,7 @@ class _HaloComm:
         self.red_all = torch.zeros((shard.world, 2), dtype=torch.float64, device=self.device)
         self.error = None
         self.n_allgather = self.n_exchange = 0
+        self.comm_slot = -1             # >= 0: the library issues both collectives itself over its RCCL communicator
         self._cb_red = HALO_CB(self._red)
         self._cb_halo = HALO_CB(self._halo)
 
@@ -144,6 +145,7 @@ class _HaloComm:
         st.red_local, st.red_all = self.red_local.data_ptr(), self.red_all.data_ptr()
         st.allgather_red, st.exchange_halo = self._cb_red, self._cb_halo
         st.user = None
+        st.comm_slot, st.reserved = int(self.comm_slot), 0
         return st
 
 
@@ -246,6 +248,7 @@ class _StepComm:
         self.error = None
         self.n_allgather = self.n_allreduce = 0
         self.bytes_allgather = self.bytes_allreduce = 0         # payload of the last step (all ranks' blocks / the sum)
+        self.comm_slot = -1             # >= 0: the library issues both collectives itself over its RCCL communicator
         self._cb_ag = ALLGATHER_CB(self._ag)
         self._cb_ar = ALLREDUCE_CB(self._ar)
 
@@ -257,6 +260,7 @@ class _StepComm:
         st.rank, st.world = self.rank, self.world
         st.xchg = self.buf.data_ptr()
         st.allgather, st.allreduce_sum, st.user = self._cb_ag, self._cb_ar, None
+        st.comm_slot, st.reserved = int(self.comm_slot), 0
         return st
 
     def _view(self, ptr, count):
@@ -343,6 +347,29 @@ class ThreadStepComm(_StepComm):
 
 
 # ---------------------------------------------------------------------------------------------- one call for a façade
+def native_comm(eng, slot, group=None, ranks=None):
+    """An RCCL communicator owned by the LIBRARY (oc_comm_create, csrc/comm.hip) for the ranks of `group` (None: the whole
+    world): the group's first rank draws the unique id, torch.distributed only carries its 128 bytes to the others, and
+    from then on the collectives of that group leave from C on the launch stream -- no Python on the launch path.
+    Collective: every member calls it (and every rank of the world takes part in the broadcast of a sub-group's id only
+    if it is a member: torch.distributed sub-group semantics).  Returns the slot."""
+    import ctypes as C_
+    ranks = list(range(dist.get_world_size())) if ranks is None else list(ranks)
+    me = dist.get_rank()
+    assert me in ranks
+    idb = (C_.c_ubyte * 128)()
+    if me == ranks[0]:
+        from ._lib import check
+        check(eng.lib.oc_comm_unique_id(idb))
+    box = [bytes(idb)]
+    if len(ranks) > 1:
+        dist.broadcast_object_list(box, src=ranks[0], group=group)
+    from ._lib import check
+    buf = (C_.c_ubyte * 128).from_buffer_copy(box[0])
+    check(eng.lib.oc_comm_create(eng.h, int(slot), buf, ranks.index(me), len(ranks)))
+    return int(slot)
+
+
 _SUBGROUPS = {}         # rank tuple -> process group: a simulation built twice in one process reuses its sub-groups
 
 
@@ -357,13 +384,18 @@ def _subgroup(ranks):
     return _SUBGROUPS[ranks]
 
 
-def dist_sharding(halo=8, by_key=True):
+def dist_sharding(halo=8, by_key=True, native=None):
     """`sharding=` argument of simulations.simulation for a torch.distributed job (one process per GPU): ONE simulation
     on all ranks.  HJB: keys first, then row blocks (key_row_plan; by_key=False: every key over all ranks) with `halo`
     rows -- at least 8 here: 7 for the solve itself (RowShard) and one more so that the floor field is exact on the row
     beyond the block, which a lookup's second cell may read -- each key's collectives on its own sub-group (nccl = RCCL over
     xGMI, or gloo); agents replicated, the step's exchange over the whole world (DistStepComm).
+    native: the collectives are issued by the library itself over RCCL communicators it owns (native_comm: slot 0 = the
+    world, slot 1 + k = key k's rank group) instead of through callbacks into torch.distributed; None = the environment's
+    OC_RCCL_NATIVE=1 on an nccl job.  (Off by default: this pool's one-GPU boxes can exercise it with one rank only.)
     Returns engine -> ({key: halo comm or None}, step comm)."""
+    if native is None:
+        native = os.environ.get("OC_RCCL_NATIVE") == "1"
     if halo < 8:
         raise ValueError("sharded lookups need halo >= 8 (the field is exact halo - 7 rows beyond a block)")
 
@@ -377,10 +409,16 @@ def dist_sharding(halo=8, by_key=True):
             if rank in ranks:
                 sh = RowShard(eng.Ny, ranks.index(rank), len(ranks), halo)
                 comms[k] = DistHaloComm(sh, eng.Nx, eng.tdtype, eng.device, group=grp, ranks=ranks)
+                if native and dist.get_backend() == "nccl" and k + 1 < 16:
+                    comms[k].comm_slot = native_comm(eng, 1 + k, group=grp, ranks=ranks)
             else:
                 comms[k] = None
         eng.key_plan = plan
-        return comms, DistStepComm(None)
+        step = DistStepComm(None)
+        if native and dist.get_backend() == "nccl":
+            step.comm_slot = native_comm(eng, 0)
+        eng.rccl_native = bool(native and dist.get_backend() == "nccl")
+        return comms, step
     return make
 
 

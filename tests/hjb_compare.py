@@ -60,8 +60,8 @@ def describe(a):
         a.size, a.max(), np.percentile(a, 99), np.percentile(a, 99.99), (a > 1e-2).mean())
 
 
-def assert_steps_acceptable(err):
+def assert_steps_acceptable(err, limit=1.1):
     """err: the float64 oracle's error norm of every step the float32 GPU solve accepted.  The GPU's own norm of the same
     step is a float32 evaluation of a sum that hovers just below 1 (the controller aims there), so a step or two may read
     1.0x in float64; none may be a step the oracle would clearly have rejected."""
-    assert (err < 1.1).all() and (err >= 1.0).sum() <= 3, (float(err.max()), int((err >= 1.0).sum()))
+    assert (err < limit).all() and (err >= 1.0).sum() <= 3, (float(err.max()), int((err >= 1.0).sum()))

@@ -72,3 +72,43 @@ def test_wall_search_is_the_full_grid_argmin(gs, L, H):
         for a in range(n):
             want = int(np.argmin(np.sqrt((X - px[a]) ** 2 + (Y - py[a]) ** 2) + V * 10e3))
             assert idx[a] == want, (name, a, px[a], py[a], idx[a], want)
+
+
+@pytest.mark.parametrize("radius", [0.0, -1.0])
+def test_warm_started_search_finds_the_same_cell(radius):
+    """From the second step on a search starts from the cell the previous step found (oc_set_tuning "wall_warm", default
+    on): the incumbent is one more candidate, so the result must still be the reference's argmin -- checked step by step
+    against the cold search (oc_wall_force) at the positions each step started from, on crowds that walk along, towards
+    and away from walls (incumbents that stay nearest, that are overtaken by another wall, that tie), with noise large
+    enough to jump cells.  radius 0: unbounded search; -1: the per-agent radius (agents leave and re-enter it)."""
+    from optimal_crowds_amd.engine import Engine
+    cfg = copy.deepcopy(oc.DEFAULT_CONFIG)
+    gs, L, H = 0.1, 16.35, 11.15
+    cfg["grid_step"] = gs
+    cfg["hjb_params"]["sigma"] = 2.0                    # noise 1.0 * N(0,1) m/s per step: agents jitter across cell edges
+    Nx, Ny, X0, Y0 = _grid(L, H, gs)
+    rng = np.random.RandomState(4)
+    n = 3000
+    for name, V in _layouts(Ny, Nx, rng).items():
+        if name in ("all_zero", "no_wall_only_target"):
+            continue
+        eng = Engine(cfg, L, H, Nx, Ny, X0, Y0, 1, 4096, dtype="float32", wall_search_radius=radius, field_mode="slices")
+        eng.set_potential(0, V, np.zeros((0, 4)))
+        eng.alloc_field(0, 4)                            # a zero floor field: desired velocity 0, the crowd is driven by noise
+        eng.set_field_horizon(0, 2)
+        px, py = rng.uniform(0.5, L - 0.5, n), rng.uniform(0.5, H - 0.5, n)
+        eng.set_agents(px, py, rng.normal(0, 1.0, n), rng.normal(0, 1.0, n), np.full(n, 1.3), np.zeros(n, dtype=np.int32))
+        eng.set_resort_every(3)                          # incumbents must survive re-sorts (they are kept per agent)
+        assert (eng.wall_last_index().cpu().numpy() == -1).all()
+        n_kept = 0
+        for s in range(12):
+            cold, _ = eng.wall_force()                   # cold search at the positions the step starts from
+            cold = cold.cpu().numpy()
+            prev = eng.wall_last_index().cpu().numpy()
+            eng.step(s, noise=rng.normal(size=(n, 2)))
+            got = eng.wall_last_index().cpu().numpy()
+            assert np.array_equal(got, cold), (name, s, int((got != cold).sum()))
+            if s > 0:
+                n_kept += int(((prev >= 0) & (prev == got)).sum())
+        assert n_kept > 0                                # (warm starts whose incumbent stayed the answer did occur)
+        eng.close()

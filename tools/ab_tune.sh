@@ -1,15 +1,11 @@
-# A/B of launch-shape knobs on the GPU box: bash tools/ab_tune.sh "pair_split=1" "pair_split=2" ...
-# an entry may carry extra bench flags after a space: "pair_split=2 --wall-radius 0.01"
-for t in "$@"; do
-  set -- $t
-  tune=$1; shift
-  tag=$(echo "$t" | tr ' /' '__')
-  timeout -k 10 300 python bench.py --steps 300 --warmup 20 --no-cpu-baseline --tune "$tune" "$@" > "gpurun_out/ab_$tag.log" 2>&1 || { tail -5 "gpurun_out/ab_$tag.log"; exit 1; }
-  python - "$tag" <<'PY'
+# A/B of a launch-shape knob on the C4 step (GPU box): bash tools/ab_tune.sh "<knob>=a" "<knob>=b" ...   [STEPS=300]
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null; mkdir -p gpurun_out
+for v in "$@"; do
+  timeout -k 10 300 python bench.py --steps ${STEPS:-300} --warmup 20 --no-cpu-baseline --no-work-count --no-dense-line ${WL:+--workload $WL} --tune "$v" > gpurun_out/ab_tune.json 2> gpurun_out/ab_tune.err || { echo "$v failed"; tail -3 gpurun_out/ab_tune.err; continue; }
+  python - "$v" <<'PY'
 import json, sys
-t = sys.argv[1]
-d = json.loads([l for l in open('gpurun_out/ab_%s.log' % t) if l.startswith('{')][-1])
-print(t, 'steps/s %.0f' % d['value'], 'gcfm kernel ms/step %.4f' % (d['breakdown']['gcfm_kernel_ms_per_step'] or 0),
-      {k: round(v['avg_ms'], 4) for k, v in d['breakdown']['kernels'].items() if v['avg_ms']})
+d = json.loads([l for l in open('gpurun_out/ab_tune.json') if l.startswith('{')][-1])
+k = d['breakdown']['kernels']
+print('%-24s value %7.0f  forces %6.1f us  finish %5.1f us  solves %.2f ms' % (sys.argv[1], d['value'], 1e3 * k['gcfm_forces']['avg_ms'], 1e3 * k['gcfm_finish']['avg_ms'], 1e3 * d['breakdown']['hjb_solve_s_total_this_rank']))
 PY
 done
