@@ -16,12 +16,12 @@ rep("    const Snap& C = S.snap;\n    const int w = threadIdx.x >> 6, lane = thr
     "    const Snap& C = S.snap;\n    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;\n"
     "    const unsigned long long T0 = __builtin_amdgcn_s_memrealtime();\n"
     "    long long* stamp = S.widx + 2 * ((size_t)blockIdx.x * 4 + w);\n    if ((int)blockIdx.x < nprep) {")
-rep("                prep_tile(P, S, C, keys, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8], mine, mine || sh.lookup_all);\n        }\n        return;",
-    "                prep_tile(P, S, C, keys, step, X0, Y0, t, lane, &S.ctrl[C_ERR + 8], mine, mine || sh.lookup_all);\n        }\n"
+rep("                          sh.prep_lookup != 0 && (mine || sh.lookup_all) && !OC_DIAG(P, 8u));\n        }\n        return;",
+    "                          sh.prep_lookup != 0 && (mine || sh.lookup_all) && !OC_DIAG(P, 8u));\n        }\n"
     "        if (lane == 0) { stamp[0] = (long long)T0; stamp[1] = (long long)__builtin_amdgcn_s_memrealtime(); }\n        return;")
-rep("    if (live && sub == 0) S.f_pair[it * 64 + lane] = make_double2(L.accx[tl][lane], L.accy[tl][lane]);\n}",
-    "    if (live && sub == 0) S.f_pair[it * 64 + lane] = make_double2(L.accx[tl][lane], L.accy[tl][lane]);\n"
-    "    if (lane == 0) { stamp[0] = (long long)T0; stamp[1] = (long long)__builtin_amdgcn_s_memrealtime(); }\n}")
+rep("        xs(S, S.des, S.ts_des, k) = ds;\n    }\n}\n\n#define RECT_TAB",
+    "        xs(S, S.des, S.ts_des, k) = ds;\n    }\n"
+    "    if (lane == 0) { stamp[0] = (long long)T0; stamp[1] = (long long)__builtin_amdgcn_s_memrealtime(); }\n}\n\n#define RECT_TAB")
 rep('    oc_timer_end(h, "gcfm_forces", s);',
     '''    oc_timer_end(h, "gcfm_forces", s);
     if (getenv("OC_WAVE_STAMPS") && (simu_step % 50) == 30) {
@@ -40,6 +40,25 @@ rep('    oc_timer_end(h, "gcfm_forces", s);',
         };
         report("prep", 0, nprep * 4);
         report("pair", nprep * 4, nw);
+        {   // pair blocks by dispatch order (deciles): start, duration, end of their wavefronts and the tiles' measured work
+            std::vector<int> ord(S.ntiles), wk(S.ntiles);
+            (void)hipMemcpy(ord.data(), S.tile_order, 4 * (size_t)S.ntiles, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(wk.data(), S.tile_work, 4 * (size_t)S.ntiles, hipMemcpyDeviceToHost);
+            const int tpbk = 4 / ns;
+            for (int d = 0; d < 10; ++d) {
+                const int b0 = npair * d / 10, b1 = npair * (d + 1) / 10;
+                double st = 0, du = 0, en = 0, enmax = 0, w = 0; int n = 0, nw2 = 0;
+                for (int b = b0; b < b1; ++b) {
+                    for (int q = 0; q < 4; ++q) {
+                        const int wv = (nprep + b) * 4 + q;
+                        const double a = (hb[2 * wv] - tmin) * 0.01, e = (hb[2 * wv + 1] - tmin) * 0.01;
+                        st += a; du += e - a; en += e; enmax = std::max(enmax, e); ++n;
+                    }
+                    for (int q = 0; q < tpbk; ++q) if (b * tpbk + q < S.ntiles) { w += wk[ord[b * tpbk + q]]; ++nw2; }
+                }
+                fprintf(stderr, "[stamps pair decile %d] blocks %d-%d start %.1f dur %.1f end %.1f (max %.1f) work/tile %.0f\\n", d, b0, b1, st / n, du / n, en / n, enmax, w / std::max(nw2, 1));
+            }
+        }
         // resident wavefronts over the launch, in 5 us bins (prep | pair)
         const int nbin = (int)((tmax - tmin) * 0.01 / 5.0) + 1;
         fprintf(stderr, "[stamps resident waves per 5 us bin, prep|pair]");
