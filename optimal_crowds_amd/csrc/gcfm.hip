@@ -32,7 +32,7 @@ struct KeyDev {
     const void* vy;
     const int2* lr;        // [Nx][Ny]: (nearest site column <= j or -1, nearest site column >= j+1 or Nx) of row r
     const float* edt;      // (Ny,Nx) distance from each grid node to the nearest site, capped at edt_cap (lower bound)
-    const int32_t* gap8;   // [Nx][ceil(Ny/8)]: min over 8 grid rows of the column gap to the row's nearest site
+    const int32_t* gap8;   // [Nx][ceil(Ny/8)]: min over 8 grid rows of the column gaps to the row's nearest sites (left | right << 16)
     double off;
     double edt_cap;
     int32_t dtype, nslice_alloc, nt_opt, nrect;
@@ -101,6 +101,7 @@ struct WEntry {
     const int32_t* g8;      // gap8 + jx * nb8
     int32_t b0;             // 8-row block of the nearest grid row
     int32_t prune_ok;       // column-gap bounds valid (agent within one cell of column jx)
+    int32_t jx, pad;        // the agent's column: X0[jx] <= px < X0[jx + 1] inside the room
 };
 
 struct Snap {               // the packed snapshot
@@ -297,6 +298,8 @@ __device__ __forceinline__ bool wall_prepare(const GcfmParams& P, const KeyDev& 
     e.g8 = kd.gap8 + (size_t)jx * ((Ny + 7) >> 3);
     e.b0 = r0 >> 3;
     e.prune_ok = fabs(px - X0[jx]) <= hx;                          // false only for agents outside the room
+    e.jx = jx;
+    e.pad = 0;
     return true;
 }
 
@@ -435,7 +438,8 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void pair_term2(f2v Rx, f2v Ry, float vxi, float vyi, float si, float hxi, float hyi,
                                            float ia2_i, float ib2_i, float inv_vdes_i, f2v vjx, f2v vjy, f2v sj,
                                            f2v ia2_j, f2v hjx, f2v hjy, float b_max, float db,
-                                           float neg_inv_eta_log2e, bool unit_dir, f2v& fx, f2v& fy) {
+                                           float neg_inv_eta_log2e, bool unit_dir, f2v& fx, f2v& fy, bool okA = true,
+                                           bool okB = true) {
     const f2v one = {1.f, 1.f}, zero = {0.f, 0.f};
     const f2v r2 = __builtin_elementwise_fma(Rx, Rx, Ry * Ry);
     const f2v inv_r = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
@@ -467,10 +471,18 @@ __device__ __forceinline__ void pair_term2(f2v Rx, f2v Ry, float vxi, float vyi,
     const f2v arg = dist * (f2v){neg_inv_eta_log2e, neg_inv_eta_log2e} *
                     (f2v){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
     const f2v ex2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-    const f2v rep = __builtin_elementwise_min(kk * ex2, one);
+    f2v rep = __builtin_elementwise_min(kk * ex2, one);
+    // a pair that does not count (beyond the cutoff, coincident, the padding half of an odd entry) is switched off HERE,
+    // one select per pair instead of one per force component and word of its float64 image: rep = 0 makes both components
+    // (-0 * R, R finite) zero
+    rep.x = okA ? rep.x : 0.f;
+    rep.y = okB ? rep.y : 0.f;
     if (unit_dir) {                     // OC_FIX_PAIR_FORCE (wave-uniform): along the unit vector
         fx = -(rep * ex);
         fy = -(rep * ey);
+        // (coincident agents: e = 0 * inf = NaN, and 0 * NaN is NaN -- this variant selects on the components too)
+        fx.x = okA ? fx.x : 0.f; fx.y = okB ? fx.y : 0.f;
+        fy.x = okA ? fy.x : 0.f; fy.y = okB ? fy.y : 0.f;
     } else {                            // the reference scales the distance vector (pedestrians.py:280)
         fx = -(rep * Rx);
         fy = -(rep * Ry);
@@ -773,9 +785,9 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                         pair_term2(Rx, Ry, va.x, va.y, va.z, aux.x,
                                    aux.y, va.w, aux.z, aux.w, (f2v){vbA.x, vbB.x}, (f2v){vbA.y, vbB.y},
                                    (f2v){vbA.z, vbB.z}, (f2v){vbA.w, vbB.w}, (f2v){hbA.x, hbB.x}, (f2v){hbA.y, hbB.y},
-                                   b_max, db, neg_inv_eta_log2e, unit_dir, fx, fy);
-                        sfx += (double)(okA ? fx.x : 0.f) + (double)(okB ? fx.y : 0.f);
-                        sfy += (double)(okA ? fy.x : 0.f) + (double)(okB ? fy.y : 0.f);
+                                   b_max, db, neg_inv_eta_log2e, unit_dir, fx, fy, okA, okB);
+                        sfx += (double)fx.x + (double)fx.y;
+                        sfy += (double)fy.x + (double)fy.y;
                     }
                 }
                 if (il_cur >= 0) {
@@ -800,13 +812,21 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
 // column gap of its rows -- and then visits the marked blocks nearest first: 8 table entries in one batch of loads,
 // pass 1 = smallest squared distance (no square roots), pass 2 = the reference's objective for the candidates inside
 // the tie band.  An agent 12 m from a pillar marks 2-3 blocks in 2 rounds instead of walking ~240 rows.
-#define GAP_NONE (1 << 28)
+// gap8 word of a block of 8 rows: bits 0..15 = the smallest j - (nearest site column <= j), bits 16..31 = the smallest
+// (nearest site column >= j + 1) - j over the block's rows; 0xFFFF = no such site in any of them (gaps saturate at 0xFFFE:
+// a smaller gap is still a lower bound)
+#define GAP_SIDE_NONE 0xFFFF
+#define GAP_NONE ((int)0xFFFFFFFFu)
 // lower bound on the squared distance to any candidate of 8-row block `blk`
 // (a BOUND, evaluated 16 times per round and agent: the rows' coordinates are taken as 8 blk h and 8 blk h + 7 h --
 // within an ulp of the axis values, and past the last row for the room's last block -- and 1 nm is given away instead
-// of selecting among exact axis values; the candidates themselves are measured on the exact axis)
-__device__ __forceinline__ double wall_block_bound(double py, int blk, int gap, bool prune_ok, int Ny, double hx,
-                                                   const Axis Y0, double& dyb2) {
+// of selecting among exact axis values; the candidates themselves are measured on the exact axis).  Horizontally the bound
+// is exact: the nearest candidate column on either side of the agent's column over the block's rows, measured like the
+// candidates themselves (X0[c] - px on the axis values) -- with the gap taken as (gap - 1) cells, as before, a straight
+// wall D away kept every block within sqrt(2 D hx) of the agent's row pending (3-4 visits at D = 7 m); now the blocks
+// that really hold something within the incumbent's distance.
+__device__ __forceinline__ double wall_block_bound(double px, double py, int blk, int gap, bool prune_ok, int jx, int Ny,
+                                                   const Axis X0, const Axis Y0, double& dyb2) {
     double ylo, yhi;
     if (Y0.lin) {
         ylo = (double)(8 * blk) * Y0.h;
@@ -816,8 +836,16 @@ __device__ __forceinline__ double wall_block_bound(double py, int blk, int gap, 
         yhi = Y0.a[min(8 * blk + 7, Ny - 1)];
     }
     const double dyb = fmax(fmax(ylo - py, py - yhi) - 1e-9, 0.0);
-    // every candidate of the block: |dy| >= dyb, |dx| >= (gap - 1) hx (the agent sits within one cell of column jx)
-    const double lbh = prune_ok ? (double)max(gap - 1, 0) * (hx * (1.0 - 1e-9)) : 0.0;
+    // every candidate of the block: |dy| >= dyb, |dx| >= the distance to the nearest candidate column of either side
+    double lbh = 0.0;
+    if (prune_ok) {
+        const int gl = gap & 0xFFFF, gr = (int)((unsigned)gap >> 16);
+        const double dl = (gl != GAP_SIDE_NONE) ? fabs(px - X0[jx - gl]) : INFINITY;
+        const double dr = (gr != GAP_SIDE_NONE) ? fabs(X0[jx + gr] - px) : INFINITY;
+        lbh = fmin(dl, dr);
+    } else if (gap == GAP_NONE) {
+        lbh = INFINITY;                         // no site in the block's rows at all
+    }
     dyb2 = dyb * dyb;
     return dyb2 + lbh * lbh;
 }
@@ -887,8 +915,8 @@ __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEnt
                                                  const Axis Y0, long long prev_flat = -1) {
     const double px = we.px, py = we.py;
     const int Nx = P.Nx, Ny = P.Ny, nb8 = (Ny + 7) >> 3;
-    const double hx = P.L / (Nx - 1);
     const double lim2 = we.lim2, off = we.off;
+    const int jx = we.jx;
     const int2* __restrict__ col = we.col;
     const int32_t* __restrict__ g8 = we.g8;
     const int b0 = we.b0;
@@ -924,7 +952,7 @@ __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEnt
                 if (bu >= nb8) up = false;
                 else {
                     double dyb2;
-                    const double lb = wall_block_bound(py, bu, gap[2 * q], prune_ok, Ny, hx, Y0, dyb2);
+                    const double lb = wall_block_bound(px, py, bu, gap[2 * q], prune_ok, jx, Ny, X0, Y0, dyb2);
                     if (dyb2 > cut0) up = false;                    // every farther block is farther still
                     else if (!(lb > cut0)) pending |= 1u << (2 * q);
                 }
@@ -933,7 +961,7 @@ __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEnt
                 if (bd < 0) dn = false;
                 else {
                     double dyb2;
-                    const double lb = wall_block_bound(py, bd, gap[2 * q + 1], prune_ok, Ny, hx, Y0, dyb2);
+                    const double lb = wall_block_bound(px, py, bd, gap[2 * q + 1], prune_ok, jx, Ny, X0, Y0, dyb2);
                     if (dyb2 > cut0) dn = false;
                     else if (!(lb > cut0)) pending |= 1u << (2 * q + 1);
                 }
@@ -950,7 +978,7 @@ __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEnt
 #pragma unroll
                 for (int z = 0; z < 16; ++z) gsel = (z == slot) ? gap[z] : gsel;
                 double dyb2;
-                const double lb = wall_block_bound(py, blk, gsel, prune_ok, Ny, hx, Y0, dyb2);
+                const double lb = wall_block_bound(px, py, blk, gsel, prune_ok, jx, Ny, X0, Y0, dyb2);
                 const double cut = fmin(thr, lim2);
                 if (dyb2 > cut) {                                   // this direction is finished
                     if (slot & 1) { dn = false; pending &= 0x55555555u; }
@@ -1006,6 +1034,8 @@ __global__ void __launch_bounds__(64) k_edt_nodes(GcfmParams P, const int2* __re
     we.g8 = gap8 + (size_t)j * ((Ny + 7) >> 3);
     we.b0 = i >> 3;
     we.prune_ok = 1;
+    we.jx = j;
+    we.pad = 0;
     const long long flat = wall_search(P, we, go, X0, Y0);
     if (!go) return;
     double d = INFINITY;
@@ -1145,8 +1175,10 @@ template <typename T>
 __device__ __forceinline__ T ring_phi(const RingCtx<T>& c, int r, int cc) {
     // (the loads are issued whatever the flag says -- a trivial tile's slot memory exists, its content is simply not used --
     // so that the five cells' flags and values of a lookup are all in flight together: one level of latency)
-    const T* b = c.slot + ((size_t)r * c.Nx + cc >> 2) * (4 * OC_RING_VALS) + (cc & 3);
-    const T y = b[0], q0 = b[4], q1 = b[8], q2 = b[12], q3 = b[16];
+    const size_t ci = (size_t)r * c.Nx + cc, rn = (size_t)c.rows * c.Nx;
+    const T* b = c.slot;
+    const T y = b[oc_ring_off(ci, 0, rn)], q0 = b[oc_ring_off(ci, 1, rn)], q1 = b[oc_ring_off(ci, 2, rn)],
+            q2 = b[oc_ring_off(ci, 3, rn)], q3 = b[oc_ring_off(ci, 4, rn)];
     const bool triv = c.first != nullptr && c.slot_index < c.first[(r / OC_RING_STY) * c.tnbx + cc / OC_RING_STX];
     T ph = y + fma_t(q3, c.h4, fma_t(q2, c.h3, fma_t(q1, c.h2, q0 * c.h1)));
     ph = triv ? c.u : ph;               // (u + h (0 x + 0 x^2 + ...) = u)
@@ -1775,19 +1807,19 @@ __global__ void k_wallmap(const float* __restrict__ V, float vmin, int Ny, int N
     }
 }
 
-// gap8[j][b] = min over rows 8b..8b+7 of min(j - left site column, right site column - j) (GAP_NONE: no site at all)
+// gap8[j][b] = (min over rows 8b..8b+7 of j - left site column) | (min of right site column - j) << 16  (see GAP_NONE)
 __global__ void __launch_bounds__(256) k_gap8(const int2* __restrict__ lr, int Nx, int Ny, int32_t* __restrict__ gap8) {
     const int nb8 = (Ny + 7) >> 3;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)Nx * nb8) return;
     const int j = (int)(t / nb8), b = (int)(t % nb8);
-    int g = GAP_NONE;
+    int gl = GAP_SIDE_NONE, gr = GAP_SIDE_NONE;
     for (int r = 8 * b; r < min(8 * b + 8, Ny); ++r) {
         const int2 c = lr[(size_t)j * Ny + r];
-        if (c.x >= 0) g = min(g, j - c.x);
-        if (c.y < Nx) g = min(g, c.y - j);
+        if (c.x >= 0) gl = min(gl, min(j - c.x, GAP_SIDE_NONE - 1));
+        if (c.y < Nx) gr = min(gr, min(c.y - j, GAP_SIDE_NONE - 1));
     }
-    gap8[t] = g;
+    gap8[t] = (int32_t)((unsigned)gl | ((unsigned)gr << 16));
 }
 
 // ---------------------------------------------------------------------------------- host helpers

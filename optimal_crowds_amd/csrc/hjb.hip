@@ -265,6 +265,13 @@ __global__ void k_norm_scaled(const T* __restrict__ a, const T* __restrict__ b, 
     block_reduce_store(s, 0.0, partial);
 }
 
+// One cell's term of the error norm, error / scale (scipy rk.py:146-147, common.py:63-66): the IEEE quotient in every
+// variant.  (The hardware reciprocal -- two instructions where the division expands to ten -- was tried for float: the
+// attempt sequence of a stability-limited solve is sensitive to the last bit of this norm, the full-size comparisons with
+// the forced-step oracle moved by their whole tolerance, and a denormal scale at the end of fp32's range gave 0 * inf.)
+template <typename T>
+__device__ __forceinline__ T err_quot(T e, T sc) { return e / sc; }
+
 // error norm of a step (scipy rk.py:146-147) + max |y_new| for range management
 template <typename T>
 __global__ void k_err_norm(const T* __restrict__ y, const T* __restrict__ ynew, Lin8<T> E /* h*E_j */, T atol,
@@ -277,7 +284,7 @@ __global__ void k_err_norm(const T* __restrict__ y, const T* __restrict__ ynew, 
             if (j < E.n) e = fma_t(E.c[j], E.k[j][i], e);
         T yn = ynew[i];
         T sc = atol + fmax(fabs(y[i]), fabs(yn)) * rtol;
-        T v = e / sc;
+        T v = err_quot(e, sc);
         s += (double)v * (double)v;
         mx = fmax(mx, (double)fabs(yn));
     }
@@ -685,6 +692,21 @@ __device__ __forceinline__ void st4_nt(T* p, const V4<T>& x) {      // streaming
     __builtin_nontemporal_store(v, reinterpret_cast<vt*>(p));
 }
 
+// a vector of the interpolant ring (k_stageV).  Planar layout: whole lines per wavefront row, written once and read back by
+// a few lookups only -> streaming stores (OC_RING_NT 0: plain).  Interleaved layout: plain stores, which the L2 merges (as
+// streaming stores its 16-byte pieces at an 80-byte stride went out as partial writes: 147 us per launch at 2048 x 2048).
+#ifndef OC_RING_NT
+#define OC_RING_NT OC_RING_PLANAR
+#endif
+template <typename T>
+__device__ __forceinline__ void st4_ring(T* p, const V4<T>& x) {
+#if OC_RING_NT
+    st4_nt(p, x);
+#else
+    st4(p, x);
+#endif
+}
+
 template <typename T>
 struct StageArgs {
     const T* y;
@@ -811,7 +833,7 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs<T> A) {
 #pragma unroll
                 for (int j = 0; j < S; ++j) e = fma_t(A.he[j], kreg[j].v[q], e);
                 const T sc = A.atol + fmax(fabs(yv.v[q]), fabs(tv.v[q])) * A.rtol;
-                const T qq = e / sc;
+                const T qq = err_quot(e, sc);
                 esum += (double)qq * (double)qq;
                 ymax = fmax(ymax, (double)fabs(tv.v[q]));
             }
@@ -1204,13 +1226,15 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             // RING: y (its pending rescale applied, as k_out applies it), K0 and Q1 .. Q3 go to the step's ring slot instead
             // -- 20 consecutive values per thread -- and nothing reads them before a lookup or the slice writer does.
             constexpr int rows[6] = {0, 2, 3, 4, 5, 6};
-            T* const rb = RING ? A.ring + (size_t)rslot * A.ring_slot_elems + (size_t)idx * OC_RING_VALS : nullptr;
+            // (idx is a multiple of 4: the thread's vector; value a of its four cells at rb + oc_ring_off(idx, a, n))
+            T* const rb = RING ? A.ring + (size_t)rslot * A.ring_slot_elems : nullptr;
+            const size_t rn = A.ring_slot_elems / OC_RING_VALS;
             // (plain stores: a thread's five 16-byte pieces are consecutive, a wavefront's 5 KB are contiguous -- the L2 merges them
             // into whole lines; as nontemporal stores each instruction's 16-byte pieces at an 80-byte stride went out as
             // partial writes: 147 us per launch at 2048 x 2048 with every tile computed)
             if (RING && ring_ok) {
-                st4(rb, quad(yv[0], yv[1]));
-                st4(rb + 4, quad(kv[0][0], kv[0][1]));
+                st4_ring(rb + oc_ring_off((size_t)idx, 0, rn), quad(yv[0], yv[1]));
+                st4_ring(rb + oc_ring_off((size_t)idx, 1, rn), quad(kv[0][0], kv[0][1]));
             }
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp) {
@@ -1222,7 +1246,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                     q1 = __builtin_elementwise_fma(kv[rows[j]][1], p2, q1);
                 }
                 if (!RING) st4(A.KM[1 + pp] + idx, quad(q0, q1));
-                else if (ring_ok) st4(rb + 8 + 4 * pp, quad(q0, q1));
+                else if (ring_ok) st4_ring(rb + oc_ring_off((size_t)idx, 2 + pp, rn), quad(q0, q1));
             }
             st4(A.KX[par ^ 1] + idx, quad(kv[NK - 1][0], kv[NK - 1][1]));     // K6 = the next step's K0 (FSAL)
         } else {
@@ -1242,7 +1266,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         const T sc = atol_s + fmax(fabs(y2[c]), fabs(t2[c])) * A.rtol;
-                        const T qq = e2[c] / sc;
+                        const T qq = err_quot(e2[c], sc);
                         esum += (double)qq * (double)qq;
                         ymax = fmax(ymax, (double)fabs(t2[c]));
                     }
@@ -1251,22 +1275,27 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         }
     }
     if (FINAL) {
-        __shared__ double ls[NT / 64], lm[NT / 64];
-        esum = wave_sum(esum);
-        ymax = wave_max(ymax);
-        if ((threadIdx.x & 63) == 0) {
-            ls[threadIdx.x >> 6] = esum;
-            lm[threadIdx.x >> 6] = ymax;
-        }
+        // The block's error share and max |y_new|: every thread leaves its pair in the tile buffer the last stage did not
+        // use (all reads of it ended before that stage's barrier), ONE wavefront adds them up -- 16 cross-lane float64
+        // reductions (12 ds_bpermute round trips each) per block became one; the launch is bound by instruction issue.
+        static_assert(sizeof(buf) / 2 >= sizeof(double2) * NT, "the reduction's pairs fit one tile buffer");
+        double2* const red = reinterpret_cast<double2*>(&buf[NQ & 1][0][0]);
+        red[threadIdx.x] = make_double2(esum, ymax);
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < 64) {
             double a = 0.0, b = 0.0;
+#pragma unroll
             for (int q = 0; q < NT / 64; ++q) {
-                a += ls[q];
-                b = fmax(b, lm[q]);
+                const double2 v = red[threadIdx.x + 64 * q];
+                a += v.x;
+                b = fmax(b, v.y);
             }
-            st_part(A.partial + 2 * logical, a);
-            st_part(A.partial + 2 * logical + 1, b);
+            a = wave_sum(a);
+            b = wave_max(b);
+            if (threadIdx.x == 0) {
+                st_part(A.partial + 2 * logical, a);
+                st_part(A.partial + 2 * logical + 1, b);
+            }
         }
         if (FUSED) {
             __syncthreads();            // (the tail reuses the tile buffers and the reduction's LDS words)
@@ -1304,25 +1333,24 @@ struct OutArgs {
 
 template <typename T, bool QIN, bool RING = false>
 __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* const (&k)[6], const T (&P)[6][4],
-                                              T in_scale, int64_t idx, int n, V4<T>& yq, V4<T> (&Q)[4]) {
+                                              T in_scale, int64_t idx, int n, V4<T>& yq, V4<T> (&Q)[4], size_t rn = 0) {
     if (RING) {
         // y = a ring slot (blocks of y[4], K0[4], Q1[4], Q2[4], Q3[4] per four cells, oc_internal.h): the values k_stageV
         // stored, the rescale already applied -- what the other branch holds after its loads and multiplications
+        // (rn: cells per slot -- the plane stride of the planar layout, oc_internal.h)
         if (n == 4) {
-            const T* b = y + idx * OC_RING_VALS;
-            yq = ld4(b);
+            yq = ld4(y + oc_ring_off((size_t)idx, 0, rn));
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) Q[pp] = ld4(b + 4 + 4 * pp);
+            for (int pp = 0; pp < 4; ++pp) Q[pp] = ld4(y + oc_ring_off((size_t)idx, 1 + pp, rn));
         } else {
-            const T* b = y + (idx >> 2) * (4 * OC_RING_VALS) + (idx & 3);
 #pragma unroll
             for (int q = 0; q < 4; ++q) yq.v[q] = (T)0;
-            yq.v[0] = b[0];
+            yq.v[0] = y[oc_ring_off((size_t)idx, 0, rn)];
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Q[pp].v[q] = (T)0;
-                Q[pp].v[0] = b[4 + 4 * pp];
+                Q[pp].v[0] = y[oc_ring_off((size_t)idx, 1 + pp, rn)];
             }
         }
         return;
@@ -1541,16 +1569,16 @@ __global__ void __launch_bounds__(256) k_ring_fill(const HjbCtl<T>* __restrict__
     for (int q = threadIdx.x; q < VPR * OC_RING_STY; q += blockDim.x) {
         const int r = r0 + q / VPR, c = c0 + 4 * (q % VPR);
         if (r >= Ny || c >= Nx) continue;
-        T* b = slot_data + ((size_t)r * Nx + c) * OC_RING_VALS;
+        const size_t ci = (size_t)r * Nx + c, rn = (size_t)Ny * Nx;
         V4<T> uu, z;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             uu.v[e] = u;
             z.v[e] = (T)0;
         }
-        st4(b, uu);
+        st4(slot_data + oc_ring_off(ci, 0, rn), uu);
 #pragma unroll
-        for (int a = 1; a < OC_RING_VALS; ++a) st4(b + 4 * a, z);
+        for (int a = 1; a < OC_RING_VALS; ++a) st4(slot_data + oc_ring_off(ci, a, rn), z);
     }
 }
 
@@ -1613,7 +1641,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> 
         }
     }
     V4<T> yq, Q[4], hy, hQ[4];
-    if (valid) interp_coeffs<T, QIN, RING>(y, kk, A.p, in_scale, idx, 4, yq, Q);
+    if (valid) interp_coeffs<T, QIN, RING>(y, kk, A.p, in_scale, idx, 4, yq, Q, A.slice_elems);
     // halo of the tile: threads 0 .. VW-1 the row above (a vector each), the next VW the row below, then OY threads the
     // column to the left and OY the column to the right (a cell each); cells outside the grid are never used
     HaloRole hr;
@@ -1628,7 +1656,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 3) k_out(OutArgs<T> 
         if (!(hr.gi >= 0 && hr.gi < Ny && hr.gj >= 0 && hr.gj < Nx)) hr.kind = 0;
     }
     const int hn = (hr.kind == 1 || hr.kind == 2) ? 4 : (hr.kind >= 3 ? 1 : 0);
-    if (hn) interp_coeffs<T, QIN, RING>(y, kk, A.p, in_scale, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ);
+    if (hn) interp_coeffs<T, QIN, RING>(y, kk, A.p, in_scale, (int64_t)hr.gi * Nx + hr.gj, hn, hy, hQ, A.slice_elems);
     auto clip = [&](T v) { return (v > lim_s) ? v : ((v < lim_s) ? lim_s : (T)0); };
     // the controller's per-slice factors: fetched once (a load from the controller block inside the slice loop would
     // put a memory round trip into every slice)

@@ -43,6 +43,22 @@ void oc_set_error(const char* fmt, ...);
 //          first[t] = the first slot in which tile t was computed (INT_MAX-like: never) -- trivial in slot s <=> s < first[t].
 //   meta   OcRingHead | OcRingSlot<T> x slots | OcRingSlice<T> x nslice | int32 first[stage tiles]
 #define OC_RING_VALS 5
+// Layout of a slot's values.  OC_RING_PLANAR 1: five planes of rows x Nx values (y | K0 | Q1 | Q2 | Q3) -- every store of the
+// stage kernel is a contiguous 16 B per lane, whole lines per wavefront row; a lookup cell's five values come from five lines.
+// 0: blocks of 20 values per four cells (y[4], K0[4], Q1[4], Q2[4], Q3[4]) -- one or two lines per lookup cell, but each
+// store instruction of the stage kernel writes 16-byte pieces at an 80-byte stride.
+#ifndef OC_RING_PLANAR
+#define OC_RING_PLANAR 1
+#endif
+// offset of value a (0 .. 4) of cell idx (= local row * Nx + column) in a slot of n = rows * Nx cells
+__host__ __device__ inline size_t oc_ring_off(size_t idx, int a, size_t n) {
+#if OC_RING_PLANAR
+    return (size_t)a * n + idx;
+#else
+    (void)n;
+    return (idx >> 2) * (4 * OC_RING_VALS) + 4 * (size_t)a + (idx & 3);
+#endif
+}
 #define OC_RING_STX 112          // stage tile of the product path (k_stageV<T, 6, 1, true, 32, 32>): 112 x 20 cells
 #define OC_RING_STY 20
 struct OcRingHead {
