@@ -71,13 +71,10 @@ def build_sim(workload, seed=20240807, wall_search_radius=-1.0, sharding=None, d
 
 
 def solve_round(sim):
-    """what run() does before the first step: one HJB solve per key (m = 0 at step 0).  Sharded: a rank solves only
-    the keys (or row blocks of keys) its group holds; the others' stats are None."""
-    stats = []
-    for k, key in enumerate(sim._key_names):
-        st, _ = sim._engine.solve(k, sim.T, sim._nt0, m=None)
-        stats.append(st)
-    return stats
+    """what run() does before the first step: one HJB solve per key (m = 0 at step 0) -- Engine.solve_keys, as the facade's
+    run() calls it: keys whose whole grid lives on this GPU are solved concurrently.  Sharded: a rank solves only the keys
+    (or row blocks of keys) its group holds; the others' stats are None."""
+    return sim._engine.solve_keys([(k, sim.T, sim._nt0, None) for k in range(len(sim._key_names))])
 
 
 def run_steps(sim, K, nt, timed_stats=None, update="synchronous", levels=None):
@@ -96,7 +93,7 @@ def run_steps(sim, K, nt, timed_stats=None, update="synchronous", levels=None):
             # run() with recompute=True (simulations.py:432-435): density of the current crowd, then every key again
             # on the shrunken horizon nt = round((T - t) / dt)  (quirk Q9)
             m = sim._density_dev(sim.sigma_convolution)
-            st = [eng.solve(k, sim.T, round((sim.T - s * sim.dt) / sim.dt), m=m)[0] for k in range(len(sim._key_names))]
+            st = eng.solve_keys([(k, sim.T, round((sim.T - s * sim.dt) / sim.dt), m) for k in range(len(sim._key_names))])
             if timed_stats is not None:
                 timed_stats.append(st)
         if update == "sequential":

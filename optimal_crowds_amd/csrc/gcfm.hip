@@ -24,6 +24,7 @@
 #include "oc_internal.h"
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -749,8 +750,12 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 // the chunk's sums are float64: every pair's float32 force is added exactly, so the result does not
                 // depend on how the launch shape (pair_split, chunk boundaries) groups the pairs
                 double sfx = 0.0, sfy = 0.0;
+                // (the NEXT entry's word is fetched one trip ahead: list word -> record addresses -> records are two dependent
+                // LDS round trips per entry otherwise; a word past the chunk's end is read and dropped -- the list has room)
+                uint32_t e_nxt = lst[min(e_beg, PAIR_LIST_CAP - 1)];
                 for (int tt = e_beg; tt < (OC_DIAG(P, 1u) ? e_beg : e_end); ++tt) {
-                    const uint32_t e = lst[tt];
+                    const uint32_t e = e_nxt;
+                    e_nxt = lst[min(tt + 1, PAIR_LIST_CAP - 1)];
                     const int il = e >> 16, jA = e & 127, jB = (e >> 7) & 127;
                     const double2 pbA = L.l_pos[w][jA], pbB = L.l_pos[w][jB];
                     const float4 vbA = L.l_vel[w][jA], vbB = L.l_vel[w][jB];
@@ -912,7 +917,7 @@ __device__ __forceinline__ void wall_block_eval(double px, double py, int blk, c
 // search then only has to look where something can still beat or tie it (exactly the reference's cell either way: an
 // incumbent is one more candidate, met again when its block is visited).
 __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEntry& we, bool go, const Axis X0,
-                                                 const Axis Y0, long long prev_flat = -1) {
+                                                 const Axis Y0, long long prev_flat = -1, int32_t* diag_cnt = nullptr) {
     const double px = we.px, py = we.py;
     const int Nx = P.Nx, Ny = P.Ny, nb8 = (Ny + 7) >> 3;
     const double lim2 = we.lim2, off = we.off;
@@ -934,7 +939,13 @@ __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEnt
         }
     }
     bool up = go, dn = go;
+#ifdef OC_DIAG_BUILD
+    int d_rounds = 0, d_visits = 0, d_myvis = 0;
+#endif
     for (int o = 0; __any(up || dn); o += 8) {
+#ifdef OC_DIAG_BUILD
+        ++d_rounds;
+#endif
         // ---- this round's 16 blocks: slot 2q = up-block b0 + o + q, slot 2q + 1 = down-block b0 - 1 - o - q
         int gap[16];
 #pragma unroll
@@ -969,6 +980,10 @@ __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEnt
         }
         // ---- visit the marked blocks, nearest first (slots are ordered by distance within a direction)
         while (__any(pending != 0u)) {
+#ifdef OC_DIAG_BUILD
+            ++d_visits;
+            d_myvis += pending ? 1 : 0;
+#endif
             if (pending) {
                 const int slot = __ffs((int)pending) - 1;
                 pending &= pending - 1u;
@@ -1013,6 +1028,20 @@ __device__ __forceinline__ long long wall_search(const GcfmParams& P, const WEnt
             }
         }
     }
+#ifdef OC_DIAG_BUILD
+    if (diag_cnt != nullptr) {          // [8] rounds of the wavefront, [9] its visit trips, [10] wavefronts, [11] lanes searching,
+        const unsigned long long mg = __ballot(go);                                  // [12] block visits summed over the lanes
+        int tot = d_myvis;
+        for (int o2 = 32; o2 > 0; o2 >>= 1) tot += __shfl_xor(tot, o2, 64);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&diag_cnt[8], d_rounds);
+            atomicAdd(&diag_cnt[9], d_visits);
+            atomicAdd(&diag_cnt[10], 1);
+            atomicAdd(&diag_cnt[11], __popcll(mg));
+            atomicAdd(&diag_cnt[12], tot);
+        }
+    }
+#endif
     return best_flat;
 }
 
@@ -1404,7 +1433,8 @@ __device__ __forceinline__ void prep_tile(const GcfmParams& P, const Scratch& S,
     if (do_wall) {
         WEntry we = {};
         const bool need = act && wall_prepare(P, kd, X0, Y0, p.x, p.y, (double)C.pvel[k].z, we);
-        const long long widx = wall_search(P, we, need, X0, Y0, (need && S.wprev != nullptr) ? (long long)S.wprev[i] : -1);
+        const long long widx = wall_search(P, we, need, X0, Y0, (need && S.wprev != nullptr) ? (long long)S.wprev[i] : -1,
+                                           S.seq_ctl);
         if (act && S.wprev != nullptr) S.wprev[i] = need ? (int32_t)widx : -1;
         double2 fw = make_double2(0.0, 0.0);
         if (act) fw = wall_force_of(P, widx, p.x, p.y, v.x, v.y, dk.v_des, X0, Y0);
@@ -2251,6 +2281,17 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
     if (h->any_ring) h->ring_step_ready = (int64_t)simu_step + 1;
     oc_timer_end(h, "gcfm_finish", s);
     OC_HIP_CHECK(hipGetLastError());
+#ifdef OC_DIAG_BUILD
+    if (getenv("OC_WALL_COUNTS") && (simu_step % 100) == 50) {
+        int32_t c[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(c, S.seq_ctl, sizeof(c), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[wall counts up to step %d] wavefronts %d: rounds %.2f, visit trips %.2f per wavefront; lanes searching %.1f per "
+                "wavefront, block visits %.2f per searching lane\n", simu_step, c[10], (double)c[8] / c[10], (double)c[9] / c[10],
+                (double)c[11] / c[10], (double)c[12] / std::max(c[11], 1));
+        (void)hipMemset(S.seq_ctl + 8, 0, 5 * sizeof(int32_t));
+    }
+#endif
     h->packed_valid = true;
     h->packed_seq = false;          // (held to the synchronous step's drift bound only)
     ++h->steps_since_sort;

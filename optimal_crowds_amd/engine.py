@@ -9,6 +9,8 @@ Buffers in HBM (row-major, N agents, K keys, grid Ny x Nx, nt0 = round(T/dt)):
   x,y,vx,vy,v_des,agent_time float64 (N);  status uint8 (N);  key int32 (N)
 """
 import ctypes as C
+import os
+import threading
 
 import numpy as np
 import torch
@@ -123,6 +125,14 @@ class Engine:
         check(self.lib.oc_create(self.dev_index, C.byref(c), X0.ctypes.data_as(C.c_void_p),
                                  Y0.ctypes.data_as(C.c_void_p), C.byref(h)))
         self.h = h
+        self._axes = (X0, Y0)
+        # independent keys' solves run concurrently (solve_keys): lane 0 = this handle on the caller's stream, lanes 1.. =
+        # auxiliary handles (their own HJB scratch) on their own streams, created by the first call that needs them
+        self._lanes = []
+        self._tuning = {}
+        self._hjb_variant = 0
+        self._prof_mode = 0
+        self.overlap_solves = os.environ.get("OC_OVERLAP_SOLVES", "1") != "0"
         self.V = [None] * n_keys
         self.fields = [None] * n_keys
         self.coef = torch.empty((Ny, Nx), dtype=self.tdtype, device=self.device)
@@ -134,6 +144,9 @@ class Engine:
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
             torch.cuda.synchronize(self.device)
+            for ln in getattr(self, "_lanes", []):
+                self.lib.oc_destroy(ln["h"])
+            self._lanes = []
             self.lib.oc_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -148,16 +161,25 @@ class Engine:
 
     def set_profiling(self, mode=3):
         """mode bits: 1 HJB kernels, 2 GCFM kernels every step, 4 GCFM kernels every 16th step; 0/False off."""
+        self._prof_mode = int(mode)
         check(self.lib.oc_set_profiling(self.h, int(mode)))
+        for ln in self._lanes:
+            check(self.lib.oc_set_profiling(ln["h"], int(mode)))
 
     def kernel_stats(self, name):
-        """(launches, total_ms, total_algorithmic_bytes) of a kernel class since the last reset."""
-        n, ms, by = C.c_int64(), C.c_double(), C.c_double()
-        check(self.lib.oc_kernel_stats(self.h, name.encode(), C.byref(n), C.byref(ms), C.byref(by)))
-        return n.value, ms.value, by.value
+        """(launches, total_ms, total_algorithmic_bytes) of a kernel class since the last reset (summed over the handles
+        of concurrent solves, solve_keys)."""
+        tot = [0, 0.0, 0.0]
+        for h in [self.h] + [ln["h"] for ln in self._lanes]:
+            n, ms, by = C.c_int64(), C.c_double(), C.c_double()
+            check(self.lib.oc_kernel_stats(h, name.encode(), C.byref(n), C.byref(ms), C.byref(by)))
+            tot = [tot[0] + n.value, tot[1] + ms.value, tot[2] + by.value]
+        return tuple(tot)
 
     def reset_kernel_stats(self):
         check(self.lib.oc_reset_kernel_stats(self.h))
+        for ln in self._lanes:
+            check(self.lib.oc_reset_kernel_stats(ln["h"]))
 
     def set_resort_every(self, steps):
         check(self.lib.oc_set_resort_every(self.h, int(steps)))
@@ -167,6 +189,9 @@ class Engine:
         check(self.lib.oc_agents_changed(self.h))
 
     def set_hjb_variant(self, variant):
+        self._hjb_variant = int(variant)
+        for ln in self._lanes:
+            check(self.lib.oc_set_hjb_variant(ln["h"], int(variant)))
         check(self.lib.oc_set_hjb_variant(self.h, int(variant)))
         if int(variant) != 0:               # the cross-check variants write slices
             self.field_mode = "slices"
@@ -174,6 +199,10 @@ class Engine:
     def set_tuning(self, name, value):
         """Launch-shape knobs of the step kernels (oc_hip.h: oc_set_tuning)."""
         check(self.lib.oc_set_tuning(self.h, name.encode(), int(value)))
+        self._tuning[name] = int(value)
+        if name.startswith("hjb_") or name == "out_tile":       # (the solves' knobs also go to the concurrent solves' handles)
+            for ln in self._lanes:
+                check(self.lib.oc_set_tuning(ln["h"], name.encode(), int(value)))
 
     def set_fix_flags(self, names):
         """Opt-in corrections of reference quirks: an iterable of 'lookup', 'wall_force', 'pair_force',
@@ -385,7 +414,21 @@ class Engine:
             f.nt = nt
             self._register_field(key)
             return st, phi_keep
-        self.make_coef(key, m)
+        st, phi_keep = self._solve_whole(key, T, nt, m, keep, want_steps, None)
+        f.nt = nt
+        self._register_field(key)
+        return st, phi_keep
+
+    def _solve_whole(self, key, T, nt, m, keep, want_steps, lane):
+        """the library call of a whole-grid solve of `key` on a lane (None: this handle, its coef buffer, the caller's
+        stream; else a dict of solve_keys: handle, coef buffer -- the caller has made the lane's stream current).  Does not
+        touch the handle's key tables: the caller registers the field afterwards."""
+        f = self.fields[key]
+        h = self.h if lane is None else lane["h"]
+        coef = self.coef if lane is None else lane["coef"]
+        if m is not None:
+            m = m.to(device=self.device, dtype=self.tdtype).contiguous()
+        check(self.lib.oc_hjb_make_coef(h, self.dtype, _ptr(self.V[key]), _ptr(m), _ptr(coef), self.stream()))
         stats = OcHjbStats()
         keep_arr = phi_keep = None
         n_keep = 0
@@ -401,7 +444,7 @@ class Engine:
             f.vx = f.vy = None                      # (a materialised copy of the previous solve)
             ring = self._ring(key, T)
             while True:
-                rcode = self.lib.oc_hjb_solve_ring(self.h, self.solve_dtype, _ptr(self.coef), float(T), int(nt),
+                rcode = self.lib.oc_hjb_solve_ring(h, self.solve_dtype, _ptr(coef), float(T), int(nt),
                                                    C.byref(ring["struct"]), kp, n_keep, _ptr(phi_keep), tp, cap,
                                                    C.byref(stats), self.stream())
                 if rcode != OC_ERR_CAPACITY:
@@ -409,14 +452,83 @@ class Engine:
                 ring = self._ring(key, T, grow=True)        # more accepted steps than slots: a larger ring, again
             check(rcode)
         else:
-            check(self.lib.oc_hjb_solve(self.h, self.solve_dtype, _ptr(self.coef), float(T), int(nt), _ptr(f.vx), _ptr(f.vy),
+            check(self.lib.oc_hjb_solve(h, self.solve_dtype, _ptr(coef), float(T), int(nt), _ptr(f.vx), _ptr(f.vy),
                                         kp, n_keep, _ptr(phi_keep), tp, cap, C.byref(stats), self.stream()))
-        f.nt = nt
-        self._register_field(key)
         st = stats.as_dict()
         if want_steps:
             st["t_steps"] = tsteps[:st["n_accept"] + 1].copy()
         return st, phi_keep
+
+    # ------------------------------------------------------------------ independent keys solved concurrently
+    def _lane(self, i):
+        """lane i >= 1 of solve_keys: an auxiliary handle (same configuration; it only ever runs HJB solves, so what it
+        allocates is the solver's scratch -- 12 state arrays), a stream and a coef buffer of its own"""
+        while len(self._lanes) < i:
+            h = C.c_void_p()
+            check(self.lib.oc_create(self.dev_index, C.byref(self.cfg_struct), self._axes[0].ctypes.data_as(C.c_void_p),
+                                     self._axes[1].ctypes.data_as(C.c_void_p), C.byref(h)))
+            check(self.lib.oc_set_hjb_variant(h, self._hjb_variant))
+            for name, value in self._tuning.items():
+                if name.startswith("hjb_") or name == "out_tile":
+                    check(self.lib.oc_set_tuning(h, name.encode(), value))
+            check(self.lib.oc_set_profiling(h, self._prof_mode))
+            self._lanes.append(dict(h=h, stream=torch.cuda.Stream(device=self.device),
+                                    coef=torch.empty((self.Ny, self.Nx), dtype=self.tdtype, device=self.device)))
+        return self._lanes[i - 1]
+
+    def solve_keys(self, jobs, max_lanes=4):
+        """Solve several keys: jobs = [(key, T, nt, m), ...] -> list of stats (None for a key another rank group holds).
+        The reference solves its keys one after the other (simulations.py:419-420, 432-435); the solves are independent,
+        and with the interpolant ring and the exact active set one of them is a chain of ~100 short, latency-bound
+        launches that leaves most of the chip idle -- so keys whose whole grid lives on this GPU are solved CONCURRENTLY,
+        each on its own handle and stream from its own host thread (the library call is synchronous; ctypes releases the
+        GIL).  Same kernels, same arithmetic, same results as solve() key by key (tests/test_hip_ring.py).
+        OC_OVERLAP_SOLVES=0 / overlap_solves = False: one after the other."""
+        jobs = list(jobs)
+        par = [q for q, (key, T, nt, m) in enumerate(jobs)
+               if self.holds_key(key) and self._key_rows(key) is None and nt - 1 <= self.fields[key].nslice]
+        if not self.overlap_solves or len(par) < 2:
+            return [self.solve(key, T, nt, m=m)[0] for key, T, nt, m in jobs]
+        out = [None] * len(jobs)
+        for q, (key, T, nt, m) in enumerate(jobs):      # (row blocks / keys held elsewhere: the ordinary path, first)
+            if q not in par:
+                out[q] = self.solve(key, T, nt, m=m)[0]
+        n_lanes = min(len(par), max(int(max_lanes), 1))
+        lanes = [None] + [self._lane(i) for i in range(1, n_lanes)]
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)                  # the potentials, the density and the last steps' lookups of the old rings
+        errs = [None] * n_lanes
+
+        def work(li):
+            try:
+                torch.cuda.set_device(self.device)
+                ln = lanes[li]
+                st = main if ln is None else ln["stream"]
+                with torch.cuda.stream(st):
+                    if ln is not None:
+                        st.wait_event(ready)
+                    for q in par[li::n_lanes]:
+                        key, T, nt, m = jobs[q]
+                        out[q] = self._solve_whole(key, T, nt, m, None, False, ln)[0]
+            except BaseException as e:      # noqa: BLE001  (re-raised by the caller's thread)
+                errs[li] = e
+        th = [threading.Thread(target=work, args=(li,)) for li in range(1, n_lanes)]
+        for t in th:
+            t.start()
+        work(0)
+        for t in th:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        # (every solve call returned after its stream had drained: whatever follows on the caller's stream is ordered
+        # behind all of them by the host)
+        for q in par:
+            key, T, nt, m = jobs[q]
+            self.fields[key].nt = nt
+            self._register_field(key)
+        return out
 
     def solve_rows(self, key, T, nt, comm, m=None, keep=None, field=None, _own=False):
         """This rank's part of a row-block HJB solve (oc_hjb_solve_rows; `comm`: parallel.DistHaloComm or

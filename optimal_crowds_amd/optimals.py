@@ -152,17 +152,25 @@ class optimals:
             return RingField(self._engine, self._k, 1)
         return DeviceField(self._engine.field_interior(self._k)[1])
 
-    def compute_optimal_velocity(self, t, m):
-        """reference optimals.py:124-206.  m: (Ny,Nx) density (NumPy array or device tensor) or None/0."""
+    def _begin_solve(self, t):
+        """the horizon bookkeeping of compute_optimal_velocity (reference optimals.py:139-142) -> (key index, T, nt)"""
         self.t = t
         self.nt_opt = round((self.T - self.t) / self.dt)
         if self._fix_horizon:       # Q9 corrected: always the full horizon, slice s = time s*dt (simulation(fixes=...))
             self.nt_opt = round(self.T / self.dt)
+        return self._k, self.T, self.nt_opt
+
+    def _end_solve(self, stats):
+        self.stats = stats
+        print('Optimal trajectories have been learnt for ' + self.target)
+
+    def compute_optimal_velocity(self, t, m):
+        """reference optimals.py:124-206.  m: (Ny,Nx) density (NumPy array or device tensor) or None/0."""
+        self._begin_solve(t)
         mt = None
         if m is not None and not np.isscalar(m):
             mt = m if torch.is_tensor(m) else torch.as_tensor(np.ascontiguousarray(m, dtype=np.float64))
-        self.stats, _ = self._engine.solve(self._k, self.T, self.nt_opt, m=mt)
-        print('Optimal trajectories have been learnt for ' + self.target)
+        self._end_solve(self._engine.solve(self._k, self.T, self.nt_opt, m=mt)[0])
 
     def choose_optimal_velocity(self, pos, t):
         """reference optimals.py:212-250 for one position (device lookup; raises IndexError like the reference)."""

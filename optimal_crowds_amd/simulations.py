@@ -326,9 +326,20 @@ class simulation:
 
     # ------------------------------------------------------------------ run (reference simulations.py:401-451)
     def _solve_all(self):
+        """every key's compute_optimal_velocity(time, m) (reference simulations.py:419-420, 432-435).  The solves are
+        independent: the engine runs those whose whole grid lives on this GPU concurrently (Engine.solve_keys); the
+        bookkeeping and the printed lines stay in the reference's key order."""
         m = self._density_dev(self.sigma_convolution) if self.simu_step > 0 else None
-        for key in self.targets:
-            self.targets[key].compute_optimal_velocity(self.time, m)
+        tg = list(self.targets.values())
+        if len(tg) < 2 or any(type(o).compute_optimal_velocity is not optimals_mod.optimals.compute_optimal_velocity
+                              or "compute_optimal_velocity" in vars(o) for o in tg):
+            for key in self.targets:        # (one key, or a caller that wrapped the method: the plain loop)
+                self.targets[key].compute_optimal_velocity(self.time, m)
+            return
+        jobs = [o._begin_solve(self.time) for o in tg]
+        stats = self._engine.solve_keys([(k, T, nt, m) for k, T, nt in jobs])
+        for o, st in zip(tg, stats):
+            o._end_solve(st)
 
     def _run_enqueued(self):
         """The loop of run() without a host round trip per step (device noise, no per-step printing): steps are

@@ -217,3 +217,50 @@ def _cfg(gs):
     cfg = copy.deepcopy(oc.DEFAULT_CONFIG)
     cfg["grid_step"] = gs
     return cfg
+
+
+@pytest.mark.parametrize("dtype,with_m", [("float32", False), ("mixed", True)])
+def test_concurrent_key_solves_equal_one_after_the_other(dtype, with_m):
+    """Engine.solve_keys: three keys of one room (three different target sets -> three potentials) solved concurrently --
+    each on its own handle, stream and host thread -- leave the rings, the statistics and the lookups that solving them
+    one after the other leaves (the reference's order: simulations.py:419-420), bit for bit."""
+    import torch
+    from optimal_crowds_amd.engine import Engine
+    cfg, room, Nx, Ny, X0, Y0, _ = _setup("gold_b", 0.05)
+    X, Y = np.meshgrid(X0, Y0)
+    names = list(room["targets"].keys())
+    keysets = [[names[0]], [names[-1]], names[:2]][:3]
+    Vs = [oc.finalize_potential(oc.create_potential(room, ks, X, Y), cfg) for ks in keysets]
+    T, nt = 3.0, 150
+    m = torch.as_tensor(_density_like(Ny, Nx)) if with_m else None
+    res = []
+    for overlap in (False, True):
+        eng = Engine(cfg, room["room_length"], room["room_height"], Nx, Ny, X0, Y0, len(Vs), 4096, dtype=dtype)
+        eng.overlap_solves = overlap
+        eng.set_tuning("hjb_active", 2)
+        for k, V in enumerate(Vs):
+            eng.set_potential(k, V, np.zeros((0, 4)))
+            eng.alloc_field(k, nt - 1)
+        stats = eng.solve_keys([(k, T, nt, m) for k in range(len(Vs))])
+        assert len(eng._lanes) == (len(Vs) - 1 if overlap else 0)
+        # a second round on the same engine (re-solve into used rings, shorter horizon for one key)
+        stats2 = eng.solve_keys([(k, T, nt - (25 if k == 1 else 0), m) for k in range(len(Vs))])
+        fields = [tuple(t.cpu().numpy() for t in eng.ring_slices(k, 0, nt - 1)) for k in range(len(Vs))]
+        rng = np.random.RandomState(5)
+        n = 2000
+        gs = room["room_length"] / (Nx - 1)
+        eng.set_agents(rng.uniform(2.5 * gs, room["room_length"] - 3.5 * gs, n), rng.uniform(2.5 * gs, room["room_height"] - 3.5 * gs, n),
+                       np.zeros(n), np.zeros(n), rng.normal(1.34, 0.26, n), (np.arange(n) % len(Vs)).astype(np.int32))
+        looks = _lookups(eng, [0, 7, 60, 120, 148])
+        res.append((stats, stats2, fields, looks))
+        eng.close()
+    (sa, sa2, fa, la), (sb, sb2, fb, lb) = res
+    for x, y in zip(sa + sa2, sb + sb2):
+        for name in ("nfev", "n_attempt", "n_accept", "n_rescale", "h_abs0", "h_min", "h_max", "final_exponent"):
+            assert x[name] == y[name], name
+    assert len({s["n_attempt"] for s in sa}) > 1            # (the keys' solves really differ)
+    for k in range(len(Vs)):
+        assert np.array_equal(fa[k][0], fb[k][0]) and np.array_equal(fa[k][1], fb[k][1])
+        assert np.abs(fa[k][0]).max() > 0.5
+    for (da, ea), (db, eb) in zip(la, lb):
+        assert np.array_equal(da, db) and ea == eb
