@@ -2168,8 +2168,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // stage launches of an attempt (k_stageV): hjb_fuse 0 = all six stages in one launch (tile 112 x 20), 1 = two launches of
     // three stages (tile 120 x 26; measured slower, kept as a cross-check of the other)
     const int fuse = ring ? 0 : h->hjb_fuse;        // (the ring is written by the one-launch attempt)
-    const int tx = fuse == 0 ? 112 : 120, ty = fuse == 0 ? 20 : 26;
-    static_assert(OC_RING_STX == 112 && OC_RING_STY == 20, "the ring's tile flags are those of k_stageV<T, 6, 1, true, 32, 32>");
+    const int tx = fuse == 0 ? OC_RING_STX : 120, ty = fuse == 0 ? OC_RING_STY : 26;
+    static_assert(OC_ST_RWV * OC_ST_RH == 1024 && 64 % OC_ST_RWV == 0, "the stage kernel's region: 1024 threads x 4 cells");
     RingView<T> R;
     memset(&R, 0, sizeof(R));
     if (ring) {
@@ -2297,11 +2297,11 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         const double seen = active_set ? (enq > 0 ? (double)mb[1] : (double)nb3) : (double)nb3;
         const bool fused = can_fuse && seen <= (double)FUSED_MAX;
         if (ring && fused) {
-            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32, true, true>), grid3, dim3(1024), 0, s, SA);
+            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true, true>), grid3, dim3(1024), 0, s, SA);
         } else if (ring) {
-            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32, true>), grid3, dim3(1024), 0, s, SA);
+            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true>), grid3, dim3(1024), 0, s, SA);
         } else if (fuse == 0) {
-            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, 32, 32>), grid3, dim3(1024), 0, s, SA);
+            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH>), grid3, dim3(1024), 0, s, SA);
         } else {
             hipLaunchKernelGGL((k_stageV<T, 3, 1, false, 32, 32>), grid3, dim3(1024), 0, s, SA);
             hipLaunchKernelGGL((k_stageV<T, 3, 4, true, 32, 32>), grid3, dim3(1024), 0, s, SA);
