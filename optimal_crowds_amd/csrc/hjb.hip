@@ -685,6 +685,23 @@ __device__ __forceinline__ V4<T> ld4(const T* p) { return *reinterpret_cast<cons
 template <typename T>
 __device__ __forceinline__ void st4(T* p, const V4<T>& x) { *reinterpret_cast<V4<T>*>(p) = x; }
 
+// the same at a 32-bit BYTE offset from a wave-uniform base: `global_load/store ... v_offset, s[base]` -- no 64-bit vector
+// address arithmetic per array (k_stageV: ten arrays per thread in an issue-bound launch)
+template <typename T>
+__device__ __forceinline__ V4<T> ld4b(const T* p, uint32_t bo) {
+    return *reinterpret_cast<const V4<T>*>(reinterpret_cast<const char*>(p) + bo);
+}
+template <typename T>
+__device__ __forceinline__ void st4b(T* p, uint32_t bo, const V4<T>& x) {
+    *reinterpret_cast<V4<T>*>(reinterpret_cast<char*>(p) + bo) = x;
+}
+template <typename T>
+__device__ __forceinline__ void st4b_nt(T* p, uint32_t bo, const V4<T>& x) {
+    typedef T vt __attribute__((ext_vector_type(4)));
+    vt v = {x.v[0], x.v[1], x.v[2], x.v[3]};
+    __builtin_nontemporal_store(v, reinterpret_cast<vt*>(reinterpret_cast<char*>(p) + bo));
+}
+
 template <typename T>
 __device__ __forceinline__ void st4_nt(T* p, const V4<T>& x) {      // streaming store: the field is written once
     typedef T vt __attribute__((ext_vector_type(4)));
@@ -698,12 +715,18 @@ __device__ __forceinline__ void st4_nt(T* p, const V4<T>& x) {      // streaming
 #ifndef OC_RING_NT
 #define OC_RING_NT OC_RING_PLANAR
 #endif
+// value a of the thread's vector (32-bit byte offset bo into a plane) of a ring slot of n cells
 template <typename T>
-__device__ __forceinline__ void st4_ring(T* p, const V4<T>& x) {
+__device__ __forceinline__ void st4_ring(T* slot, uint32_t bo, int a, size_t n, const V4<T>& x) {
+#if OC_RING_PLANAR
+    T* const plane = slot + (size_t)a * n;              // (wave-uniform)
 #if OC_RING_NT
-    st4_nt(p, x);
+    st4b_nt(plane, bo, x);
 #else
-    st4(p, x);
+    st4b(plane, bo, x);
+#endif
+#else
+    st4(slot + oc_ring_off((size_t)(bo / sizeof(T)), a, n), x);
 #endif
 }
 
@@ -1056,6 +1079,10 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     const int gi = (logical / nbx) * TY - HY + ry, gj = (logical % nbx) * TX - HX + 4 * vx;
     const bool in = gi >= 0 && gi < Ny && gj >= 0 && gj < Nx;      // (Nx % 4 == 0: a vector is inside or outside as a whole)
     const int64_t idx = (int64_t)gi * Nx + gj;
+    // the same as an unsigned 32-bit element offset (the grid has fewer than 2^30 cells: hjb_solve_dev checks): with a
+    // wave-uniform array pointer the access is `base in scalar registers + 32-bit vector offset` -- one shift for all of the
+    // launch's ten arrays, where a 64-bit index cost two 64-bit vector operations per array (the launch is issue-bound)
+    const uint32_t ui = in ? (uint32_t)idx * (uint32_t)sizeof(T) : 0u;     // (BYTE offset)
     const int rslot = RING ? ctl->n_accept : 0;                     // the ring slot of the step this attempt tries
     const bool ring_ok = RING && rslot < A.ring_cap;                // (beyond the capacity k_control ends the solve)
     // The thread's four cells as two PAIRS: float pairs are packed-math operands (v_pk_fma_f32 / v_pk_add_f32 /
@@ -1094,7 +1121,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     const bool need_test = track && (A.flags_prev == nullptr || own_prev);
     bool cell_trivial = true;
     if (in) {
-        const V4<T> y4 = ld4(y + idx), c4 = ld4(A.coef + idx);
+        const V4<T> y4 = ld4b(y, ui), c4 = ld4b(A.coef, ui);
         if (need_test) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -1109,7 +1136,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         }
 #pragma unroll
         for (int j = 0; j < S0; ++j) {
-            const V4<T> k4 = ld4(kin[j] + idx);
+            const V4<T> k4 = ld4b(kin[j], ui);
             kv[j][0] = (T2){k4.v[0], k4.v[1]};
             kv[j][1] = (T2){k4.v[2], k4.v[3]};
             if (need_test && j == 0) {
@@ -1141,12 +1168,12 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                     uu.v[q] = un;
                 }
                 if (!RING) {                    // (Q1 .. Q3 of a trivial tile: with the ring its flag says "all zero")
-                    st4(A.KM[1] + idx, z);
-                    st4(A.KM[2] + idx, z);
-                    st4(A.KM[3] + idx, z);
+                    st4b(A.KM[1], ui, z);
+                    st4b(A.KM[2], ui, z);
+                    st4b(A.KM[3], ui, z);
                 }
-                st4(A.KX[par ^ 1] + idx, z);
-                st4(ynew + idx, uu);
+                st4b(A.KX[par ^ 1], ui, z);
+                st4b(ynew, ui, uu);
             }
             if (threadIdx.x == 0) {
                 const int r_lo = bi * TY, r_hi = min(r_lo + TY, Ny);
@@ -1217,6 +1244,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     }
     const bool store = in && ry >= HY && ry < RH - HY && vx >= HX / 4 && vx < RWV - HX / 4;
     double esum = 0.0, ymax = 0.0;
+    T ymax_t = (T)0;                    // (the maximum is exact in the state's own type: one conversion per thread)
     if (store) {
         if (FINAL) {
             // What k_out needs of K0 .. K6 is the quartic interpolant's Q = K^T P (scipy rk.py:178-180).  Column 0 of P is
@@ -1233,8 +1261,8 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             // into whole lines; as nontemporal stores each instruction's 16-byte pieces at an 80-byte stride went out as
             // partial writes: 147 us per launch at 2048 x 2048 with every tile computed)
             if (RING && ring_ok) {
-                st4_ring(rb + oc_ring_off((size_t)idx, 0, rn), quad(yv[0], yv[1]));
-                st4_ring(rb + oc_ring_off((size_t)idx, 1, rn), quad(kv[0][0], kv[0][1]));
+                st4_ring(rb, ui, 0, rn, quad(yv[0], yv[1]));
+                st4_ring(rb, ui, 1, rn, quad(kv[0][0], kv[0][1]));
             }
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp) {
@@ -1245,17 +1273,17 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                     q0 = __builtin_elementwise_fma(kv[rows[j]][0], p2, q0);
                     q1 = __builtin_elementwise_fma(kv[rows[j]][1], p2, q1);
                 }
-                if (!RING) st4(A.KM[1 + pp] + idx, quad(q0, q1));
-                else if (ring_ok) st4_ring(rb + oc_ring_off((size_t)idx, 2 + pp, rn), quad(q0, q1));
+                if (!RING) st4b(A.KM[1 + pp], ui, quad(q0, q1));
+                else if (ring_ok) st4_ring(rb, ui, 2 + pp, rn, quad(q0, q1));
             }
-            st4(A.KX[par ^ 1] + idx, quad(kv[NK - 1][0], kv[NK - 1][1]));     // K6 = the next step's K0 (FSAL)
+            st4b(A.KX[par ^ 1], ui, quad(kv[NK - 1][0], kv[NK - 1][1]));      // K6 = the next step's K0 (FSAL)
         } else {
-            st4(A.KM[0] + idx, quad(kv[S0][0], kv[S0][1]));
-            st4(A.KM[1] + idx, quad(kv[S0 + 1][0], kv[S0 + 1][1]));
-            st4(A.KM[2] + idx, quad(kv[S0 + 2][0], kv[S0 + 2][1]));
+            st4b(A.KM[0], ui, quad(kv[S0][0], kv[S0][1]));
+            st4b(A.KM[1], ui, quad(kv[S0 + 1][0], kv[S0 + 1][1]));
+            st4b(A.KM[2], ui, quad(kv[S0 + 2][0], kv[S0 + 2][1]));
         }
         if (FINAL) {
-            st4(ynew + idx, quad(t[0], t[1]));      // the last stage's working value IS y_new
+            st4b(ynew, ui, quad(t[0], t[1]));       // the last stage's working value IS y_new
             if (gi >= A.row_lo && gi < A.row_hi) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
@@ -1268,7 +1296,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                         const T sc = atol_s + fmax(fabs(y2[c]), fabs(t2[c])) * A.rtol;
                         const T qq = err_quot(e2[c], sc);
                         esum += (double)qq * (double)qq;
-                        ymax = fmax(ymax, (double)fabs(t2[c]));
+                        ymax_t = fmax(ymax_t, fabs(t2[c]));
                     }
                 }
             }
@@ -1280,6 +1308,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         // reductions (12 ds_bpermute round trips each) per block became one; the launch is bound by instruction issue.
         static_assert(sizeof(buf) / 2 >= sizeof(double2) * NT, "the reduction's pairs fit one tile buffer");
         double2* const red = reinterpret_cast<double2*>(&buf[NQ & 1][0][0]);
+        ymax = (double)ymax_t;
         red[threadIdx.x] = make_double2(esum, ymax);
         __syncthreads();
         if (threadIdx.x < 64) {
@@ -2014,6 +2043,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     S.Ny = sh ? sh->Ny_local : c.Ny;
     S.Nx = c.Nx;
     S.n = (int64_t)S.Ny * S.Nx;
+    OC_REQUIRE(S.n * (int64_t)sizeof(T) < ((int64_t)1 << 32), "grid too large: the stage kernel addresses an array by 32-bit byte offsets");
     const int own_lo = sh ? sh->own_lo : 0, own_hi = sh ? sh->own_hi : S.Ny;
     const int64_t own_off = (int64_t)own_lo * S.Nx, n_own = (int64_t)(own_hi - own_lo) * S.Nx;
     const double n_rms = sh ? (double)sh->Ny_global * S.Nx : (double)S.n;
@@ -2498,6 +2528,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
     S.Ny = sh ? sh->Ny_local : c.Ny;
     S.Nx = c.Nx;
     S.n = (int64_t)S.Ny * S.Nx;
+    OC_REQUIRE(S.n * (int64_t)sizeof(T) < ((int64_t)1 << 32), "grid too large: the stage kernel addresses an array by 32-bit byte offsets");
     const int own_lo = sh ? sh->own_lo : 0, own_hi = sh ? sh->own_hi : S.Ny;
     const int64_t own_off = (int64_t)own_lo * S.Nx, n_own = (int64_t)(own_hi - own_lo) * S.Nx;
     const double n_rms = sh ? (double)sh->Ny_global * S.Nx : (double)S.n;     // cells of the whole grid
