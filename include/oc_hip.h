@@ -140,7 +140,7 @@ int oc_hjb_solve_rows(oc_handle* h, int dtype, const void* coef_rows, double T, 
  * oc_hjb_solve and keeps, instead of slices, what SciPy's dense output of each ACCEPTED step is made of (rk.py:178-180,
  * 560-575): y_old, Q0 = K0, Q1 .. Q3 -- five values per cell and step (2048^2, T = 20: 93 steps x 5 arrays = 7.8 GB per
  * key instead of 999 slices x 2 = 33.5 GB, and no extra array pass at all: the stage launch stores them in the place of
- * Q1 .. Q3) -- plus a table slice -> (step, h x^1..4).  oc_set_field_ring registers it for the agent step, whose lookups
+ * Q1 .. Q3; a slot is five planes of rows x Nx values, y | K0 | Q1 | Q2 | Q3) -- plus a table slice -> (step, h x^1..4).  oc_set_field_ring registers it for the agent step, whose lookups
  * then evaluate phi(t_eval) at the cell and its four neighbours and `vels` (optimals.py:168-186) on the spot, with the FMA
  * chain of the slice writer: bit-identical to looking the value up in the slices oc_hjb_solve writes.
  * oc_hjb_ring_slices materialises slices from a ring with the slice writer itself (for optimals.vx_opt / tests).

@@ -1139,7 +1139,7 @@ __device__ __forceinline__ double2 field_fetch(const KeyDev& kd, int step, int i
 
 // ---- the same values from the interpolant ring (oc_set_field_ring) -----------------------------------------------------
 // Slice `step` of the direction field is not in memory; what is: for the accepted RK step that contains the slice's time,
-// y_old, K0 and Q1 .. Q3 of every cell (OcRingSlot / blocks of 20 values per four cells) and the slice's four factors
+// y_old, K0 and Q1 .. Q3 of every cell (OcRingSlot / five planes per slot) and the slice's four factors
 // h x^1..4 (OcRingSlice).  ring_dir evaluates phi at the cell and its four neighbours (scipy rk.py:560-575), clips it and
 // forms `vels` (optimals.py:168-186) exactly as the slice writer k_out does -- same operations in the same order on the
 // same inputs, so the result is the bit pattern a slice would hold.  A stage tile that was trivial in the accepted attempt

@@ -894,8 +894,8 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     const int32_t* flags_prev;      // the previous attempt's flags (NULL at the first attempt)
     int32_t* flags_cur;
     const int32_t* work;            // the attempt's work list (ctl->work_count tiles, build_work_list), or NULL: every tile
-    // interpolant ring (RING kernels): y, K0, Q1 .. Q3 of the step go to slot ctl->n_accept (blocks of 20 values per four
-    // cells, oc_internal.h) instead of Q1 .. Q3 to KM -- an attempt that is rejected is overwritten by the next one
+    // interpolant ring (RING kernels): y, K0, Q1 .. Q3 of the step go to slot ctl->n_accept (five planes, oc_internal.h)
+    // instead of Q1 .. Q3 to KM -- an attempt that is rejected is overwritten by the next one
     T* ring;
     size_t ring_slot_elems;         // 5 * rows * Nx
     int32_t* ring_first;            // [ntile]: the first slot in which the tile was computed (OC_RING_NEVER: not yet)
@@ -1252,14 +1252,13 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             // K_j of the cell is in a register, and take the place of K2 .. K5 in memory -- one array pass less for this
             // launch, and k_out reads y + 4 arrays instead of y + 6.  (Same FMA chain as interp_coeffs: bit-identical.)
             // RING: y (its pending rescale applied, as k_out applies it), K0 and Q1 .. Q3 go to the step's ring slot instead
-            // -- 20 consecutive values per thread -- and nothing reads them before a lookup or the slice writer does.
+            // -- one 16-byte vector per plane and thread -- and nothing reads them before a lookup or the slice writer does.
             constexpr int rows[6] = {0, 2, 3, 4, 5, 6};
             // (idx is a multiple of 4: the thread's vector; value a of its four cells at rb + oc_ring_off(idx, a, n))
             T* const rb = RING ? A.ring + (size_t)rslot * A.ring_slot_elems : nullptr;
             const size_t rn = A.ring_slot_elems / OC_RING_VALS;
-            // (plain stores: a thread's five 16-byte pieces are consecutive, a wavefront's 5 KB are contiguous -- the L2 merges them
-            // into whole lines; as nontemporal stores each instruction's 16-byte pieces at an 80-byte stride went out as
-            // partial writes: 147 us per launch at 2048 x 2048 with every tile computed)
+            // (streaming stores of whole lines: st4_ring; with the interleaved layout -- five 16-byte pieces per thread at an
+            // 80-byte stride -- a dense launch took 49.7 us at 2048 x 2048 against 37.8 us with planes)
             if (RING && ring_ok) {
                 st4_ring(rb, ui, 0, rn, quad(yv[0], yv[1]));
                 st4_ring(rb, ui, 1, rn, quad(kv[0][0], kv[0][1]));
@@ -1364,8 +1363,8 @@ template <typename T, bool QIN, bool RING = false>
 __device__ __forceinline__ void interp_coeffs(const T* __restrict__ y, const T* const (&k)[6], const T (&P)[6][4],
                                               T in_scale, int64_t idx, int n, V4<T>& yq, V4<T> (&Q)[4], size_t rn = 0) {
     if (RING) {
-        // y = a ring slot (blocks of y[4], K0[4], Q1[4], Q2[4], Q3[4] per four cells, oc_internal.h): the values k_stageV
-        // stored, the rescale already applied -- what the other branch holds after its loads and multiplications
+        // y = a ring slot (planes y | K0 | Q1 | Q2 | Q3, oc_internal.h): the values k_stageV stored, the rescale already
+        // applied -- what the other branch holds after its loads and multiplications
         // (rn: cells per slot -- the plane stride of the planar layout, oc_internal.h)
         if (n == 4) {
             yq = ld4(y + oc_ring_off((size_t)idx, 0, rn));

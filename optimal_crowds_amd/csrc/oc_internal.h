@@ -35,12 +35,13 @@ void oc_set_error(const char* fmt, ...);
 // (scipy rk.py:178-180, 560-575): y_old, K0 = Q0 and Q1 .. Q3 -- five values per cell and step instead of two per cell and
 // t_eval point (C4: 93 steps x 5 arrays against 999 slices x 2) -- and the direction (optimals.py:168-186) is evaluated
 // where it is looked up, with the same FMA chain as the slice writer k_out.
-//   data   per slot (= accepted step) rows x Nx/4 blocks of 20 values: y[4], K0[4], Q1[4], Q2[4], Q3[4] of four
-//          consecutive cells of a row (one lookup cell's five values share one or two cache lines; the stage kernel
-//          stores five natural 16-byte vectors per thread).  Only the stage tiles that were COMPUTED in the accepted
-//          attempt are written (exact active set); the others read as (u, 0, 0, 0, 0).  The active set only grows during
-//          a solve (a tile that was computed once is computed in every later attempt), so ONE word per tile says it all:
-//          first[t] = the first slot in which tile t was computed (INT_MAX-like: never) -- trivial in slot s <=> s < first[t].
+//   data   per slot (= accepted step) five planes of rows x Nx values: y | K0 | Q1 | Q2 | Q3 (OC_RING_PLANAR below: every store
+//          of the stage kernel is a contiguous 16 B per lane -- whole lines per wavefront row, streamed past the caches; a
+//          lookup cell's five values come from five lines, and there are few lookups).  Only the stage tiles that were
+//          COMPUTED in the accepted attempt are written (exact active set); the others read as (u, 0, 0, 0, 0).  The active
+//          set only grows during a solve (a tile that was computed once is computed in every later attempt), so ONE word per
+//          tile says it all: first[t] = the first slot in which tile t was computed (INT_MAX-like: never) -- trivial in
+//          slot s <=> s < first[t].
 //   meta   OcRingHead | OcRingSlot<T> x slots | OcRingSlice<T> x nslice | int32 first[stage tiles]
 #define OC_RING_VALS 5
 // Layout of a slot's values.  OC_RING_PLANAR 1: five planes of rows x Nx values (y | K0 | Q1 | Q2 | Q3) -- every store of the

@@ -496,6 +496,16 @@ class Engine:
         n_lanes = min(len(par), max(int(max_lanes), 1))
         lanes = [None] + [self._lane(i) for i in range(1, n_lanes)]
         main = torch.cuda.current_stream(self.device)
+        # everything the lanes read is put in place HERE, by the caller's thread on the caller's stream: the densities go to
+        # the device once (a lane thread does no host-to-device copy and frees no tensor), the rings exist
+        on_dev = {}
+        for q in par:
+            key, T, nt, m = jobs[q]
+            if m is not None and id(m) not in on_dev:
+                on_dev[id(m)] = m.to(device=self.device, dtype=self.tdtype).contiguous()
+            if self.fields[key].is_ring:
+                self._ring(key, T)
+        jobs = [(key, T, nt, on_dev.get(id(m), m) if m is not None else None) for key, T, nt, m in jobs]
         ready = torch.cuda.Event()
         ready.record(main)                  # the potentials, the density and the last steps' lookups of the old rings
         errs = [None] * n_lanes
