@@ -50,6 +50,17 @@ for name in (tag + sfx + "_bench.log", tag + sfx + "_bench_plain.log", tag + sfx
         if lines:
             open(os.path.join(P, name.replace(".log", ".json")), "w").write(lines[-1])
 
+# the round's other bench lines (tools/run_extras.sh): every gpurun_out/<tag>_<what>.log whose last line is a bench line
+if workload == "metro_station":
+    for src in sorted(glob.glob(os.path.join(G, tag + "_*.log"))):
+        name = os.path.basename(src)
+        what = name[len(tag) + 1:-4]
+        if not what.startswith(("bench_mixed", "bench_slices", "sequential_", "synchronous_", "rccl_", "rehearsal_")):
+            continue
+        lines = [l for l in open(src) if l.startswith("{")]
+        if lines:
+            open(os.path.join(P, name.replace(".log", ".json")), "w").write(lines[-1])
+
 traffic = {}
 for d, cname in ((tag + sfx + "_pmc_fetch", "FETCH_SIZE"), (tag + sfx + "_pmc_write", "WRITE_SIZE")):
     f = sorted(glob.glob(os.path.join(G, d, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
