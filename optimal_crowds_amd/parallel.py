@@ -50,17 +50,29 @@ def sum_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
-def key_row_plan(n_keys, world):
+ROW_MIN_CELLS = 1 << 22        # a row block below ~4 M cells is a chain of latency-bound launches: nothing to win by splitting
+
+
+def key_row_plan(n_keys, world, ncell=None, min_cells=None):
     """partition by key first (the solves of different keys are independent: zero communication), then split
     each key's grid into row blocks over the ranks of its group.  Returns, per key, the tuple of world ranks that solve
     it, in row-block order.  world >= n_keys: contiguous groups of world // n_keys ranks (the first world % n_keys
-    groups get one more): C4 on 4 GPUs = 2 keys x 2-way rows.  world < n_keys: key k goes whole to rank k % world."""
+    groups get one more): 2 keys on 4 GPUs = 2 groups of 2.  world < n_keys: key k goes whole to rank k % world.
+    ncell (cells of one key's grid): a group only uses as many of its ranks as leave every row block at least
+    `min_cells` cells (default ROW_MIN_CELLS, or the environment's OC_ROW_MIN_CELLS) -- "only where grid / agent counts make
+    it natural": on one MI355X a 2048^2 solve is ~100 launches of 25 us on a few dozen CUs, splitting it only adds two
+    collectives per attempt, so C4's keys stay whole at any N (ranks without a key still take their share of the step) and
+    C5's 4096^2 grid goes 4-way.  ncell=None: every rank of a group gets a block."""
     if world >= n_keys:
         base, rem = divmod(world, n_keys)
         plan, r0 = [], 0
         for k in range(n_keys):
             n = base + (1 if k < rem else 0)
-            plan.append(tuple(range(r0, r0 + n)))
+            use = n
+            if ncell is not None:
+                mc = int(min_cells if min_cells is not None else os.environ.get("OC_ROW_MIN_CELLS", ROW_MIN_CELLS))
+                use = max(1, min(n, int(ncell) // max(mc, 1)))
+            plan.append(tuple(range(r0, r0 + use)))
             r0 += n
         return plan
     return [(k % world,) for k in range(n_keys)]
@@ -384,9 +396,10 @@ def _subgroup(ranks):
     return _SUBGROUPS[ranks]
 
 
-def dist_sharding(halo=8, by_key=True, native=None):
+def dist_sharding(halo=8, by_key=True, native=None, min_cells=None):
     """`sharding=` argument of simulations.simulation for a torch.distributed job (one process per GPU): ONE simulation
-    on all ranks.  HJB: keys first, then row blocks (key_row_plan; by_key=False: every key over all ranks) with `halo`
+    on all ranks.  HJB: keys first, then row blocks where a block keeps at least min_cells cells (key_row_plan;
+    by_key=False: every key over all ranks) with `halo`
     rows -- at least 8 here: 7 for the solve itself (RowShard) and one more so that the floor field is exact on the row
     beyond the block, which a lookup's second cell may read -- each key's collectives on its own sub-group (nccl = RCCL over
     xGMI, or gloo); agents replicated, the step's exchange over the whole world (DistStepComm).
@@ -401,12 +414,21 @@ def dist_sharding(halo=8, by_key=True, native=None):
 
     def make(eng):
         world, rank = dist.get_world_size(), dist.get_rank()
-        plan = key_row_plan(eng.n_keys, world) if by_key else [tuple(range(world))] * eng.n_keys
+        plan = (key_row_plan(eng.n_keys, world, ncell=eng.Nx * eng.Ny, min_cells=min_cells) if by_key
+                else [tuple(range(world))] * eng.n_keys)
         comms = {}
+        # a single key that is not worth splitting: EVERY rank solves it whole (the same kernels on the same inputs: the same
+        # bits) instead of rank 0 alone with the others waiting -- every rank then holds the whole floor field, lookups stay
+        # local and the step needs its all-gather only.  (It also keeps the ranks' view of "are the fields sharded" the same:
+        # oc_gcfm_step_sharded decides it from the fields registered on the rank.)
+        replicate = by_key and eng.n_keys == 1 and len(plan[0]) == 1 and world > 1
+        eng.key_replicated = replicate
         for k, ranks in enumerate(plan):
             # (every rank asks for every group, member or not, in the same order: torch.distributed requires it)
             grp = _subgroup(ranks) if len(ranks) > 1 else None
-            if rank in ranks:
+            if replicate:
+                comms[k] = DistHaloComm(RowShard(eng.Ny, 0, 1, halo), eng.Nx, eng.tdtype, eng.device, group=None, ranks=(rank,))
+            elif rank in ranks:
                 sh = RowShard(eng.Ny, ranks.index(rank), len(ranks), halo)
                 comms[k] = DistHaloComm(sh, eng.Nx, eng.tdtype, eng.device, group=grp, ranks=ranks)
                 if native and dist.get_backend() == "nccl" and k + 1 < 16:

@@ -68,7 +68,7 @@ def test_bench_two_ranks_without_a_launcher():
     assert d["rccl"]["ranks"] == 2 and d["rccl"]["hjb_key_plan"] == [[0], [1]]
 
 
-def _torchrun_bench(workload, extra=()):
+def _torchrun_bench(workload, extra=(), env_extra=None):
     """the driver's N > 1 command (one rank per GPU) rehearsed on this one-GPU box: both ranks on cuda:0, collectives
     over gloo (OC_BENCH_ONE_DEVICE=1) -- the same bench.py code path, communicators and library calls as over RCCL"""
     import socket
@@ -76,7 +76,7 @@ def _torchrun_bench(workload, extra=()):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, OC_BENCH_ONE_DEVICE="1")
+    env = dict(os.environ, OC_BENCH_ONE_DEVICE="1", **(env_extra or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
            "--workload", workload, "--no-cpu-baseline", *extra]
@@ -105,8 +105,14 @@ def test_bench_two_ranks_sharded_keys_first():
 
 
 def test_bench_two_ranks_sharded_row_blocks():
-    """1 key on 2 ranks: two row blocks, an all-gather of the error norm and a halo exchange per RK attempt"""
-    d = _torchrun_bench("slalom", ("--mode", "sharded", "--no-ensemble-line"))
+    """1 key on 2 ranks: two row blocks, an all-gather of the error norm and a halo exchange per RK attempt
+    (OC_ROW_MIN_CELLS=1: by default a 1024 x 1024 grid is not worth splitting -- parallel.key_row_plan -- and stays whole,
+    which the first call checks)"""
+    whole = _torchrun_bench("slalom", ("--mode", "sharded", "--no-ensemble-line"))
+    assert whole["rccl"]["hjb_key_plan"] == [[0]] and whole["rccl"]["hjb_halo_exchanges_this_rank"] == 0
+    # (a single unsplit key is solved whole by EVERY rank: the floor field is local everywhere, one all-gather per step)
+    assert whole["rccl"]["collectives_per_step"] == 1 and whole["rccl"]["step_allreduces"] == 0 and whole["value"] > 0
+    d = _torchrun_bench("slalom", ("--mode", "sharded", "--no-ensemble-line"), {"OC_ROW_MIN_CELLS": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "ensemble" not in d
     r = d["rccl"]
     assert r["hjb_key_plan"] == [[0, 1]] and r["step_allreduces"] == 25 and r["step_allgathers"] == 25

@@ -39,7 +39,7 @@ def _worker(rank, world, port, q):
     held = [k for k in range(2) if comms2[k] is not None]
     shape2 = [(comms2[k].shard.world, comms2[k].shard.g0, comms2[k].shard.g1) for k in held]
     eng1 = _StubEngine(1, 64, 16)
-    comms1, step1 = parallel.dist_sharding(halo=8)(eng1)
+    comms1, step1 = parallel.dist_sharding(halo=8, min_cells=1)(eng1)      # (by default a grid this small stays whole)
     sh = comms1[0].shard
     # the two collectives of a row-block solve through the key's communicator
     comms1[0].red_local.copy_(torch.tensor([1.0 + rank, 10.0 * (rank + 1)], dtype=torch.float64))
@@ -84,6 +84,13 @@ def test_key_row_plan():
     assert parallel.key_row_plan(2, 1) == [(0,), (0,)]
     assert parallel.key_row_plan(3, 2) == [(0,), (1,), (0,)]
     assert parallel.key_row_plan(2, 3) == [(0, 1), (2,)]
+    # with the grid's size: row blocks only where a block keeps ROW_MIN_CELLS cells (a smaller one is latency-bound anyway)
+    assert parallel.key_row_plan(2, 4, ncell=2048 * 2048) == [(0,), (2,)]          # C4: keys whole at any N
+    assert parallel.key_row_plan(2, 8, ncell=2048 * 2048) == [(0,), (4,)]
+    assert parallel.key_row_plan(1, 8, ncell=4096 * 4096) == [(0, 1, 2, 3)]        # C5: 4-way rows
+    assert parallel.key_row_plan(1, 2, ncell=4096 * 4096) == [(0, 1)]
+    assert parallel.key_row_plan(1, 2, ncell=1024 * 1024) == [(0,)]
+    assert parallel.key_row_plan(1, 2, ncell=1024 * 1024, min_cells=1) == [(0, 1)]
     for K in range(1, 6):
         for W in range(1, 9):
             plan = parallel.key_row_plan(K, W)

@@ -303,10 +303,10 @@ def test_simulation_run_sharded_matches_single_gpu():
         assert np.median(d) <= 1e-6 and (d > 1e-3).mean() <= 0.1
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 3])
 def test_simulation_run_keys_first_then_rows(world):
     """SURVEY 8e "partition by key first": gold_b has two target keys.  2 virtual ranks = one whole key per rank (no
-    solve-time collective at all); 4 ranks = 2 keys x 2-way row blocks.  A rank holds no field of the other group's key,
+    solve-time collective at all); 4 ranks = 2 keys x 2-way row blocks; 3 ranks with one of them holding no key.  A rank holds no field of the other group's key,
     the step's lookups for those agents are answered by the ranks that do and travel with the all-reduce.  Against the
     same run on one engine: same exits, same horizons, positions as in the row-block test."""
     import contextlib
@@ -332,8 +332,10 @@ def test_simulation_run_keys_first_then_rows(world):
         return out
 
     ref = finish(make(None))
-    plan = parallel.key_row_plan(2, world)
-    assert plan == ([(0,), (1,)] if world == 2 else [(0, 1), (2, 3)])
+    # world 3: the plan of a grid that is not worth splitting on 3 ranks -- keys whole on ranks 0 and 2, rank 1 holds NO
+    # field at all and only takes its share of the step (parallel.key_row_plan with the grid's size)
+    plan = parallel.key_row_plan(2, world) if world != 3 else parallel.key_row_plan(2, 3, ncell=1 << 22)
+    assert plan == {2: [(0,), (1,)], 4: [(0, 1), (2, 3)], 3: [(0,), (2,)]}[world]
     tw_keys = [parallel.ThreadWorld(len(r)) for r in plan]
     tw_step = parallel.ThreadWorld(world)
     lock = threading.Lock()
