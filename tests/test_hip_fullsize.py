@@ -287,3 +287,56 @@ def test_t20_fp32_error_alone_on_the_gpu_step_sequence():
         assert a.size == 0 or a.max() <= 1e-2
         assert flips <= 1e-3
     eng.close()
+
+
+def test_c4_lookups_through_the_ring_equal_lookups_in_the_slices(c4):
+    """At the headline size: the desired velocities of all 100 000 agents (both keys) looked up through the interpolant ring
+    -- the product path: vels evaluated at the one or two cells a lookup reads -- are the bit patterns found in the slices a
+    slice-writing solve (`field='slices'`: oc_hjb_solve, the reference's fill loop optimals.py:200-204) leaves, at early,
+    middle and late steps, and so are slices materialised from the ring (oc_hjb_ring_slices)."""
+    import bench
+    import torch
+    sim, cfg, stats = c4
+    eng = sim._engine
+    assert eng.fields[0].is_ring and eng.field_mode == "ring"
+    ref, _ = bench.build_sim("metro_station", field="slices")          # same seed: the same crowd
+    try:
+        rstats = bench.solve_round(ref)
+        for a, b in zip(stats, rstats):
+            assert (a["n_attempt"], a["n_accept"], a["nfev"], a["final_exponent"]) == (b["n_attempt"], b["n_accept"], b["nfev"],
+                                                                                       b["final_exponent"])
+        st0 = eng.get_state()           # (earlier tests of this module have stepped the fixture's crowd: the same state here)
+        ref._engine.set_agents(st0["x"], st0["y"], st0["vx"], st0["vy"], sim._v_des, sim._key_of, status=st0["status"])
+        moving = 0
+        for step in (0, 1, 37, 250, 600, 997, 998):
+            d0, e0 = eng.lookup(step)
+            d1, e1 = ref._engine.lookup(step)
+            assert e0 == e1
+            assert torch.equal(d0, d1), step
+            moving += int((d0.abs().sum(dim=1) > 0).sum())
+        assert moving > 1000            # (most of this crowd stands in the far field, whose direction is zero: probes below)
+        # probe positions where the field lives: around each key's exits
+        rng = np.random.RandomState(4)
+        for k, name in enumerate(sim._key_names):
+            rect = np.array([sim._room["targets"][t] for t in sim._possible[name]])[0]
+            n = 20000
+            xs = np.clip(rect[0] + rng.uniform(-25, 25, n), 0.5, sim.room_length - 0.5)
+            ys = np.clip(rect[1] + rng.uniform(-25, 25, n), 0.5, sim.room_height - 0.5)
+            nz = 0
+            for step in (0, 300, 900):
+                p0, pe0 = eng.lookup_points(k, xs, ys, step)
+                p1, pe1 = ref._engine.lookup_points(k, xs, ys, step)
+                assert pe0 == pe1 and np.array_equal(p0, p1)
+                nz += int((np.abs(p0).sum(axis=1) > 0).sum())
+            assert nz > 3000                                            # (probe-steps that see a direction)
+        ref._engine.set_agents(st0["x"], st0["y"], st0["vx"], st0["vy"], sim._v_des, sim._key_of, status=st0["status"])
+        eng.set_agents(st0["x"], st0["y"], st0["vx"], st0["vy"], sim._v_des, sim._key_of, status=st0["status"])
+        for k in range(2):
+            for s in (0, 400, 998):
+                vx, vy = eng.ring_slices(k, s, s + 1)
+                assert torch.equal(vx[0], ref._engine.fields[k][0][s]) and torch.equal(vy[0], ref._engine.fields[k][1][s])
+    finally:
+        ref._engine.close()
+        ref._engine.fields = []
+        del ref
+        torch.cuda.empty_cache()
