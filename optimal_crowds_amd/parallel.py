@@ -382,6 +382,15 @@ def native_comm(eng, slot, group=None, ranks=None):
     return int(slot)
 
 
+def _rccl_usable(eng):
+    """can liboc_hip bind librccl in this process? (oc_comm_unique_id dlopens it and draws an id)"""
+    import ctypes as C_
+    try:
+        return eng.lib.oc_comm_unique_id((C_.c_ubyte * 128)()) == 0
+    except Exception:       # noqa: BLE001
+        return False
+
+
 _SUBGROUPS = {}         # rank tuple -> process group: a simulation built twice in one process reuses its sub-groups
 
 
@@ -404,11 +413,13 @@ def dist_sharding(halo=8, by_key=True, native=None, min_cells=None):
     beyond the block, which a lookup's second cell may read -- each key's collectives on its own sub-group (nccl = RCCL over
     xGMI, or gloo); agents replicated, the step's exchange over the whole world (DistStepComm).
     native: the collectives are issued by the library itself over RCCL communicators it owns (native_comm: slot 0 = the
-    world, slot 1 + k = key k's rank group) instead of through callbacks into torch.distributed; None = the environment's
-    OC_RCCL_NATIVE=1 on an nccl job.  (Off by default: this pool's one-GPU boxes can exercise it with one rank only.)
+    world, slot 1 + k = key k's rank group) instead of through callbacks into torch.distributed.  None = on for an nccl
+    job unless the environment says OC_RCCL_NATIVE=0: with callbacks a step pays two trips through the interpreter (one-rank
+    RCCL group at C4: 0.42 ms per step against 0.28, profiles/r03_rccl_*one_rank.json); if a communicator cannot be created
+    the callbacks take over (a line on stderr says so).
     Returns engine -> ({key: halo comm or None}, step comm)."""
     if native is None:
-        native = os.environ.get("OC_RCCL_NATIVE") == "1"
+        native = os.environ.get("OC_RCCL_NATIVE", "1") != "0"
     if halo < 8:
         raise ValueError("sharded lookups need halo >= 8 (the field is exact halo - 7 rows beyond a block)")
 
@@ -416,6 +427,19 @@ def dist_sharding(halo=8, by_key=True, native=None, min_cells=None):
         world, rank = dist.get_world_size(), dist.get_rank()
         plan = (key_row_plan(eng.n_keys, world, ncell=eng.Nx * eng.Ny, min_cells=min_cells) if by_key
                 else [tuple(range(world))] * eng.n_keys)
+        use_native = bool(native and dist.get_backend() == "nccl")
+        if use_native:
+            # every rank must take the same path: try the library's RCCL binding HERE, on all ranks, and agree on the outcome
+            # before any communicator is created
+            ok = torch.tensor([1 if _rccl_usable(eng) else 0], dtype=torch.int32, device=eng.device)
+            if world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if rank == 0:
+                    import sys
+                    print("optimal_crowds_amd.parallel: librccl could not be bound by liboc_hip on every rank -- collectives "
+                          "through torch.distributed callbacks", file=sys.stderr)
+                use_native = False
         comms = {}
         # a single key that is not worth splitting: EVERY rank solves it whole (the same kernels on the same inputs: the same
         # bits) instead of rank 0 alone with the others waiting -- every rank then holds the whole floor field, lookups stay
@@ -431,15 +455,15 @@ def dist_sharding(halo=8, by_key=True, native=None, min_cells=None):
             elif rank in ranks:
                 sh = RowShard(eng.Ny, ranks.index(rank), len(ranks), halo)
                 comms[k] = DistHaloComm(sh, eng.Nx, eng.tdtype, eng.device, group=grp, ranks=ranks)
-                if native and dist.get_backend() == "nccl" and k + 1 < 16:
+                if use_native and k + 1 < 16:
                     comms[k].comm_slot = native_comm(eng, 1 + k, group=grp, ranks=ranks)
             else:
                 comms[k] = None
         eng.key_plan = plan
         step = DistStepComm(None)
-        if native and dist.get_backend() == "nccl":
+        if use_native:
             step.comm_slot = native_comm(eng, 0)
-        eng.rccl_native = bool(native and dist.get_backend() == "nccl")
+        eng.rccl_native = use_native
         return comms, step
     return make
 

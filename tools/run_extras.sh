@@ -15,7 +15,7 @@ for wl in room_test exit_opposite; do
   python bench.py --workload $wl --steps 200 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_synchronous_$wl.log 2>> gpurun_out/${tag}_sequential_$wl.err
 done
 # the sharded mode on a one-rank RCCL group (callbacks, then the library's own communicators)
-OC_BENCH_FORCE_SHARDED=1 python bench.py --steps 20 --warmup 2 --mode sharded --no-cpu-baseline --no-ensemble-line > gpurun_out/${tag}_rccl_one_rank.log 2> gpurun_out/${tag}_rccl_one_rank.err || tail -3 gpurun_out/${tag}_rccl_one_rank.err
+OC_RCCL_NATIVE=0 OC_BENCH_FORCE_SHARDED=1 python bench.py --steps 20 --warmup 2 --mode sharded --no-cpu-baseline --no-ensemble-line > gpurun_out/${tag}_rccl_one_rank.log 2> gpurun_out/${tag}_rccl_one_rank.err || tail -3 gpurun_out/${tag}_rccl_one_rank.err
 OC_RCCL_NATIVE=1 OC_BENCH_FORCE_SHARDED=1 python bench.py --steps 20 --warmup 2 --mode sharded --no-cpu-baseline --no-ensemble-line > gpurun_out/${tag}_rccl_native_one_rank.log 2> gpurun_out/${tag}_rccl_native_one_rank.err || tail -3 gpurun_out/${tag}_rccl_native_one_rank.err
 # the driver's N = 2 command without a launcher, rehearsed on ONE device over gloo (not a scaling number)
 OC_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 20 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_rehearsal_n2_one_device.log 2> gpurun_out/${tag}_rehearsal_n2.err || tail -3 gpurun_out/${tag}_rehearsal_n2.err
