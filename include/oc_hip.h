@@ -296,6 +296,14 @@ int oc_comm_destroy(oc_handle* h, int slot);
  * 1 + index of an agent that was in the IndexError band (0: none), the first step in which it was }.  Synchronises;
  * reset != 0 clears the last three afterwards.  simulations.py:427 (loop condition), optimals.py:234-239 (IndexError). */
 int oc_run_status(oc_handle* h, int32_t* out4, int reset, void* stream);
+/* oc_set_tuning(h, "lazy_state", 1): oc_gcfm_step no longer scatters x / y / vx / vy / agent_time into the caller's arrays in
+ * every step (five 8-byte stores per agent at random addresses: more than half of the step's second launch at 500 000
+ * agents) -- the state lives in the library's slot-ordered snapshot, an agent that leaves is written when it does, and the
+ * arrays are brought up to date by oc_agents_sync, by the periodic re-sort and by every other entry point that reads them
+ * (oc_density, the diagnostic exports, the sequential and the sharded step).  `status` is always current.  Call
+ * oc_agents_sync BEFORE reading the arrays yourself, and before writing them (then oc_agents_changed, as ever).  Default 0:
+ * every step leaves the arrays current (simulations.py:303-326 writes the agent's own fields). */
+int oc_agents_sync(oc_handle* h, void* stream);
 int oc_set_resort_every(oc_handle* h, int32_t steps);
 /* Between consecutive oc_gcfm_step calls the library reuses the packed snapshot it wrote itself; call this after
  * modifying the state arrays in place from outside (new array pointers are detected automatically). */
@@ -332,6 +340,7 @@ int oc_set_hjb_variant(oc_handle* h, int variant);
  *                  1 = 128 x 8, 2 = 256 x 4 cells
  *   "hjb_fuse"     stage launches of an RK attempt of the product path: 0 = one launch of six stages (default),
  *                  1 = two launches of three
+ *   "lazy_state"   see oc_agents_sync (default 0)
  *   "wall_warm"    1 (default) = the exact nearest-wall search of an agent (pedestrians.py:311-315) starts from the cell the
  *                  previous step's search found -- a valid candidate, so the result is the same cell; 0 = always cold
  *   "hjb_tail"     ring solves (oc_hjb_solve_ring): 1 (default) = while few blocks take part in an attempt -- small grids, or

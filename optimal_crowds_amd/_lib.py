@@ -137,6 +137,7 @@ SIGNATURES = {
     "oc_run_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "oc_set_resort_every": (C.c_int, [C.c_void_p, C.c_int32]),
     "oc_agents_changed": (C.c_int, [C.c_void_p]),
+    "oc_agents_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "oc_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(OcAgents), C.c_double, C.c_void_p, C.c_double,
                              C.c_void_p, C.c_void_p]),
     "oc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

@@ -139,6 +139,10 @@ extern "C" int oc_density(oc_handle* h, int dtype, const oc_agents* a, double si
     OC_REQUIRE(sigma > 0, "sigma must be positive");
     OC_REQUIRE(dtype == OC_F32 || dtype == OC_F64, "bad dtype");
     OC_HIP_CHECK(hipSetDevice(h->device));
+    {   // lazy_state: the positions and the status are read from the caller's arrays
+        int rcf = oc_flush_state(h, (hipStream_t)stream);
+        if (rcf) return rcf;
+    }
     hipStream_t s = (hipStream_t)stream;
     const oc_config& c = h->cfg;
     if (trunc_sigmas <= 0) trunc_sigmas = 6.0;

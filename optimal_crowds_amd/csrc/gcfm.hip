@@ -124,6 +124,8 @@ struct Scratch {
     int32_t *vals_a, *vals_b;
     Snap snap;
     double2* pvd;           // float64 velocity per slot (only the tile's own finisher touches it: single buffer)
+    double* ptime;          // agent_time per slot (ped.time): advanced here every step, scattered to the caller's array with the
+                            // rest of the state -- every step, or (lazy_state) when somebody needs it
     PDK* pdk;
     double4* tile_box0;
     int32_t* nb_list;       // [ntiles][NB_MAX + 1]: count (or -1 = overflow) then tile ids
@@ -347,7 +349,7 @@ __global__ void __launch_bounds__(64) k_pack(const double* __restrict__ x, const
                                              const double* __restrict__ vx, const double* __restrict__ vy,
                                              const double* __restrict__ v_des, const uint8_t* __restrict__ status,
                                              const int32_t* __restrict__ key_of, const int32_t* __restrict__ order,
-                                             int N, GcfmParams P, Scratch S) {
+                                             int N, GcfmParams P, Scratch S, const double* __restrict__ agent_time) {
     const Snap& C = S.snap;
     int k = blockIdx.x * 64 + threadIdx.x;
     int i = (k < N) ? order[k] : -1;
@@ -377,6 +379,7 @@ __global__ void __launch_bounds__(64) k_pack(const double* __restrict__ x, const
     }
     S.pvd[k] = make_double2(vxd, vyd);
     S.pdk[k] = dk;
+    S.ptime[k] = (act && agent_time != nullptr) ? agent_time[i] : 0.0;
     const double4 tb = tile_boxes(act ? px : INFINITY, act ? py : INFINITY, act ? px : -INFINITY, act ? py : -INFINITY,
                                   threadIdx.x, blockIdx.x, C.qbox);
     if (threadIdx.x == 0) {
@@ -1521,7 +1524,7 @@ template <bool SEQ>
 __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const double* __restrict__ rect_tab, int nkeys,
                                                StepArgs A, int seq_round, double seq_margin,
                                                const double* __restrict__ err_slots, int n_err_slots, int64_t err_stride,
-                                               const KeyDev* __restrict__ keys, KeyStep* __restrict__ ksteps) {
+                                               const KeyDev* __restrict__ keys, KeyStep* __restrict__ ksteps, int lazy = 0) {
     __shared__ double l_rect[RECT_KEYS_LDS * RECT_TAB];
     const Snap& C = S.snap;
     const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
@@ -1551,7 +1554,8 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
         err0 = S.ctrl[C_ERR + 8];
         for (int r = 0; r < n_err_slots; ++r) err0 = max(err0, (int)err_slots[(size_t)r * err_stride]);
     }
-    const double at0 = (act && A.agent_time) ? A.agent_time[i] : 0.0;
+    // (lazy: the time comes from its slot-ordered copy -- no gather by agent index; SEQ keeps the caller's array as the source)
+    const double at0 = !act ? 0.0 : (lazy ? S.ptime[k] : (A.agent_time ? A.agent_time[i] : 0.0));
     double n0 = 0.0, n1 = 0.0;
     if (act) {      // noise: caller's standard normals, or Philox4x32-10 + Box-Muller (float32)
         if (A.noise) {
@@ -1582,11 +1586,10 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
             nvx *= sc;
             nvy *= sc;
         }
-        A.x[i] = nx;
-        A.y[i] = ny;
-        A.vx[i] = nvx;
-        A.vy[i] = nvy;
-        if (A.agent_time) A.agent_time[i] = at0 + dt;
+        S.ptime[k] = at0 + dt;
+        // the caller's state arrays, in agent order: five scattered 8-byte stores per agent (at 500 000 agents more than half
+        // of this launch).  lazy_state: only for an agent that LEAVES in this step -- its slot is given up below; everybody
+        // else's state is scattered by k_flush_state when somebody needs the arrays (the re-sort, a read, another entry point)
         if (SEQ) {
             S.seq_state[k] = 2;
             if (!(fabs(nx - p.x) <= seq_margin && fabs(ny - p.y) <= seq_margin)) S.seq_ctl[4] = 1;
@@ -1596,6 +1599,13 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
         const int nrect = (int)rt[0];
         for (int q = 0; q < nrect; ++q)
             if (fabs(nx - rt[1 + 4 * q]) < rt[3 + 4 * q] * 0.5 && fabs(ny - rt[2 + 4 * q]) < rt[4 + 4 * q] * 0.5) out = true;
+        if (!lazy || out) {
+            A.x[i] = nx;
+            A.y[i] = ny;
+            A.vx[i] = nvx;
+            A.vy[i] = nvy;
+            if (A.agent_time) A.agent_time[i] = at0 + dt;
+        }
         if (out) {
             A.status[i] = 0;
             C.ppos[k] = make_double2(1e300, 1e300);
@@ -1646,6 +1656,23 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     }
 }
 
+
+// lazy_state: the packed snapshot -> the caller's state arrays (agent order), for every agent that is still inside (an agent
+// that left was written when it did)
+__global__ void __launch_bounds__(256) k_flush_state(Scratch S, double* __restrict__ x, double* __restrict__ y,
+                                                     double* __restrict__ vx, double* __restrict__ vy,
+                                                     double* __restrict__ agent_time) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S.Np) return;
+    const int i = S.snap.pidx[k];
+    if (i < 0) return;
+    const double2 p = S.snap.ppos[k], v = S.pvd[k];
+    x[i] = p.x;
+    y[i] = p.y;
+    vx[i] = v.x;
+    vy[i] = v.y;
+    if (agent_time) agent_time[i] = S.ptime[k];
+}
 
 // ---------------------------------------------------------------------------------- sequential (Gauss-Seidel) mode
 // The reference updates the agents ONE BY ONE in a fresh random permutation, and an agent sees the already advanced
@@ -1892,16 +1919,23 @@ GcfmParams make_params(const oc_handle* h) {
     return P;
 }
 
+int flush_state_impl(oc_handle* h, hipStream_t s);
+
 int carve(oc_handle* h, int N, Scratch* S, bool diag = false) {
     int Np = ((N + 63) / 64) * 64;
     if (Np == 0) Np = 64;
     const int nt = Np / 64;
     const size_t per_snap = sizeof(double2) + sizeof(float4) + sizeof(float2) + sizeof(int32_t);
     const size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + per_snap + sizeof(double2) + sizeof(PDK) +
-                       3 * sizeof(double2) + sizeof(long long) + sizeof(int32_t);
+                       3 * sizeof(double2) + sizeof(long long) + sizeof(int32_t) + sizeof(double);
     size_t need = (per + 2 * sizeof(int32_t)) * (size_t)Np + (6 * sizeof(double4) + (NB_MAX + 3) * sizeof(int32_t)) * (size_t)nt +
                   1024 + 16384;
     if (need > h->gcfm_bytes) {
+        if (h->state_dirty) {           // lazy_state: the snapshot about to be dropped is ahead of the caller's arrays
+            int rcf = flush_state_impl(h, nullptr);
+            if (rcf) return rcf;
+            OC_HIP_CHECK(hipStreamSynchronize(nullptr));
+        }
         if (h->gcfm_buf) OC_HIP_CHECK(hipFree(h->gcfm_buf));
         h->gcfm_buf = nullptr;
         OC_HIP_CHECK(hipMalloc(&h->gcfm_buf, need));
@@ -1931,6 +1965,7 @@ int carve(oc_handle* h, int N, Scratch* S, bool diag = false) {
     S->snap.qbox = (double4*)take(sizeof(double4) * 4 * nt);
     S->pvd = (double2*)take(sizeof(double2) * Np);
     S->pdk = (PDK*)take(sizeof(PDK) * Np);
+    S->ptime = (double*)take(sizeof(double) * Np);
     S->f_pair = (double2*)take(sizeof(double2) * Np);
     S->f_wall = (double2*)take(sizeof(double2) * Np);
     S->des = (double2*)take(sizeof(double2) * Np);
@@ -2030,6 +2065,10 @@ bool wallmaps_ready(const oc_handle* h) {
 // re-sort + full pack of the current state + neighbour lists + dispatch order
 int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hipStream_t s) {
     const int N = a->N;
+    {   // lazy_state: the re-sort reads the caller's arrays -- bring them up to date first (same stream: ordered)
+        int rcf = flush_state_impl(h, s);
+        if (rcf) return rcf;
+    }
     // the searches' incumbents belong to THESE agents, arrays and wall maps: anything else starts cold (a plain re-sort of
     // the same agents keeps them: they are indexed by agent)
     if (S->wprev != nullptr && (!h->wprev_valid || h->packed_x != a->x || h->packed_N != N)) {
@@ -2044,7 +2083,7 @@ int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hi
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_pack, dim3(S->ntiles), dim3(64), 0, s, a->x, a->y, a->vx, a->vy, a->v_des, a->status, a->key,
-                       S->vals_b, N, P, *S);
+                       S->vals_b, N, P, *S, (const double*)a->agent_time);
     const bool have_work = h->work_valid && h->work_tiles == S->ntiles;
     if (!have_work) OC_HIP_CHECK(hipMemsetAsync(S->tile_work, 0, sizeof(int32_t) * S->ntiles, s));
     hipLaunchKernelGGL(k_tile_lists, dim3(S->ntiles), dim3(64), 0, s, P, *S, have_work ? 1 : 0);
@@ -2059,6 +2098,21 @@ int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hi
     return OC_OK;
 }
 
+int flush_state_impl(oc_handle* h, hipStream_t s) {
+    if (!h->state_dirty) return OC_OK;
+    h->state_dirty = false;
+    const oc_agents& a = h->dirty_agents;
+    if (a.N <= 0 || h->gcfm_buf == nullptr) return OC_OK;
+    // (the packed snapshot these arrays are behind is still in the scratch: it is only ever overwritten by a repack, which
+    // comes through here first, or dropped by a reallocation, which carve() precedes by a flush)
+    Scratch S;
+    int rc = carve(h, a.N, &S);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_flush_state, dim3((S.Np + 255) / 256), dim3(256), 0, s, S, a.x, a.y, a.vx, a.vy, a.agent_time);
+    OC_HIP_CHECK(hipGetLastError());
+    return OC_OK;
+}
+
 int prepare(oc_handle* h, const oc_agents* a, Scratch* S, GcfmParams* P, hipStream_t s) {
     int rc = carve(h, a->N, S, true);      // single-shot diagnostic exports: own control words
     if (rc) return rc;
@@ -2069,7 +2123,15 @@ int prepare(oc_handle* h, const oc_agents* a, Scratch* S, GcfmParams* P, hipStre
 
 }   // namespace
 
+int oc_flush_state(oc_handle* h, hipStream_t s) { return flush_state_impl(h, s); }
+
 // ---------------------------------------------------------------------------------- C ABI
+extern "C" int oc_agents_sync(oc_handle* h, void* stream) {
+    OC_REQUIRE(h, "null handle");
+    OC_HIP_CHECK(hipSetDevice(h->device));
+    return flush_state_impl(h, (hipStream_t)stream);
+}
+
 extern "C" int oc_wallmap_build(oc_handle* h, int key, const float* V, float vmin, void* stream) {
     OC_REQUIRE(h && V && key >= 0 && key < (int)h->wallmaps.size(), "bad argument");
     OC_HIP_CHECK(hipSetDevice(h->device));
@@ -2109,6 +2171,7 @@ static int require_wallmaps(oc_handle* h) {
 
 extern "C" int oc_agents_changed(oc_handle* h) {
     OC_REQUIRE(h, "null handle");
+    h->state_dirty = false;             // (lazy_state: the caller has written the arrays -- call oc_agents_sync BEFORE doing so)
     h->packed_valid = false;
     h->wprev_valid = false;
     return OC_OK;
@@ -2220,6 +2283,7 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
     A.step = simu_step;
     A.cnt_out = counters ? counters : S.ctrl;
     const KeyDev* kd = (const KeyDev*)h->key_tables_dev;
+    const int lazy = (h->lazy_state != 0 && comm == nullptr) ? 1 : 0;       // (the sharded step keeps the arrays current)
     const int ns = h->pair_split, tpb = 4 / ns, ntl = share.hi - share.lo;
     const int npair = (ntl + tpb - 1) / tpb;
     // prep blocks: one tile per wavefront while that takes at most `prep_blocks` blocks; beyond, k tiles per wavefront
@@ -2277,7 +2341,11 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
     oc_timer_begin(h, "gcfm_finish", s);
     hipLaunchKernelGGL(k_finish<false>, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
                        (int)h->fields.size(), A, 0, 0.0, err_slots, n_err_slots, err_stride, kd,
-                       h->any_ring ? ksteps : (KeyStep*)nullptr);
+                       h->any_ring ? ksteps : (KeyStep*)nullptr, lazy);
+    if (lazy) {
+        h->state_dirty = true;
+        h->dirty_agents = *a;
+    }
     if (h->any_ring) h->ring_step_ready = (int64_t)simu_step + 1;
     oc_timer_end(h, "gcfm_finish", s);
     OC_HIP_CHECK(hipGetLastError());
@@ -2329,6 +2397,7 @@ extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t
     OC_REQUIRE(perm || a->N == 0, "the sequential step needs the permutation");
     OC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    if ((rc = flush_state_impl(h, s))) return rc;      // (this mode reads and writes the caller's arrays every round)
     Scratch S;
     if ((rc = carve(h, a->N, &S))) return rc;
     GcfmParams P = make_params(h);
@@ -2462,6 +2531,7 @@ extern "C" int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t si
                "oc_step_comm.comm_slot names no communicator of this rank / world (oc_comm_create)");
     OC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    if ((rc = flush_state_impl(h, s))) return rc;
     Scratch S;
     if ((rc = carve(h, a->N, &S))) return rc;
     GcfmParams P = make_params(h);

@@ -268,7 +268,15 @@ extern "C" int oc_set_key_targets(oc_handle* h, int key, const double* rects, in
 
 extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     OC_REQUIRE(h && name, "null argument");
-    if (!strcmp(name, "pair_split")) {
+    if (!strcmp(name, "lazy_state")) {
+        OC_REQUIRE(value == 0 || value == 1, "lazy_state must be 0 or 1");
+        if (value == 0 && h->state_dirty) {     // (back to "every step leaves the arrays current": make them so now)
+            int rcf = oc_flush_state(h, nullptr);
+            if (rcf) return rcf;
+            OC_HIP_CHECK(hipStreamSynchronize(nullptr));
+        }
+        h->lazy_state = value;
+    } else if (!strcmp(name, "pair_split")) {
         OC_REQUIRE(value == 1 || value == 2 || value == 4, "pair_split must be 1, 2 or 4");
         h->pair_split = value;
     } else if (!strcmp(name, "prep_blocks")) {

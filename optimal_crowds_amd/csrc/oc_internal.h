@@ -193,6 +193,9 @@ struct oc_handle {
     bool packed_valid = false;  // the packed snapshot matches the caller's state arrays
     const void* packed_x = nullptr;
     int32_t packed_N = -1;
+    int lazy_state = 0;         // 1: oc_gcfm_step leaves the caller's state arrays to k_flush_state (oc_set_tuning "lazy_state")
+    bool state_dirty = false;   // the caller's x / y / vx / vy / agent_time are behind the packed snapshot (flush_state)
+    oc_agents dirty_agents;     // ... namely these arrays
     bool wprev_valid = false;   // the wall searches' incumbents (gcfm.hip: Scratch::wprev) belong to the packed agents
     int wall_warm = 1;          // 1: a wall search starts from the cell the previous step found (oc_set_tuning "wall_warm")
     bool packed_seq = false;    // the snapshot has only been advanced by sequential steps since its re-sort
@@ -266,6 +269,9 @@ int oc_comm_allreduce_sum_f64(oc_handle* h, int slot, double* buf, int64_t count
 int oc_comm_exchange_halo(oc_handle* h, int slot, const void* send_up, void* recv_up, const void* send_dn, void* recv_dn,
                           size_t bytes, int has_up, int has_dn, hipStream_t s);
 void oc_comm_destroy_all(oc_handle* h);
+
+// lazy_state (gcfm.hip): bring the caller's state arrays up to date with the packed snapshot, if they are behind
+int oc_flush_state(oc_handle* h, hipStream_t s);
 
 // timers (oc_api.hip)
 void oc_timer_begin(oc_handle* h, const char* name, hipStream_t s);

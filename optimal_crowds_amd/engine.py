@@ -79,6 +79,33 @@ class _Field:
         return iter((self[0], self[1], self.nslice, self.nt))
 
 
+class _AgentState(dict):
+    """The agents' SoA tensors.  With lazy_state (Engine.lazy_state, the default) a step leaves x / y / vx / vy / agent_time
+    in the library's slot-ordered snapshot instead of scattering them into these tensors (oc_hip.h: oc_agents_sync); reading
+    one of them here brings them up to date first, so that callers keep seeing "the step updated the state in place"."""
+    _LAZY = ("x", "y", "vx", "vy", "agent_time")
+
+    def __init__(self, eng, *a, **kw):
+        super().__init__(*a, **kw)
+        self._eng = eng
+
+    def __getitem__(self, k):
+        if k in self._LAZY:
+            self._eng.flush_state()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def values(self):
+        self._eng.flush_state()
+        return super().values()
+
+    def items(self):
+        self._eng.flush_state()
+        return super().items()
+
+
 class Engine:
     def __init__(self, cfg, room_length, room_height, Nx, Ny, X0, Y0, n_keys, max_agents,
                  device="cuda:0", dtype="float32", wall_search_radius=0.0, field_mode="ring"):
@@ -133,6 +160,11 @@ class Engine:
         self._hjb_variant = 0
         self._prof_mode = 0
         self.overlap_solves = os.environ.get("OC_OVERLAP_SOLVES", "1") != "0"
+        # lazy_state: steps keep the agents' state in the library's snapshot; the tensors in self.agents are brought up to
+        # date when somebody reads them (_AgentState) -- OC_LAZY_STATE=0 / set_lazy_state(False): scattered in every step
+        self._state_behind = False
+        self.lazy_state = False
+        self.set_lazy_state(os.environ.get("OC_LAZY_STATE", "1") != "0")
         self.V = [None] * n_keys
         self.fields = [None] * n_keys
         self.coef = torch.empty((Ny, Nx), dtype=self.tdtype, device=self.device)
@@ -185,8 +217,22 @@ class Engine:
         check(self.lib.oc_set_resort_every(self.h, int(steps)))
 
     def agents_changed(self):
-        """Call after modifying the agent tensors in place between steps."""
+        """Call after modifying the agent tensors in place between steps (tensors taken from self.agents[...] are current:
+        reading them there synchronises first)."""
+        self._state_behind = False
         check(self.lib.oc_agents_changed(self.h))
+
+    def set_lazy_state(self, on):
+        """oc_set_tuning("lazy_state"): leave x / y / vx / vy / agent_time in the library's snapshot between steps"""
+        self.flush_state()
+        check(self.lib.oc_set_tuning(self.h, b"lazy_state", 1 if on else 0))
+        self.lazy_state = bool(on)
+
+    def flush_state(self):
+        """bring the tensors of self.agents up to date with the steps enqueued so far (oc_agents_sync; on the current stream)"""
+        if self._state_behind:
+            self._state_behind = False
+            check(self.lib.oc_agents_sync(self.h, self.stream()))
 
     def set_hjb_variant(self, variant):
         self._hjb_variant = int(variant)
@@ -608,8 +654,9 @@ class Engine:
         N = len(x)
         mk = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         st = np.ones(N, dtype=np.uint8) if status is None else np.ascontiguousarray(status, dtype=np.uint8)
-        self.agents = dict(
-            N=N, x=mk(x), y=mk(y), vx=mk(vx), vy=mk(vy), v_des=mk(v_des),
+        self._state_behind = False
+        self.agents = _AgentState(
+            self, N=N, x=mk(x), y=mk(y), vx=mk(vx), vy=mk(vy), v_des=mk(v_des),
             status=torch.as_tensor(st).to(dev),
             key=torch.as_tensor(np.ascontiguousarray(key, dtype=np.int32)).to(dev),
             agent_time=mk(np.zeros(N) if agent_time is None else agent_time))
@@ -633,6 +680,7 @@ class Engine:
 
     def _with_probe(self, x, y, vx, vy, v_des, key, fn):
         """Run fn() with a temporary agent set (single-point queries of the facade), then restore."""
+        self.flush_state()
         saved = (self.agents, self._astruct)
         try:
             self.set_agents(x, y, vx, vy, v_des, key)
@@ -676,6 +724,7 @@ class Engine:
             noise = torch.as_tensor(np.ascontiguousarray(noise, dtype=np.float64)).to(self.device)
         check(self.lib.oc_gcfm_step(self.h, C.byref(self._astruct), int(simu_step), _ptr(noise),
                                     C.c_uint64(int(seed)), _ptr(self.counters), self.stream()))
+        self._state_behind = self.lazy_state
         if sync:
             c = self.counters.cpu().numpy()
             return int(c[0]), int(c[1]), int(c[2])

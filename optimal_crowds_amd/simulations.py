@@ -226,6 +226,7 @@ class simulation:
         if record and self.N > 0:
             self._rec = torch.empty((nt0 + 3, 4, self.N), dtype=torch.float64, device=eng.device)
             self._rec_status = torch.empty((nt0 + 3, self.N), dtype=torch.uint8, device=eng.device)
+            eng.set_lazy_state(False)       # (the recorder reads the state after every step: keep it current in the arrays)
             self._record(0)
         self._history_on = (self._rec is not None) if history is None else bool(history)
         self.history = _History(self)
@@ -425,6 +426,7 @@ class simulation:
 
     def _density_of(self, x, y, status, sigma):
         eng = self._engine
+        eng.flush_state()
         saved, sstruct = eng.agents, eng._astruct
         try:
             eng.set_agents(x.cpu().numpy(), y.cpu().numpy(), np.zeros(self.N), np.zeros(self.N), self._v_des,
