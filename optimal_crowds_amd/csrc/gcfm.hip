@@ -1531,7 +1531,9 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     if (SEQ && seq_round > 0 && S.seq_ctl[(seq_round - 1) & 3] == 0) return;      // (a round enqueued past the last level)
     if (SEQ && it == 0 && lane == 0) S.seq_ctl[5] = seq_round + 1;
     // the NEXT step's ring lookups (interpolant ring: slice -> slot, factors): resolved here, once per key, off every path
-    if (ksteps != nullptr && it == (int)gridDim.x - 1)
+    // (by block 0, the first to be dispatched: its two dependent loads per key -- slice table, slot record -- end long before
+    // the launch does; in the last block they were the launch's tail)
+    if (ksteps != nullptr && it == 0)
         for (int q = lane; q < nkeys; q += 64) ring_step_prepare(keys[q], A.step + 1, ksteps[q]);
     const bool tab_lds = nkeys <= RECT_KEYS_LDS;
     if (tab_lds)

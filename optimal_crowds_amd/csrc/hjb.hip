@@ -1067,7 +1067,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         // the host's mailbox last (pinned host memory: posted writes over PCIe, nothing of the tail waits behind them)
         if (threadIdx.x == 0) {
             const HjbCtl<T>& c = s_tail.c;
-            A.mailbox[1] = A.active_set ? (c.dense_mode ? (double)nb : (double)c.work_count) : (double)nb;
+            A.mailbox[1] = A.active_set ? (c.dense_mode ? (double)nb + 0.5 : (double)c.work_count) : (double)nb;
             A.mailbox[0] = (double)c.ticks + (c.done ? 4294967296.0 : 0.0);
         }
     };
@@ -1446,7 +1446,8 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
     if (todo == 2) {                                // every tile is active and stays so: no flags, no list from now on
         if (threadIdx.x == 0) {
             ctl->dense_mode = 1;
-            if (mailbox) mailbox[1] = (double)ntile;
+            if (mailbox) mailbox[1] = (double)ntile + 0.5;       // (+ 0.5: "every tile, for the rest of the solve" -- the host
+                                                                 // stops enqueuing the list builder's launch)
         }
         return;
     }
@@ -2373,7 +2374,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         if (prof) event();
         if (!ring) {
             launch_out<T, TO, true>(h->out_tile, S.Nx, S.Ny, s, OA);
-        } else if (active_set && !fused) {  // no slice writer beside which the list could be built: its own (one-block) launch
+        } else if (active_set && !fused && seen != (double)nb3 + 0.5) {
+            // no slice writer beside which the list could be built: its own (one-block) launch -- until the device has
+            // posted dense_mode (every tile active for the rest of the solve: C5's re-solves under the crowd's density,
+            // 2 200 launches of ~5 us per run that did nothing)
             hipLaunchKernelGGL(k_list<T>, dim3(1), dim3(256), 0, s, ctl_nxt, (const int32_t*)OA.flags, OA.flags_next, OA.work,
                                OA.parts_rw, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty, (volatile double*)mb_dev);
         }
@@ -2430,8 +2434,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             done = hc.done != 0;
         }
     }
+    // (the solve's last copies go through ITS stream: hipMemcpy works on the null stream, which serialises with whatever a
+    // concurrent solve of another key -- Engine.solve_keys -- has enqueued there)
+    OC_HIP_CHECK(hipMemcpyAsync(&hc, ctlb[enq & 1], sizeof(hc), hipMemcpyDeviceToHost, s));   // (what the last controller left)
     OC_HIP_CHECK(hipStreamSynchronize(s));
-    OC_HIP_CHECK(hipMemcpy(&hc, ctlb[enq & 1], sizeof(hc), hipMemcpyDeviceToHost));     // (what the last controller left)
     if (hc.status != 0) {
         if (hc.status == OC_ERR_SOLVER - 200) {
             oc_set_error("hjb_solve_ring: more than %d accepted steps (t = %g reached): the ring is too small", R.cap, hc.t);
@@ -2441,8 +2447,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         else oc_set_error("RK45: NaN error norm at t=%g (state overflow?)", hc.t);
         return OC_ERR_SOLVER;
     }
+    OcRingHead rh;
     if (ring) {
-        OcRingHead rh;
         memset(&rh, 0, sizeof(rh));
         rh.n_slots = hc.n_accept;
         rh.nt = nt;
@@ -2450,7 +2456,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         rh.nslice = R.nslice;
         rh.te_step = hc.te_step;
         rh.Tfinal = hc.Tfinal;
-        OC_HIP_CHECK(hipMemcpy(R.head, &rh, sizeof(rh), hipMemcpyHostToDevice));
+        OC_HIP_CHECK(hipMemcpyAsync(R.head, &rh, sizeof(rh), hipMemcpyHostToDevice, s));     // (rh lives until the sync below)
         if (n_keep > 0) {               // the audit output: phi at the kept t_eval points, from the ring
             int rc2 = ring_emit<T, TO>(h, R, hc.n_accept, 0, nt, nullptr, nullptr, phi_keep, keep_slot_dev, s);
             if (rc2) return rc2;
@@ -2461,7 +2467,9 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // (the controller's ticks, not the attempts enqueued: with the fused tail an attempt past the end of the solve returns
     // before anything is logged, and its slot holds an older solve's word)
     std::vector<int32_t> log((size_t)std::max(std::min(std::min(enq, (int)hc.ticks), LOG_CAP), 0));
-    if (!log.empty()) OC_HIP_CHECK(hipMemcpy(log.data(), h->hjb_log, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost));
+    if (!log.empty())
+        OC_HIP_CHECK(hipMemcpyAsync(log.data(), h->hjb_log, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost, s));
+    OC_HIP_CHECK(hipStreamSynchronize(s));
     for (size_t a = 0; a < log.size(); ++a)
         if (log[a] & 2) stats.n_slices_written += log[a] >> 8;
     if (prof_on) {
