@@ -240,8 +240,9 @@ int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step, const doub
  * permutation `perm` (device int32 (N): perm[0] moves first; the host draws it like simulations.py:271 does), and
  * agent i sees the NEW position / velocity / status of every agent visited before it.  The library level-schedules the
  * permutation: an agent moves as soon as all earlier agents within cutoff + 2 M of it have moved (M = "seq_margin_mm",
- * default 250 mm, a bound on one step's displacement that every round verifies; a violation is OC_ERR_STATE), one pair
- * of launches per level, so the result equals the one-by-one loop up to float32 pair arithmetic and summation order.
+ * default 250 mm, a bound on one step's displacement that every round verifies; a violation is OC_ERR_STATE): every agent's
+ * number of earlier agents within reach is counted once per step and released as they move, one pair of launches per
+ * level, so the result equals the one-by-one loop up to float32 pair arithmetic and summation order.
  * noise as in oc_gcfm_step (noise[i] = agent i's draw, whatever its place in the permutation).  rounds_out (host, may be
  * NULL): number of levels.  The levels are looped on the device: the host enqueues as many rounds as the previous step
  * needed (plus a margin), rounds past the last level return at once, and it synchronises ONCE per step (again only if the

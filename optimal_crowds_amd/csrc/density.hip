@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(256) k_density(DensParams P, const double2* __
                                                  const int32_t* __restrict__ cs, const double* __restrict__ X0,
                                                  const double* __restrict__ Y0, const float* __restrict__ Vall,
                                                  T* __restrict__ out) {
-    __shared__ double lex[DB][DT_X], ley[DB][DT_Y];            // 48 KB
+    // (rows padded by one double: the factor table is WRITTEN one row per lane -- agent fq = lane -- and an unpadded row of
+    // 32 doubles put all 64 lanes of a store on the same banks: a third of the LDS cycles of the launch were conflicts)
+    __shared__ double lex[DB][DT_X + 1], ley[DB][DT_Y + 1];    // 51 KB
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int j0 = blockIdx.x * DT_X, i0 = blockIdx.y * DT_Y;
     const int j1 = min(j0 + DT_X - 1, P.Nx - 1), i1 = min(i0 + DT_Y - 1, P.Ny - 1);

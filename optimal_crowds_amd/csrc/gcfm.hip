@@ -143,6 +143,8 @@ struct Scratch {
     int32_t* ctrl;
     int32_t* seq_rank;      // sequential mode: position of the slot's agent in the step's permutation
     int32_t* seq_state;     // 0 = not yet updated this step, 1 = being updated in this round, 2 = updated (or no agent)
+    int32_t* seq_dep;       // earlier agents within reach that have not moved yet (k_seq_count; released by k_finish<true>)
+    double2* seq_pos0;      // the slot's position at the start of the step (the reach test's positions; 1e300: no agent)
     int32_t* seq_ctl;       // [0..3]: agents still pending after round r (slot r & 3); [4]: displacement-bound violations;
                             // [5]: rounds that advanced somebody (= the permutation's dependency levels)
     int32_t Np, ntiles;
@@ -175,6 +177,11 @@ struct Axis {
 __device__ __forceinline__ double wmin(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 __device__ __forceinline__ double wmax(double v) {
@@ -1512,13 +1519,39 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
     }
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// The candidate tiles of tile `it` in the sequential mode: its neighbour list as it stands (cutoff + 2 drift around the
+// sort-time boxes: covers cutoff + 2 M around every position of the step), or every tile when the lists are not valid.  The
+// dependency count and its release walk the SAME tiles with the SAME positions (seq_pos0), so an agent counted is an agent
+// released.
+struct SeqCand {
+    const int32_t* nb;
+    int cnt;
+    __device__ __forceinline__ SeqCand(const Scratch& S, int it) {
+        nb = S.nb_list + (size_t)it * (NB_MAX + 1);
+        const int c = nb[0];
+        const bool use_list = (c >= 0) && (S.ctrl[C_INVALID] == 0);
+        cnt = use_list ? c : -S.ntiles;             // (< 0: all tiles 0 .. -cnt - 1)
+    }
+    __device__ __forceinline__ int size() const { return cnt >= 0 ? cnt : -cnt; }
+    __device__ __forceinline__ int tile(int e) const { return cnt >= 0 ? nb[1 + e] : e; }
+};
+
 #define RECT_TAB (1 + 4 * OC_MAX_TARGET_RECTS)      // doubles per key in the exit-rectangle table: count, then (cx,cy,w,h)
 #define RECT_KEYS_LDS 8
 
 // simulations.py:303-332 for the 64 agents of a tile, float64, then the next step's packed snapshot in place.
 // Everything is read by slot and was prepared by k_forces: one level of loads.
-// SEQ (sequential mode, k_seq_pairs below): only the agents marked for this round (seq_state == 1) are advanced; the
-// others keep their records.  `seq_round` selects the slot of the pending counter, `seq_margin` is the displacement
+// SEQ (sequential mode, k_seq_go below): only the agents marked for this round (seq_state == 1) are advanced; the
+// others keep their records; every agent advanced is then taken off the dependency counts of the LATER agents within reach.  `seq_round` selects the slot of the pending counter, `seq_margin` is the displacement
 // bound the round's independence rests on (a larger move raises seq_ctl[4]).
 template <bool SEQ>
 __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const double* __restrict__ rect_tab, int nkeys,
@@ -1628,6 +1661,37 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
     if (SEQ) {      // agents that still wait for an earlier neighbour: the host launches rounds until none is left
         const unsigned long long m_pend = __ballot(live && sstate == 0);
         if (lane == 0 && m_pend) atomicAdd(&S.seq_ctl[seq_round & 3], __popcll(m_pend));
+        // release: the agents advanced here no longer hold back the later agents within reach (the positions and the reach
+        // of k_seq_count: earlier minus later, the same operands in the same order)
+        unsigned long long am = __ballot(act);
+        if (am) {
+            const int rank_me = S.seq_rank[k];
+            const double2 p0 = S.seq_pos0[k];
+            const double reach = P.cutoff + 2.0 * seq_margin, reach2 = reach * reach;
+            const SeqCand cand(S, it);
+            const int nc = cand.size();
+            while (am) {
+                const int f = __ffsll((long long)am) - 1;
+                am &= am - 1;
+                const int rf = __builtin_amdgcn_readlane(rank_me, f);
+                const double fx0 = readlane_f64(p0.x, f), fy0 = readlane_f64(p0.y, f);
+                for (int e = 0; e < nc; e += 4) {               // (four tiles' loads in flight per trip: the chain is latency)
+                    int jj[4], rj[4];
+                    double2 pj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        jj[u] = (e + u < nc) ? cand.tile(e + u) * 64 + lane : -1;
+                        rj[u] = (jj[u] >= 0) ? S.seq_rank[jj[u]] : 0x7FFFFFFF;
+                        pj[u] = (jj[u] >= 0) ? S.seq_pos0[jj[u]] : make_double2(1e300, 1e300);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double dx = fx0 - pj[u].x, dy = fy0 - pj[u].y;
+                        if (rj[u] > rf && rj[u] != 0x7FFFFFFF && dx * dx + dy * dy < reach2) atomicSub(&S.seq_dep[jj[u]], 1);
+                    }
+                }
+            }
+        }
     }
     // counters: only exits touch them (one word takes ~88 atomics per us: 1563 tiles adding to one counter every step
     // would cost more than the rest of this kernel)
@@ -1683,10 +1747,12 @@ __global__ void __launch_bounds__(256) k_flush_state(Scratch S, double* __restri
 // permutation and lies within cutoff + 2 M of it has been advanced (M = bound on one step's displacement, checked by
 // k_finish<true>): two agents advanced in the same round are then farther apart than the cutoff before and after their
 // moves, so neither contributes to the other, and each reads exactly the state the one-by-one loop would have shown
-// it -- new records of the earlier neighbours, old records of the later ones.  A round = k_seq_pairs (who is free to
-// go + their pair sums from the LIVE records) + k_finish<true> (advance them in place); the rounds' number is the
-// depth of the permutation's dependency graph (tens at crowd densities), so this mode costs that many launches per
-// step: it exists for trajectory-level parity with the reference, the synchronous step is the fast path.
+// it -- new records of the earlier neighbours, old records of the later ones.  Once per step k_seq_count gives every agent
+// the number of earlier agents within reach; a round = k_seq_go (the agents whose count has reached zero: their pair sums
+// from the LIVE records) + k_finish<true> (advance them in place and take them off the counts of the later agents within
+// reach); the rounds' number is the depth of the permutation's dependency graph (tens to hundreds at crowd densities), so
+// this mode costs that many launch pairs per step: it exists for trajectory-level parity with the reference, the
+// synchronous step is the fast path.
 __global__ void k_seq_invperm(const int32_t* __restrict__ perm, int N, int32_t* __restrict__ inv) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < N) {
@@ -1702,29 +1768,60 @@ __global__ void k_seq_init(Scratch S, const int32_t* __restrict__ inv) {
     const int i = S.snap.pidx[k];
     S.seq_rank[k] = (i >= 0) ? inv[i] : 0x7FFFFFFF;
     S.seq_state[k] = (i >= 0) ? 0 : 2;
+    S.seq_dep[k] = 0;
+    S.seq_pos0[k] = S.snap.ppos[k];
 }
 
 struct SeqLds {
     double2 pos[64];
-    float4 vel[64];
-    float2 head[64];
-    int32_t rank[64], state[64];
+    int32_t rank[64];
 };
 
-// one wavefront per tile, one lane per agent i; every pair of the candidate tiles is visited (float64 distances, the
-// packed float32 force of pair_term2, float64 sums in slot order of the j's)
-__global__ void __launch_bounds__(64) k_seq_pairs(GcfmParams P, Scratch S, int round, double margin) {
+// Once per step: dep[i] = number of agents that come EARLIER in the permutation and lie within reach = cutoff + 2 M of agent
+// i at the start of the step -- those it has to wait for.  One wavefront per tile, one lane per agent, the candidate tiles'
+// positions and ranks staged through LDS.
+__global__ void __launch_bounds__(64) k_seq_count(GcfmParams P, Scratch S, double margin) {
     __shared__ SeqLds L;
+    const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
+    const int rank_i = S.seq_rank[k];
+    const double2 pi = S.seq_pos0[k];
+    const bool live = S.seq_state[k] == 0;
+    const double reach = P.cutoff + 2.0 * margin, reach2 = reach * reach;
+    const SeqCand cand(S, it);
+    int dep = 0;
+    for (int e = 0; e < cand.size(); ++e) {
+        const int jt = cand.tile(e);
+        __syncthreads();
+        L.pos[lane] = S.seq_pos0[jt * 64 + lane];
+        L.rank[lane] = S.seq_rank[jt * 64 + lane];
+        __syncthreads();
+        if (!live) continue;
+        for (int q = 0; q < 64; ++q) {
+            const double2 pa = L.pos[q];
+            const double dx = pa.x - pi.x, dy = pa.y - pi.y;
+            dep += (L.rank[q] < rank_i && dx * dx + dy * dy < reach2) ? 1 : 0;
+        }
+    }
+    S.seq_dep[k] = dep;
+}
+
+// One round, first launch: the agents that wait for nobody any more (dep == 0) get their pair sums from the LIVE records
+// -- new records of the earlier neighbours, old ones of the later -- and are marked for k_finish<true>.  A tile without such
+// an agent leaves after two loads; for a free agent the wavefront's lanes take the 64 records of a candidate tile each (two
+// tiles per trip, one in each half of the packed registers), and the lanes' float64 partial sums are added up across the
+// wavefront.  (Round 2 re-derived "who is free" from all pairs in every round and walked the candidate tiles one after the
+// other behind two barriers each: 230 us per level at 5 000 agents.)
+__global__ void __launch_bounds__(64) k_seq_go(GcfmParams P, Scratch S, int round) {
     const Snap& C = S.snap;
     const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
     if (it == 0 && lane == 0) S.seq_ctl[(round + 1) & 3] = 0;          // next round's pending counter
     // the levels are looped on the DEVICE: the host enqueues rounds a whole step ahead, and a round that finds nobody
     // pending after the one before it returns at once (one load per wavefront) -- no host round trip per level
     if (round > 0 && S.seq_ctl[(round - 1) & 3] == 0) return;
-    const int st_i = S.seq_state[k];
-    if (!__any(st_i == 0)) return;                                      // the whole tile has been advanced
     const int i = C.pidx[k];
-    const int rank_i = S.seq_rank[k];
+    const bool free_i = i >= 0 && S.seq_state[k] == 0 && S.seq_dep[k] == 0;
+    unsigned long long fm = __ballot(free_i);
+    if (!fm) return;
     const double2 pi = C.ppos[k];
     const float4 vi = C.pvel[k];
     const float2 hi = C.phead[k];
@@ -1738,74 +1835,62 @@ __global__ void __launch_bounds__(64) k_seq_pairs(GcfmParams P, Scratch S, int r
     const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
     const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
     const bool unit_dir = (P.fix & OC_FIX_PAIR_FORCE) != 0;
-    const double reach = P.cutoff + 2.0 * margin, reach2 = reach * reach;
-    const double4 bi = C.tile_box[it];
-    bool blocked = false;
-    double fx = 0.0, fy = 0.0;
-    const int32_t* nb = S.nb_list + (size_t)it * (NB_MAX + 1);
-    const int nb_cnt = nb[0];
-    const bool use_list = (nb_cnt >= 0) && (S.ctrl[C_INVALID] == 0);
-    const int nchunk = use_list ? 1 : (S.ntiles + 63) / 64;
-    // Two passes over the candidate tiles.  Pass 0: who is free to go -- positions, ranks and states only, a handful of
-    // instructions per pair.  Pass 1: the pair sums of the agents that ARE free -- in a round of a deep permutation that is
-    // one agent in a few tiles (5 000 agents at 2.5 / m^2: ~220 levels, ~23 agents per round), so most wavefronts leave
-    // after pass 0.  (One pass doing both recomputed every pending agent's whole pair sum in every round.)
-    for (int pass = 0; pass < 2; ++pass) {
-        const bool mine = i >= 0 && st_i == 0 && !blocked;         // pass 1: free agents only
-        if (pass == 1 && !__any(mine)) return;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            int t;
-            if (use_list) t = (lane < nb_cnt) ? nb[1 + lane] : -1;
-            else t = (ch * 64 + lane < S.ntiles) ? ch * 64 + lane : -1;
-            // (live boxes: read while other tiles may be advancing; a box only ever matters through agents that are within
-            // reach, and those are not being advanced in this round -- see the header)
-            const bool hit = (t >= 0) && box_hit(bi, C.tile_box[t], reach + margin);
-            unsigned long long tmask = __ballot(hit);
-            while (tmask) {
-                const int jt = __builtin_amdgcn_readlane(t, __ffsll((long long)tmask) - 1);
-                tmask &= tmask - 1;
-                __syncthreads();
-                L.pos[lane] = C.ppos[jt * 64 + lane];
-                if (pass == 0) {
-                    L.rank[lane] = S.seq_rank[jt * 64 + lane];
-                    L.state[lane] = S.seq_state[jt * 64 + lane];
-                } else {
-                    L.vel[lane] = C.pvel[jt * 64 + lane];
-                    L.head[lane] = C.phead[jt * 64 + lane];
-                }
-                __syncthreads();
-                if (!mine) continue;
-                if (pass == 0) {
-                    for (int q = 0; q < 64; ++q) {
-                        const double2 pa = L.pos[q];
-                        const double dxA = pa.x - pi.x, dyA = pa.y - pi.y;
-                        // an earlier neighbour that has not moved yet: wait for it
-                        blocked = blocked || (L.state[q] != 2 && L.rank[q] < rank_i && dxA * dxA + dyA * dyA < reach2);
-                    }
-                } else {
-                    for (int q = 0; q < 64; q += 2) {
-                        const double2 pa = L.pos[q], pb = L.pos[q + 1];
-                        const double dxA = pa.x - pi.x, dyA = pa.y - pi.y, dxB = pb.x - pi.x, dyB = pb.y - pi.y;
-                        const double d2A = dxA * dxA + dyA * dyA, d2B = dxB * dxB + dyB * dyB;
-                        const bool okA = d2A <= P.cut_d2max && d2A > 0.0, okB = d2B <= P.cut_d2max && d2B > 0.0;
-                        if (okA || okB) {
-                            const float4 va = L.vel[q], vb = L.vel[q + 1];
-                            const float2 ha = L.head[q], hb = L.head[q + 1];
-                            f2v gx, gy;
-                            pair_term2((f2v){(float)dxA, (float)dxB}, (f2v){(float)dyA, (float)dyB}, vi.x, vi.y, vi.z, hi.x, hi.y,
-                                       vi.w, ib2_i, inv_vdes, (f2v){va.x, vb.x}, (f2v){va.y, vb.y}, (f2v){va.z, vb.z},
-                                       (f2v){va.w, vb.w}, (f2v){ha.x, hb.x}, (f2v){ha.y, hb.y}, b_max, db, neg_inv_eta_log2e,
-                                       unit_dir, gx, gy);
-                            if (okA) { fx += (double)gx.x; fy += (double)gy.x; }
-                            if (okB) { fx += (double)gx.y; fy += (double)gy.y; }
-                        }
-                    }
-                }
+    const SeqCand cand(S, it);
+    const int nc = cand.size();
+    double my_fx = 0.0, my_fy = 0.0;
+    while (fm) {
+        const int f = __ffsll((long long)fm) - 1;
+        fm &= fm - 1;
+        // agent f's record, wave-uniform
+        const double px = readlane_f64(pi.x, f), py = readlane_f64(pi.y, f);
+        const float vxf = readlane_f32(vi.x, f), vyf = readlane_f32(vi.y, f), sf = readlane_f32(vi.z, f), ia2f = readlane_f32(vi.w, f);
+        const float hxf = readlane_f32(hi.x, f), hyf = readlane_f32(hi.y, f);
+        const float ib2f = readlane_f32(ib2_i, f), ivdf = readlane_f32(inv_vdes, f);
+        double fx = 0.0, fy = 0.0;
+        for (int e0 = 0; e0 < nc; e0 += 4) {                // (four tiles' positions in flight per trip: the chain is latency)
+            int jt4[4];
+            double2 p4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                jt4[u] = (e0 + u < nc) ? cand.tile(e0 + u) : -1;
+                p4[u] = (jt4[u] >= 0) ? C.ppos[jt4[u] * 64 + lane] : make_double2(1e300, 1e300);
             }
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int jtA = jt4[2 * h2], jtB = jt4[2 * h2 + 1];
+            const double2 pa = p4[2 * h2], pb = p4[2 * h2 + 1];
+            const double dxA = pa.x - px, dyA = pa.y - py, dxB = pb.x - px, dyB = pb.y - py;
+            const double d2A = dxA * dxA + dyA * dyA, d2B = dxB * dxB + dyB * dyB;
+            const bool okA = d2A <= P.cut_d2max && d2A > 0.0, okB = d2B <= P.cut_d2max && d2B > 0.0;
+            if (!__any(okA || okB)) continue;
+            float4 va = make_float4(0.f, 0.f, 0.f, 1.f), vb = va;
+            float2 ha = make_float2(1.f, 0.f), hb = ha;
+            if (okA) {
+                va = C.pvel[jtA * 64 + lane];
+                ha = C.phead[jtA * 64 + lane];
+            }
+            if (okB) {
+                vb = C.pvel[jtB * 64 + lane];
+                hb = C.phead[jtB * 64 + lane];
+            }
+            f2v gx, gy;
+            pair_term2((f2v){okA ? (float)dxA : 1.f, okB ? (float)dxB : 1.f}, (f2v){okA ? (float)dyA : 0.f, okB ? (float)dyB : 0.f},
+                       vxf, vyf, sf, hxf, hyf, ia2f, ib2f, ivdf, (f2v){va.x, vb.x}, (f2v){va.y, vb.y}, (f2v){va.z, vb.z},
+                       (f2v){va.w, vb.w}, (f2v){ha.x, hb.x}, (f2v){ha.y, hb.y}, b_max, db, neg_inv_eta_log2e, unit_dir, gx, gy,
+                       okA, okB);
+            fx += (double)gx.x + (double)gx.y;
+            fy += (double)gy.x + (double)gy.y;
+          }
+        }
+        fx = wsum(fx);
+        fy = wsum(fy);
+        if (lane == f) {
+            my_fx = fx;
+            my_fy = fy;
         }
     }
-    if (i >= 0 && st_i == 0 && !blocked) {
-        xs(S, S.f_pair, S.ts_pair, k) = make_double2(fx, fy);
+    if (free_i) {
+        xs(S, S.f_pair, S.ts_pair, k) = make_double2(my_fx, my_fy);
         S.seq_state[k] = 1;
     }
 }
@@ -1929,7 +2014,7 @@ int carve(oc_handle* h, int N, Scratch* S, bool diag = false) {
     const int nt = Np / 64;
     const size_t per_snap = sizeof(double2) + sizeof(float4) + sizeof(float2) + sizeof(int32_t);
     const size_t per = 2 * sizeof(uint32_t) + 2 * sizeof(int32_t) + per_snap + sizeof(double2) + sizeof(PDK) +
-                       3 * sizeof(double2) + sizeof(long long) + sizeof(int32_t) + sizeof(double);
+                       3 * sizeof(double2) + sizeof(long long) + sizeof(int32_t) + sizeof(double) + sizeof(int32_t) + sizeof(double2);
     size_t need = (per + 2 * sizeof(int32_t)) * (size_t)Np + (6 * sizeof(double4) + (NB_MAX + 3) * sizeof(int32_t)) * (size_t)nt +
                   1024 + 16384;
     if (need > h->gcfm_bytes) {
@@ -1986,6 +2071,8 @@ int carve(oc_handle* h, int N, Scratch* S, bool diag = false) {
     S->tile_order = (int32_t*)take(sizeof(int32_t) * nt);
     S->seq_rank = (int32_t*)take(sizeof(int32_t) * Np);
     S->seq_state = (int32_t*)take(sizeof(int32_t) * Np);
+    S->seq_dep = (int32_t*)take(sizeof(int32_t) * Np);
+    S->seq_pos0 = (double2*)take(sizeof(double2) * Np);
     S->Np = Np;
     S->ntiles = nt;
     return OC_OK;
@@ -2389,7 +2476,7 @@ extern "C" int oc_gcfm_step(oc_handle* h, const oc_agents* a, int32_t simu_step,
 }
 
 
-// One SEQUENTIAL step (see k_seq_pairs): the caller's permutation and noise, rounds until every active agent has moved.
+// One SEQUENTIAL step (see k_seq_go): the caller's permutation and noise, rounds until every active agent has moved.
 extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t simu_step, const int32_t* perm,
                                        const double* noise, uint64_t seed, int32_t* counters, int32_t* rounds_out,
                                        void* stream) {
@@ -2442,6 +2529,8 @@ extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t
         hipLaunchKernelGGL(kf, dim3(nprep), dim3(256), 0, s, P, S, kd, (const KeyStep*)h->key_steps_dev, simu_step, axis_x(h),
                            axis_y(h), nprep, all, A.cnt_out);
     }
+    // every agent's count of earlier agents within reach, once per step (start-of-step positions: k_seq_init kept them)
+    hipLaunchKernelGGL(k_seq_count, dim3(S.ntiles), dim3(64), 0, s, P, S, margin);
     GcfmParams Pf = P;
     Pf.drift = P.drift - margin;            // validity bound of the neighbour lists in this mode (see above)
     // ONE host synchronisation per step: as many rounds as the last step needed (+ a margin) are enqueued at once; rounds
@@ -2452,7 +2541,7 @@ extern "C" int oc_gcfm_step_sequential(oc_handle* h, const oc_agents* a, int32_t
     int batch = std::max(8, h->seq_rounds_hint + std::max(4, h->seq_rounds_hint / 8));
     while (pending > 0) {
         for (int b = 0; b < batch; ++b, ++rounds) {
-            hipLaunchKernelGGL(k_seq_pairs, dim3(S.ntiles), dim3(64), 0, s, P, S, rounds, margin);
+            hipLaunchKernelGGL(k_seq_go, dim3(S.ntiles), dim3(64), 0, s, P, S, rounds);
             hipLaunchKernelGGL((k_finish<true>), dim3(S.ntiles), dim3(64), 0, s, Pf, S, (const double*)h->rect_tab_dev,
                                (int)h->fields.size(), A, rounds, margin, (const double*)nullptr, 0, (int64_t)1, kd,
                                (KeyStep*)nullptr);
