@@ -109,6 +109,9 @@ def run_steps(sim, K, nt, timed_stats=None, update="synchronous", levels=None):
         else:
             eng.step(s, noise=None, seed=sim._seed + done // nt, sync=False)
         done += 1
+    # lazy_state (the engine's default, include/oc_hip.h: oc_agents_sync): the steps keep the agents' state in the library's
+    # slot-ordered snapshot; the caller's arrays are brought up to date at the re-sorts and HERE, inside the timed region
+    eng.flush_state()
 
 
 def host_cores():
@@ -531,6 +534,9 @@ def main():
                    + (", recompute=True" if sim.recompute else ""),
                    "parallelism": parallelism, "mode": "sharded" if sharded else ("ensemble" if world > 1 else "single"),
                    "noise": "device Philox", "agent_state": "f64", "pair_math": "f32",
+                   "agent_arrays": ("lazy_state: the caller's x / y / vx / vy / agent_time are scattered at the re-sorts and at "
+                                    "the end of the timed region (oc_agents_sync), not in every step") if eng.lazy_state
+                   else "scattered in every step",
                    "update": ("sequential: the reference's one-by-one order in a fresh permutation per step, level-scheduled "
                               "(mean %.1f levels per step, max %d)" % (float(np.mean(seq_levels)), max(seq_levels))
                               if seq_levels else "synchronous (frozen snapshot)"),
