@@ -57,3 +57,38 @@ def test_the_product_never_touches_the_oracle():
     for src in ("csrc/oc_api.hip", "csrc/hjb.hip", "csrc/gcfm.hip", "csrc/density.hip", "csrc/raster.hip", "csrc/sort.hip"):
         txt = open(os.path.join(REPO, "optimal_crowds_amd", src)).read()
         assert not re.search(r'#include\s*[<"][^>"]*oracle|liboc_oracle|occ_', txt)      # (comments may cite the oracle)
+
+
+def test_source_hash_ignores_comments_and_white_space(tmp_path, monkeypatch):
+    """bench.csrc_hash stamps the counter files: rewording a comment must not make them stale, changing code must"""
+    sys.path.insert(0, REPO)
+    import bench
+    d = tmp_path / "optimal_crowds_amd" / "csrc"
+    d.mkdir(parents=True)
+    (d / "a.hip").write_text("// one\nint f(int x) { return x + 1; }   /* two */\n")
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    h0 = bench.csrc_hash()
+    (d / "a.hip").write_text("// another comment\n\nint f(int x)   {\n  return x + 1;\n}\n")
+    assert bench.csrc_hash() == h0
+    (d / "a.hip").write_text("int f(int x) { return x + 2; }\n")
+    assert bench.csrc_hash() != h0
+
+
+def test_agent_state_dictionary_synchronises_before_a_read():
+    """Engine.agents with lazy_state: reading a state array goes through flush_state first; status / key / N do not"""
+    from optimal_crowds_amd.engine import _AgentState
+
+    class Eng:
+        n = 0
+
+        def flush_state(self):
+            self.n += 1
+    e = Eng()
+    a = _AgentState(e, N=3, x="X", y="Y", vx="VX", vy="VY", agent_time="T", status="S", key="K", v_des="D")
+    assert (a["N"], a["status"], a["key"], a["v_des"]) == (3, "S", "K", "D") and e.n == 0
+    assert a["x"] == "X" and e.n == 1
+    assert [a[k] for k in ("y", "vx", "vy", "agent_time")] == ["Y", "VX", "VY", "T"] and e.n == 5
+    assert a.get("x") == "X" and a.get("nope", 7) == 7 and e.n == 6
+    assert len(list(a.items())) == 9 and e.n == 7
+    assert isinstance(a, dict) and "x" in a                 # (membership tests do not synchronise)
+    assert e.n == 7
