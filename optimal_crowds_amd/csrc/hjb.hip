@@ -368,13 +368,18 @@ struct CtlLds {
 // block's size, so the launch shape never changes a decision.  ctl_in: the attempt's controller block; ctl_out: where the
 // next attempt's goes (the two alternate, so that a late block of the attempt's own launch never reads a block that the
 // fused tail is already rewriting).
-template <typename T, bool SC1>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `beside`: called by EVERY thread between the controller's serial section (thread 0) and the barrier behind it -- the
+// other wavefronts run it while thread 0 decides (the fused tail's list builder does its decision-independent part there)
+template <typename T, bool SC1, typename HOOK = NoHook>
 __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_in, HjbCtl<T>* __restrict__ ctl_out,
                                              const double* parts, int nparts, double* __restrict__ t_steps, int t_cap,
                                              int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox,
                                              int active_set, OcRingSlot<T>* __restrict__ rslots,
                                              OcRingSlice<T>* __restrict__ rslices, int ring_cap, CtlLds<T>& L,
-                                             bool store_out = true, bool ctl_loaded = false) {
+                                             bool store_out = true, bool ctl_loaded = false, HOOK beside = HOOK()) {
     HjbCtl<T>& c = L.c;
     double (&ls)[4] = L.ls, (&lm)[4] = L.lm, (&la)[4] = L.la;
     int& all_active = L.all_active;
@@ -513,6 +518,7 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
         if (tk - 1 < log_cap) att_log[tk - 1] = logw;
         if (mailbox) mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
     }
+    beside();
     __syncthreads();
     // what does not depend on anything but the decision's scalars is dealt to the lanes: the next attempt's 43
     // coefficients (threads 0..42) and the accepted step's dense-output factors (threads 64..; rk.py:560-575:
@@ -947,11 +953,20 @@ __device__ __forceinline__ bool is_pow2(double v) {
     return (b & 0x000FFFFFFFFFFFFFull) == 0ull && e != 0ull && e != 0x7FFull;
 }
 
+// what the list builder can do before the controller has decided (list_prepare): the thread's tiles, which of them go on
+// the list if the buffers hold the trivial values already, and the wavefront's prefix sum of the counts
+struct ListPre {
+    uint32_t listed, listed_hi;
+    int mine, incl, t_lo, t_hi;
+    bool valid;
+};
 template <typename T, bool SC1>
 __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __restrict__ flags_cur,
                                                 int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
                                                 double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* sflag, int nbytes,
-                                                volatile double* mailbox, bool flags_ready);
+                                                volatile double* mailbox, bool flags_ready, const ListPre* pre = nullptr,
+                                                int32_t* wsum_ext = nullptr);
+__device__ __forceinline__ ListPre list_prepare(int tnbx, int tnby, const uint8_t* sflag, int32_t* wsum);
 
 // ---- lean multi-stage kernel: four cells of a row per thread, no per-cell index arithmetic ------------------------
 // (Round 1's multi-stage kernels dealt the region's cells to the threads round-robin; that cost ~100 instructions of
@@ -1046,13 +1061,23 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                     if (t0 + u * 256 < nb) sflag[t0 + u * 256] = f[u] != 0 ? 1 : 0;
             }
         }
+        // While thread 0 runs the controller's serial float64 part (~2.7 us), the other wavefronts form the list builder's
+        // decision-independent half from the flags just fetched: which tiles go on the next list if tiles may stay off it,
+        // the counts, the wavefronts' prefix sums (list_prepare; the barrier inside control_body that precedes the serial
+        // part has made the flag bytes visible, the one behind it publishes wsum).
+        __shared__ int32_t s_wsum[16];
+        ListPre lpre;
+        lpre.valid = false;
+        auto beside = [&]() {
+            if (pre_ok && s_tail.c.dense_mode == 0) lpre = list_prepare(nbx, nby, sflag, s_wsum);
+        };
         control_body<T, true>(ctl, A.ctl_out, A.partial, nb, A.t_steps, A.t_cap, A.att_log, A.log_cap, nullptr, A.active_set,
-                              A.rslots, A.rslices, A.ring_cap, s_tail, false, true);
+                              A.rslots, A.rslices, A.ring_cap, s_tail, false, true, beside);
         // (the tile buffers are free: the builder's flag bytes)
         static_assert(sizeof(buf) >= 12000, "the builder's flag bytes fit the tile buffers");
         if (A.active_set)
             build_work_list<T, true>(&s_tail.c, A.flags_cur, A.flags_next, A.work_next, A.partial, nbx, nby, sflag,
-                                     (int)sizeof(buf), nullptr, pre_ok);
+                                     (int)sizeof(buf), nullptr, pre_ok, &lpre, s_wsum);
         __syncthreads();
         if (threadIdx.x < 256) {
             constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
@@ -1433,13 +1458,15 @@ template <typename T, bool SC1>
 __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __restrict__ flags_cur,
                                                 int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
                                                 double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* sflag, int nbytes,
-                                                volatile double* mailbox, bool flags_ready) {
+                                                volatile double* mailbox, bool flags_ready, const ListPre* pre,
+                                                int32_t* wsum_ext) {
     // Called by every thread of the block (barriers inside), and every thread works: the builder is a chain of dependent
     // integer and LDS instructions per tile, so its length is the tiles per THREAD (8 per thread with 256 threads at
     // 2048 x 2048 took 8 us of the fused tail; 2 per thread with the stage block's 1024).  SC1: flags_cur was written by
     // other blocks of this very launch (fused tail) -- sc1 loads, see ld_part.
     // flags_ready: sflag[] already holds the tiles' flags (the fused tail's idle wavefronts fetched them meanwhile)
-    __shared__ int32_t wsum[16];
+    __shared__ int32_t wsum_own[16];
+    int32_t* const wsum = wsum_ext != nullptr ? wsum_ext : wsum_own;
     const int todo = ctl->list_todo, nth = (int)blockDim.x;
     const int ntile = tnbx * tnby;
     if (todo == 0) return;
@@ -1454,9 +1481,17 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
     const bool skip_ok = (ctl->rejected != 0 || (ctl->in_scale == (T)1 && ctl->out_in_scale == (T)1)) && ntile <= nbytes;
     // every thread owns a contiguous run of tiles (an ordered list keeps neighbouring tiles in neighbouring blocks)
     const int per_thr = (ntile + nth - 1) / nth;
-    const int t_lo = min((int)threadIdx.x * per_thr, ntile), t_hi = min(t_lo + per_thr, ntile);
+    int t_lo = min((int)threadIdx.x * per_thr, ntile), t_hi = min(t_lo + per_thr, ntile);
     uint32_t listed = 0xFFFFFFFFu, listed_hi = 0xFFFFFFFFu;     // bit q: tile t_lo + q goes on the list (per_thr <= 64)
-    if (skip_ok) {
+    // (fused tail: the tiles per thread, the masks, the counts and the wavefronts' prefix sums were formed by list_prepare
+    // while thread 0 ran the controller -- valid whenever the decision allows tiles to stay off the list, which is the rule)
+    const bool use_pre = pre != nullptr && pre->valid && skip_ok && wsum_ext != nullptr;
+    if (use_pre) {
+        listed = pre->listed;
+        listed_hi = pre->listed_hi;
+        t_lo = pre->t_lo;
+        t_hi = pre->t_hi;
+    } else if (skip_ok) {
         if (!flags_ready) {
             // (eight independent loads in flight per thread: as sc1 loads in a one-load-per-trip loop each trip waited for
             // its own round trip to the L2)
@@ -1497,16 +1532,21 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
     const uint32_t m_hi = nmine >= 64 ? 0xFFFFFFFFu : (nmine > 32 ? ((1u << (nmine - 32)) - 1u) : 0u);
     listed &= m_lo;
     listed_hi &= m_hi;
-    const int mine = __popc(listed) + __popc(listed_hi);
+    int mine = __popc(listed) + __popc(listed_hi);
     int incl = mine;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (nth + 63) >> 6;
+    if (use_pre) {
+        mine = pre->mine;
+        incl = pre->incl;           // (wsum[] was posted before the controller's barriers)
+    } else {
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
     }
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
     int off = incl - mine, total = 0;
     for (int q = 0; q < nwv; ++q) {
         off += q < wv ? wsum[q] : 0;
@@ -1531,6 +1571,58 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
         ctl->work_count = total;
         if (mailbox) mailbox[1] = (double)total;     // (the host picks the launch sequence by it: fused tail or not)
     }
+}
+
+// The decision-independent half of build_work_list, for the fused tail: called by every thread beside the controller's serial
+// section (sflag[] holds the attempt's flags and a barrier lies behind their stores).  Same masks and scan as there; the
+// tiles are dealt to wavefronts 1 .. only: wavefront 0 arrives when its thread 0 has decided, the others meanwhile (the list
+// comes out in the same -- ascending -- order of tiles either way).
+__device__ __forceinline__ ListPre list_prepare(int tnbx, int tnby, const uint8_t* sflag, int32_t* wsum) {
+    ListPre r;
+    const int nth = (int)blockDim.x - 64, ntile = tnbx * tnby, tid = (int)threadIdx.x - 64;
+    const int per_thr = (ntile + nth - 1) / nth;
+    const int t_lo = tid < 0 ? 0 : min(tid * per_thr, ntile), t_hi = tid < 0 ? 0 : min(t_lo + per_thr, ntile);
+    uint32_t listed = 0xFFFFFFFFu, listed_hi = 0xFFFFFFFFu;
+    int bi = t_lo / tnbx, bj = t_lo % tnbx;
+    for (int t = t_lo; t < t_hi; ++t) {
+        uint32_t q9 = 1u;
+#pragma unroll
+        for (int di = -1; di <= 1; ++di)
+#pragma unroll
+            for (int dj = -1; dj <= 1; ++dj) {
+                const int ni = bi + di, nj = bj + dj;
+                const bool inside = ni >= 0 && ni < tnby && nj >= 0 && nj < tnbx;
+                q9 &= inside ? (uint32_t)sflag[inside ? ni * tnbx + nj : t] : 1u;
+            }
+        const int q = t - t_lo;
+        if (q9) {
+            if (q < 32) listed &= ~(1u << q);
+            else listed_hi &= ~(1u << (q - 32));
+        }
+        if (++bj == tnbx) {
+            bj = 0;
+            ++bi;
+        }
+    }
+    const int nmine = t_hi - t_lo;
+    const uint32_t m_lo = nmine >= 32 ? 0xFFFFFFFFu : ((1u << max(nmine, 0)) - 1u);
+    const uint32_t m_hi = nmine >= 64 ? 0xFFFFFFFFu : (nmine > 32 ? ((1u << (nmine - 32)) - 1u) : 0u);
+    r.listed = listed & m_lo;
+    r.listed_hi = listed_hi & m_hi;
+    r.mine = __popc(r.listed) + __popc(r.listed_hi);
+    int incl = r.mine;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    r.incl = incl;
+    r.t_lo = t_lo;
+    r.t_hi = t_hi;
+    r.valid = per_thr <= 64;
+    return r;
 }
 
 template <typename T>
