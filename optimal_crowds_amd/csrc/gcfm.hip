@@ -1553,14 +1553,19 @@ struct SeqCand {
 // SEQ (sequential mode, k_seq_go below): only the agents marked for this round (seq_state == 1) are advanced; the
 // others keep their records; every agent advanced is then taken off the dependency counts of the LATER agents within reach.  `seq_round` selects the slot of the pending counter, `seq_margin` is the displacement
 // bound the round's independence rests on (a larger move raises seq_ctl[4]).
-template <bool SEQ>
-__global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const double* __restrict__ rect_tab, int nkeys,
+// WPB: tiles (wavefronts) per block.  One-wavefront blocks are bound by the rate at which workgroups can be dispatched:
+// at 500 000 agents the launch held ~330 of the chip's 8 192 wavefront slots on average (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES,
+// profiles/r03_open_room_pmc_step.json) -- 64 us for a kernel whose wavefronts live 2 us each.  The synchronous step packs
+// four tiles into a block.
+template <bool SEQ, int WPB = 1>
+__global__ void __launch_bounds__(64 * WPB) k_finish(GcfmParams P, Scratch S, const double* __restrict__ rect_tab, int nkeys,
                                                StepArgs A, int seq_round, double seq_margin,
                                                const double* __restrict__ err_slots, int n_err_slots, int64_t err_stride,
                                                const KeyDev* __restrict__ keys, KeyStep* __restrict__ ksteps, int lazy = 0) {
     __shared__ double l_rect[RECT_KEYS_LDS * RECT_TAB];
     const Snap& C = S.snap;
-    const int it = blockIdx.x, lane = threadIdx.x, k = it * 64 + lane;
+    static_assert(!SEQ || WPB == 1, "the sequential rounds keep one tile per block");
+    const int it = (int)blockIdx.x * WPB + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63, k = it * 64 + lane;
     if (SEQ && seq_round > 0 && S.seq_ctl[(seq_round - 1) & 3] == 0) return;      // (a round enqueued past the last level)
     if (SEQ && it == 0 && lane == 0) S.seq_ctl[5] = seq_round + 1;
     // the NEXT step's ring lookups (interpolant ring: slice -> slot, factors): resolved here, once per key, off every path
@@ -1570,7 +1575,11 @@ __global__ void __launch_bounds__(64) k_finish(GcfmParams P, Scratch S, const do
         for (int q = lane; q < nkeys; q += 64) ring_step_prepare(keys[q], A.step + 1, ksteps[q]);
     const bool tab_lds = nkeys <= RECT_KEYS_LDS;
     if (tab_lds)
-        for (int q = lane; q < nkeys * RECT_TAB; q += 64) l_rect[q] = rect_tab[q];
+        for (int q = threadIdx.x; q < nkeys * RECT_TAB; q += 64 * WPB) l_rect[q] = rect_tab[q];
+    if (WPB > 1 && it >= S.ntiles) {                // (the last block's spare wavefronts: the barrier, nothing else)
+        __syncthreads();
+        return;
+    }
     const int i = C.pidx[k];
     const int sstate = SEQ ? S.seq_state[k] : 1;
     const bool live = i >= 0;                       // an agent sits in this slot
@@ -2428,7 +2437,9 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
         }
     }
     oc_timer_begin(h, "gcfm_finish", s);
-    hipLaunchKernelGGL(k_finish<false>, dim3(S.ntiles), dim3(64), 0, s, P, S, (const double*)h->rect_tab_dev,
+    constexpr int FIN_WPB = 4;
+    hipLaunchKernelGGL((k_finish<false, FIN_WPB>), dim3((S.ntiles + FIN_WPB - 1) / FIN_WPB), dim3(64 * FIN_WPB), 0, s, P, S,
+                       (const double*)h->rect_tab_dev,
                        (int)h->fields.size(), A, 0, 0.0, err_slots, n_err_slots, err_stride, kd,
                        h->any_ring ? ksteps : (KeyStep*)nullptr, lazy);
     if (lazy) {

@@ -2419,11 +2419,11 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         const double seen = active_set ? (enq > 0 ? (double)mb[1] : (double)nb3) : (double)nb3;
         const bool fused = can_fuse && seen <= (double)FUSED_MAX;
         if (ring && fused) {
-            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true, true>), grid3, dim3(1024), 0, s, SA);
+            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true, true>), grid3, dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
         } else if (ring) {
-            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true>), grid3, dim3(1024), 0, s, SA);
+            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true>), grid3, dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
         } else if (fuse == 0) {
-            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH>), grid3, dim3(1024), 0, s, SA);
+            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH>), grid3, dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
         } else {
             hipLaunchKernelGGL((k_stageV<T, 3, 1, false, 32, 32>), grid3, dim3(1024), 0, s, SA);
             hipLaunchKernelGGL((k_stageV<T, 3, 4, true, 32, 32>), grid3, dim3(1024), 0, s, SA);

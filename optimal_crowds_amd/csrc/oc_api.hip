@@ -52,7 +52,7 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
         };
         h->axes_linspace = is_linspace(X0_host, cfg->Nx, cfg->room_length) && is_linspace(Y0_host, cfg->Ny, cfg->room_height);
     }
-    h->red_blocks = std::max(1024, ((cfg->Nx + 63) / 64) * ((cfg->Ny + 15) / 16));
+    h->red_blocks = std::max(1024, ((cfg->Nx + 31) / 32) * ((cfg->Ny + 15) / 16));
     OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * 2 * h->red_blocks));
     OC_HIP_CHECK(hipMalloc(&h->red_out, sizeof(double) * 16));
     OC_HIP_CHECK(hipHostMalloc(&h->red_host, sizeof(double) * (2 * OC_MAX_WORLD + 8), hipHostMallocMapped));
