@@ -346,8 +346,9 @@ int oc_set_hjb_variant(oc_handle* h, int variant);
  *                  previous step's search found -- a valid candidate, so the result is the same cell; 0 = always cold
  *   "hjb_tail"     ring solves (oc_hjb_solve_ring): 1 (default) = while few blocks take part in an attempt -- small grids, or
  *                  the active set's short lists -- the LAST block of the stage launch to finish is the attempt's step
- *                  controller and list builder (one launch per attempt instead of three); 0 = always separate launches.
- *                  Same decisions, same results either way.
+ *                  controller and list builder (one launch per attempt instead of three); 0 = always separate launches;
+ *                  2 = the fused launch at any number of blocks (two-level tickets; measured slower when every tile is
+ *                  computed, kept for that comparison).  Same decisions, same results either way.
  *   "hjb_active"   exact active set of oc_hjb_solve: tiles of the grid on which phi is one constant power of two, K0 = 0
  *                  and coef = 0 -- the far field of a solve with m = 0, where optimals.py:144-164 evaluates to exactly 0
  *                  -- are not computed; every slice of the direction field is still written, and fields, step sequence

@@ -238,7 +238,7 @@ __global__ void k_cell_keys(const double* __restrict__ x, const double* __restri
                             int32_t* __restrict__ vals) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    uint32_t key = 0x3FFFFFFFu;                     // inactive agents sort to the end
+    uint32_t key = 1u << (2 * P.horder);            // inactive agents sort to the end (curve indices are < 4^horder)
     if (status[i]) {
         double fx = x[i] / P.cell, fy = y[i] / P.cell;
         int cx = (fx > 0) ? (fx < P.ncx - 1 ? (int)fx : P.ncx - 1) : 0;
@@ -2177,7 +2177,8 @@ int repack(oc_handle* h, const oc_agents* a, Scratch* S, const GcfmParams& P, hi
     if (N > 0) {
         hipLaunchKernelGGL(k_cell_keys, dim3((N + 255) / 256), dim3(256), 0, s, a->x, a->y, a->status, N, P, S->keys_a,
                            S->vals_a);
-        int rc = oc_sort_pairs(h, S->keys_a, S->keys_b, S->vals_a, S->vals_b, N, 30, s);
+        // (only the bits a key can have are sorted: 15 - 17 instead of 30 at the BASELINE rooms -- half the radix passes)
+        int rc = oc_sort_pairs(h, S->keys_a, S->keys_b, S->vals_a, S->vals_b, N, std::min(30, 2 * P.horder + 1), s);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_pack, dim3(S->ntiles), dim3(64), 0, s, a->x, a->y, a->vx, a->vy, a->v_des, a->status, a->key,

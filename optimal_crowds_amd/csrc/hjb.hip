@@ -968,6 +968,11 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
                                                 int32_t* wsum_ext = nullptr);
 __device__ __forceinline__ ListPre list_prepare(int tnbx, int tnby, const uint8_t* sflag, int32_t* wsum);
 
+// fused tail: tickets on one counter up to TAIL_FLAT_MAX participating blocks, in two levels beyond (k_stageV: fused_tail)
+#define TAIL_FLAT_MAX 640
+#define TAIL_GROUPS 64
+#define TAIL_COUNTER_BYTES (128 * (1 + TAIL_GROUPS))
+
 // ---- lean multi-stage kernel: four cells of a row per thread, no per-cell index arithmetic ------------------------
 // (Round 1's multi-stage kernels dealt the region's cells to the threads round-robin; that cost ~100 instructions of
 // index and predicate arithmetic per cell and stage -- 450 SIMD cycles per wavefront-cell-stage, the launch time scaled
@@ -1035,11 +1040,29 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tail.c);
         for (int i = threadIdx.x; i < NW32; i += 256) dst[i] = src[i];
     }
+    const int part_pos = logical;                       // this block's number among the participants (0 .. n_part - 1)
     auto fused_tail = [&]() {                           // called by every thread of a participating block, at its end
         if (threadIdx.x == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this block's sc1 words have left
-            const int ticket = __hip_atomic_fetch_add(A.tail_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (ticket == n_part - 1) ? 1 : 0;
+            // One counter takes ~90 tickets per us: fine for the active set's short lists, not for a launch of thousands of
+            // blocks.  Those draw in two levels: TAIL_GROUPS group counters (each in its own 128-byte line), and the block that
+            // completes a group draws on the launch's counter.  (Every block's stores precede its ticket, a group's tickets
+            // precede its draw on the top counter: whoever completes that one has everybody's words behind it.)
+            int last = 0;
+            if (n_part <= TAIL_FLAT_MAX) {
+                const int ticket = __hip_atomic_fetch_add(A.tail_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = (ticket == n_part - 1) ? 1 : 0;
+            } else {
+                const int g = part_pos % TAIL_GROUPS, gsize = (n_part - g + TAIL_GROUPS - 1) / TAIL_GROUPS;
+                int32_t* const gc = A.tail_counter + 32 * (1 + g);
+                const int t1 = __hip_atomic_fetch_add(gc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t1 == gsize - 1) {
+                    __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int t2 = __hip_atomic_fetch_add(A.tail_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = (t2 == TAIL_GROUPS - 1) ? 1 : 0;
+                }
+            }
+            s_last = last;
         }
         __syncthreads();
         if (!s_last) return;
@@ -1050,7 +1073,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         // the controller: its error partials and the flags are in flight together)
         uint8_t* const sflag = reinterpret_cast<uint8_t*>(&buf[0][0][0]);
         static_assert(NT >= 512, "the tail's helper wavefronts");
-        const bool pre_ok = A.active_set != 0 && nb <= (int)sizeof(buf);
+        const bool pre_ok = sparse && A.active_set != 0 && nb <= (int)sizeof(buf);     // (dense mode: no flags, no list)
         if (pre_ok && threadIdx.x >= 256 && threadIdx.x < 512) {
             for (int t0 = (int)threadIdx.x - 256; t0 < nb; t0 += 8 * 256) {
                 int32_t f[8];
@@ -2159,8 +2182,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     if (!h->hjb_tsteps) OC_HIP_CHECK(hipMalloc((void**)&h->hjb_tsteps, sizeof(double) * T_CAP));
     if (!h->hjb_log) OC_HIP_CHECK(hipMalloc((void**)&h->hjb_log, sizeof(int32_t) * LOG_CAP));
     if (!h->hjb_tail) {
-        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_tail, 64));
-        OC_HIP_CHECK(hipMemset(h->hjb_tail, 0, 64));
+        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_tail, TAIL_COUNTER_BYTES));
+        OC_HIP_CHECK(hipMemset(h->hjb_tail, 0, TAIL_COUNTER_BYTES));
     }
     static_assert(sizeof(HjbCtl<T>) <= 2048, "controller block too large");
     // two controller blocks: attempt a reads ctlb[a & 1], its controller leaves the next attempt's in ctlb[(a + 1) & 1]
@@ -2255,7 +2278,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     if (!h->hjb_ctl_host) OC_HIP_CHECK(hipHostMalloc(&h->hjb_ctl_host, 4096, hipHostMallocDefault));
     memcpy(h->hjb_ctl_host, &hc, sizeof(hc));
     OC_HIP_CHECK(hipMemcpyAsync(ctl, h->hjb_ctl_host, sizeof(hc), hipMemcpyHostToDevice, s));
-    OC_HIP_CHECK(hipMemsetAsync(h->hjb_tail, 0, 64, s));           // (a solve that failed half-way may have left tickets)
+    OC_HIP_CHECK(hipMemsetAsync(h->hjb_tail, 0, TAIL_COUNTER_BYTES, s));   // (a solve that failed half-way may have left tickets)
     if (dev_init)
         hipLaunchKernelGGL(k_init_step<T>, dim3(1), dim3(64), 0, s, ctl, h->red_out, 1, n_rms, std::fabs(tf - t0));
     volatile double* mb = h->red_host + 2 * OC_MAX_WORLD + 4;      // [0] ticks + 2^32 * done (k_control), [1] listed tiles
@@ -2360,7 +2383,11 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // attempt instead of three.  Every participating block takes a ticket on ONE counter (~90 atomics per us on this chip),
     // so it pays while few blocks take part: small grids, or the active set's short lists.  The host picks the sequence per
     // attempt from what the device last posted (mb[1]: listed tiles); any choice is correct, only the speed differs.
-    const int FUSED_MAX = 640;
+    // hjb_tail = 1 (default): the fused launch while few blocks take part (the flat ticket's range), stage launch + k_control
+    // otherwise; 2: every attempt fused, two-level tickets beyond that range -- measured at 4096 x 4096 with every tile
+    // computed: 193 us per launch against 163 + k_control's 10 (each block's end waits for its ticket with 15 wavefronts at
+    // the barrier: block slots, not atomics, are what it costs); kept for that comparison.
+    const double FUSED_MAX = h->hjb_tail_fuse == 2 ? 1e18 : (double)TAIL_FLAT_MAX;
     const bool can_fuse = ring != nullptr && !sh && h->hjb_tail_fuse != 0;
     SA.tail_counter = h->hjb_tail;
     SA.t_steps = h->hjb_tsteps;
@@ -2417,7 +2444,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         }
         // blocks that will take part, as far as the host knows (the device is a few attempts ahead of what it posted)
         const double seen = active_set ? (enq > 0 ? (double)mb[1] : (double)nb3) : (double)nb3;
-        const bool fused = can_fuse && seen <= (double)FUSED_MAX;
+        const bool fused = can_fuse && seen <= FUSED_MAX;
         if (ring && fused) {
             hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true, true>), grid3, dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
         } else if (ring) {

@@ -304,7 +304,7 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
         h->wall_warm = value;
         h->wprev_valid = false;
     } else if (!strcmp(name, "hjb_tail")) {
-        OC_REQUIRE(value >= 0 && value <= 1, "hjb_tail out of range");
+        OC_REQUIRE(value >= 0 && value <= 2, "hjb_tail out of range");
         h->hjb_tail_fuse = value;
     } else if (!strcmp(name, "hjb_fuse")) {
         OC_REQUIRE(value >= 0 && value <= 1, "hjb_fuse out of range");
