@@ -1553,10 +1553,9 @@ struct SeqCand {
 // SEQ (sequential mode, k_seq_go below): only the agents marked for this round (seq_state == 1) are advanced; the
 // others keep their records; every agent advanced is then taken off the dependency counts of the LATER agents within reach.  `seq_round` selects the slot of the pending counter, `seq_margin` is the displacement
 // bound the round's independence rests on (a larger move raises seq_ctl[4]).
-// WPB: tiles (wavefronts) per block.  One-wavefront blocks are bound by the rate at which workgroups can be dispatched:
-// at 500 000 agents the launch held ~330 of the chip's 8 192 wavefront slots on average (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES,
-// profiles/r03_open_room_pmc_step.json) -- 64 us for a kernel whose wavefronts live 2 us each.  The synchronous step packs
-// four tiles into a block.
+// WPB: tiles (wavefronts) per block.  The synchronous step packs four tiles into a block: a quarter of the workgroups to
+// dispatch.  By the kernel trace the launch gains little (C4 9.6 -> 9.1 us, C5 17.5 -> 17.6 us: profiles/r03_*_kernel_stats.csv);
+// the bench's HIP-event samples of single launches at C5, taken while a solve runs on another stream, fell from 64 to 20 us.
 template <bool SEQ, int WPB = 1>
 __global__ void __launch_bounds__(64 * WPB) k_finish(GcfmParams P, Scratch S, const double* __restrict__ rect_tab, int nkeys,
                                                StepArgs A, int seq_round, double seq_margin,
