@@ -373,7 +373,10 @@ struct NoHook {
 };
 // `beside`: called by EVERY thread between the controller's serial section (thread 0) and the barrier behind it -- the
 // other wavefronts run it while thread 0 decides (the fused tail's list builder does its decision-independent part there)
-template <typename T, bool SC1, typename HOOK = NoHook>
+// UNR: error shares in flight per worker thread and trip (the sums are formed in the same order whatever it is).  The
+// stand-alone launch behind a sweep of every tile reads thousands of shares: 16 per trip there (4096 x 4096: 30 per thread,
+// two round trips to the L2 instead of eight); the fused tail has the stage kernel's 64 registers and keeps 4.
+template <typename T, bool SC1, typename HOOK = NoHook, int UNR = 4>
 __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_in, HjbCtl<T>* __restrict__ ctl_out,
                                              const double* parts, int nparts, double* __restrict__ t_steps, int t_cap,
                                              int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox,
@@ -396,16 +399,16 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
     // the attempt's error sums (issued together with the block's load; unused if the solve is over)
     double s = 0.0, m = 0.0, na = 0.0;
     if (worker) {
-        for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * nth) {
-            double2 v[4];
+        for (int i0 = threadIdx.x; i0 < nparts; i0 += UNR * nth) {
+            double2 v[UNR];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const int i = i0 + u * nth;
                 v[u] = (i < nparts) ? make_double2(ld_part<SC1>(parts + 2 * i), ld_part<SC1>(parts + 2 * i + 1))
                                     : make_double2(0.0, 0.0);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 s += v[u].x;
                 m = fmax(m, v[u].y);
                 na += v[u].x > 0.0 ? 1.0 : 0.0;
@@ -575,8 +578,8 @@ __global__ void __launch_bounds__(256) k_control(const HjbCtl<T>* __restrict__ c
                                                  int active_set = 0, OcRingSlot<T>* __restrict__ rslots = nullptr,
                                                  OcRingSlice<T>* __restrict__ rslices = nullptr, int ring_cap = 0) {
     __shared__ CtlLds<T> L;
-    control_body<T, false>(ctl_in, ctl_out, parts, nparts, t_steps, t_cap, att_log, log_cap, mailbox, active_set, rslots, rslices,
-                           ring_cap, L);
+    control_body<T, false, NoHook, 16>(ctl_in, ctl_out, parts, nparts, t_steps, t_cap, att_log, log_cap, mailbox, active_set, rslots,
+                                       rslices, ring_cap, L);
 }
 
 // SciPy's select_initial_step (common.py:68-134, order 4) without the host: the three RMS norms are reduced on the device
@@ -968,6 +971,21 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
                                                 int32_t* wsum_ext = nullptr);
 __device__ __forceinline__ ListPre list_prepare(int tnbx, int tnby, const uint8_t* sflag, int32_t* wsum);
 
+// KEEP_SGPR: ONE empty asm statement whose operands must sit in scalar registers -- the loads that produce them are all
+// issued, and waited for once, before it (k_stageV's prologue)
+__device__ __forceinline__ int32_t sgpr_bits(int32_t v) { return v; }
+__device__ __forceinline__ int32_t sgpr_bits(float v) { return __builtin_bit_cast(int32_t, v); }
+__device__ __forceinline__ int64_t sgpr_bits(double v) { return __builtin_bit_cast(int64_t, v); }
+template <typename P>
+__device__ __forceinline__ int64_t sgpr_bits(P* v) { return (int64_t)reinterpret_cast<uintptr_t>(v); }
+#define SB(x) "s"(sgpr_bits(x))
+// a wave-uniform word of memory that THIS launch does not write (the scalar cache is invalidated between launches): a
+// scalar load -- through a plain pointer the compiler takes a vector load and a readfirstlane, with a wait in between
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
+}
+
 // fused tail: tickets on one counter up to TAIL_FLAT_MAX participating blocks, in two levels beyond (k_stageV: fused_tail)
 #define TAIL_FLAT_MAX 640
 #define TAIL_GROUPS 64
@@ -1000,8 +1018,14 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     static_assert(NQ == 3 || (NQ == 6 && S0 == 1 && FINAL), "three stages per launch, or the whole attempt");
     __shared__ alignas(16) T buf[2][RH + 2][LS];    // slot of region cell (r, c): [r + 1][c + 4]; one spare ring
     const HjbCtl<T>* __restrict__ ctl = A.ctl;
-    if (ctl->done) return;                          // an attempt enqueued past the end of the solve
-    const int par = ctl->parity;
+    // Everything the launch reads of the controller block (264 contiguous bytes, fresh in every attempt: the first wavefront
+    // of a CU misses the scalar cache on each of its lines) is loaded in ONE batch up front, together with this block's entry
+    // of the work list: left to itself the compiler issues these loads where the values are first used, behind the early
+    // exits -- a chain of five dependent round trips to the L2 (3 - 5 us) before a block of a sparse attempt, alone on its CU,
+    // issues its first vector load.  (keep_sgpr: an empty asm statement that needs the values in scalar registers.)
+    const int c_done = ctl->done, par = ctl->parity, c_dense = ctl->dense_mode, c_wcount = ctl->work_count,
+              c_nacc = ctl->n_accept, c_rej = ctl->rejected;
+    const T c_oiscale = ctl->out_in_scale, c_ubg = ctl->u_bg;
     T cc[NQ][6], he[7];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
@@ -1013,17 +1037,25 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
 #pragma unroll
     for (int j = 0; j < 7; ++j) he[j] = FINAL ? ctl->he[j] : (T)0;
     const T atol_s = ctl->atol_s, in_scale = ctl->in_scale;
-    const T* __restrict__ y = A.Y[par];
-    const T* kin[4] = {A.KX[par], A.KM[0], A.KM[1], A.KM[2]};
-    T* ynew = A.Y[par ^ 1];
     const int Ny = A.Ny, Nx = A.Nx;
     const int nbx = (Nx + TX - 1) / TX, nby = (Ny + TY - 1) / TY, nb = nbx * nby;
     const int per = (nb + 7) / 8;
     int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);              // XCD-aware order (tile_of_block)
+    const bool listed = NQ == 6 && A.flags_cur != nullptr && A.work != nullptr;
+    const int w_entry = listed ? A.work[min(logical, nb - 1)] : 0;      // (read before it is known to be needed: in bounds)
+    asm volatile("" ::SB(c_done), SB(par), SB(c_dense), SB(c_wcount), SB(c_nacc), SB(c_rej), SB(w_entry), SB(c_oiscale), SB(c_ubg),
+                 SB(atol_s), SB(in_scale), SB(cc[0][0]), SB(cc[NQ / 2 - 1][5]), SB(cc[NQ / 2][0]), SB(cc[NQ - 1][5]), SB(he[0]),
+                 SB(he[6]), SB(A.coef), SB(A.flags_prev));
+    if (c_done) return;                             // an attempt enqueued past the end of the solve
+    const T* __restrict__ y = A.Y[par];
+    const T* kin[4] = {A.KX[par], A.KM[0], A.KM[1], A.KM[2]};
+    asm volatile("" ::SB(y), SB(kin[0]));           // (the two pointers picked by the parity: in registers before the loads
+                                                    // below are issued, or a late scalar load would wait for all of those)
+    T* ynew = A.Y[par ^ 1];
     if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
-    const bool sparse = NQ == 6 && A.flags_cur != nullptr && ctl->dense_mode == 0;
+    const bool sparse = NQ == 6 && A.flags_cur != nullptr && c_dense == 0;
     // blocks that take part in the attempt (the others have returned above or do so just below): what the tail waits for
-    const int n_part = (sparse && A.work != nullptr) ? min(ctl->work_count, nb) : nb;
+    const int n_part = (sparse && A.work != nullptr) ? min(c_wcount, nb) : nb;
     auto st_part = [&](double* p, double v) {           // a word for the controller (thread 0 only)
         if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *p = v;
@@ -1032,14 +1064,25 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *p = v;
     };
-    // FUSED: every participating block copies the controller block into LDS as it starts (1 KB out of the L2, nobody waits
-    // for it): the block that turns out to be the last one has it at hand instead of behind another round trip
+    // FUSED: every participating block copies the controller block into LDS as it starts (1 KB out of the L2): the block that
+    // turns out to be the last one has it at hand instead of behind another round trip.  The words are LOADED here and stored
+    // below, behind the tile's own loads (store_ctl_words) -- stored on the spot, the first four wavefronts of every block sat
+    // out a round trip to the L2 before they issued anything else.
+    constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4), CW = (NW32 + 255) / 256;
+    uint32_t cw[CW];
     if (FUSED && threadIdx.x < 256) {
-        constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tail.c);
-        for (int i = threadIdx.x; i < NW32; i += 256) dst[i] = src[i];
+#pragma unroll
+        for (int q = 0; q < CW; ++q) cw[q] = ((int)threadIdx.x + 256 * q < NW32) ? src[threadIdx.x + 256 * q] : 0u;
     }
+    auto store_ctl_words = [&]() {
+        if (FUSED && threadIdx.x < 256) {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tail.c);
+#pragma unroll
+            for (int q = 0; q < CW; ++q)
+                if ((int)threadIdx.x + 256 * q < NW32) dst[threadIdx.x + 256 * q] = cw[q];
+        }
+    };
     const int part_pos = logical;                       // this block's number among the participants (0 .. n_part - 1)
     auto fused_tail = [&]() {                           // called by every thread of a participating block, at its end
         if (threadIdx.x == 0) {
@@ -1120,8 +1163,8 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         }
     };
     if (sparse && A.work != nullptr) {              // active set: entry `logical` of the work list, or nothing to do
-        if (logical >= ctl->work_count) return;
-        logical = A.work[logical];
+        if (logical >= c_wcount) return;
+        logical = w_entry;
     }
     const int vx = (int)threadIdx.x % RWV, ry = (int)threadIdx.x / RWV;
     const int gi = (logical / nbx) * TY - HY + ry, gj = (logical % nbx) * TX - HX + 4 * vx;
@@ -1131,7 +1174,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     // wave-uniform array pointer the access is `base in scalar registers + 32-bit vector offset` -- one shift for all of the
     // launch's ten arrays, where a 64-bit index cost two 64-bit vector operations per array (the launch is issue-bound)
     const uint32_t ui = in ? (uint32_t)idx * (uint32_t)sizeof(T) : 0u;     // (BYTE offset)
-    const int rslot = RING ? ctl->n_accept : 0;                     // the ring slot of the step this attempt tries
+    const int rslot = RING ? c_nacc : 0;                     // the ring slot of the step this attempt tries
     const bool ring_ok = RING && rslot < A.ring_cap;                // (beyond the capacity k_control ends the solve)
     // The thread's four cells as two PAIRS: float pairs are packed-math operands (v_pk_fma_f32 / v_pk_add_f32 /
     // v_pk_mul_f32: one instruction for two cells -- the launch is bound by VALU issue, 71 % busy before this), double
@@ -1160,16 +1203,36 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     T u_raw = (T)0;
     const bool track = sparse;
     const int bi = logical / nbx, bj = logical % nbx;
-    if (track) {
-        u_raw = y[(int64_t)(bi * TY) * Nx + bj * TX];       // (uniform address: the tile's first cell)
-        own_prev = A.flags_prev != nullptr && A.flags_prev[logical] != 0;
+    // Every load of the prologue is issued before anything waits for one of them: y, coef and K0, then -- as scalar loads,
+    // which wait on their own counter -- the tile's far-field probe and its previous flag (as first written the compiler had
+    // put K0 behind the triviality test of y and coef and the flag behind the probe: three dependent round trips where one
+    // does).
+    V4<T> y4, c4, k4in[S0];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        y4.v[q] = c4.v[q] = (T)0;
+#pragma unroll
+        for (int j = 0; j < S0; ++j) k4in[j].v[q] = (T)0;
     }
+    if (in) {
+        y4 = ld4b(y, ui);
+        c4 = ld4b(A.coef, ui);
+#pragma unroll
+        for (int j = 0; j < S0; ++j) k4in[j] = ld4b(kin[j], ui);
+    }
+    int32_t flag_prev = 0;
+    if (track) {
+        u_raw = uniform_load(y + ((int64_t)(bi * TY) * Nx + bj * TX));     // (the tile's first cell; y is read-only here)
+        // (unconditional: behind a branch the flag's load waited for the probe's)
+        flag_prev = uniform_load((A.flags_prev != nullptr ? A.flags_prev : A.flags_cur) + logical);
+    }
+    store_ctl_words();
+    own_prev = A.flags_prev != nullptr && flag_prev != 0;
     // a tile that was computed in the previous attempt is computed again without the test (the front only advances; were
     // it ever trivial again, computing it is still right): the test's barrier is paid by the ring around the active region
     const bool need_test = track && (A.flags_prev == nullptr || own_prev);
     bool cell_trivial = true;
     if (in) {
-        const V4<T> y4 = ld4b(y, ui), c4 = ld4b(A.coef, ui);
         if (need_test) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -1184,7 +1247,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         }
 #pragma unroll
         for (int j = 0; j < S0; ++j) {
-            const V4<T> k4 = ld4b(kin[j], ui);
+            const V4<T> k4 = k4in[j];
             kv[j][0] = (T2){k4.v[0], k4.v[1]};
             kv[j][1] = (T2){k4.v[2], k4.v[3]};
             if (need_test && j == 0) {
@@ -1204,10 +1267,10 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         // (u_raw == the controller's far-field value: every trivial tile then provably holds ONE and the same power of two --
         // what k_control's ymax for the tiles off the list and the ring's per-slot `u` assume; a tile that is constant at
         // any other value is simply computed)
-        if (need_test) trivial = __syncthreads_and((cell_trivial && is_pow2(u_raw) && u_raw == ctl->u_bg) ? 1 : 0) != 0;
+        if (need_test) trivial = __syncthreads_and((cell_trivial && is_pow2(u_raw) && u_raw == c_ubg) ? 1 : 0) != 0;
         if (trivial) {
             const T un = u_raw * in_scale;
-            const bool can_skip = own_prev && (ctl->rejected != 0 || (in_scale == (T)1 && ctl->out_in_scale == (T)1));
+            const bool can_skip = own_prev && (c_rej != 0 || (in_scale == (T)1 && c_oiscale == (T)1));
             if (!can_skip && in && ry >= HY && ry < RH - HY && vx >= HX / 4 && vx < RWV - HX / 4) {
                 V4<T> z, uu;
 #pragma unroll
