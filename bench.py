@@ -275,7 +275,7 @@ def pmc_file(pattern, workload="metro_station"):
     return None
 
 
-def pmc_traffic(workload, kernel_class="hjb_out"):
+def pmc_traffic(workload, kernel_class="hjb_out", per_attempt=False):
     """HBM bytes per launch of a kernel class from the committed PMC summary (profiles/rNN_pmc_traffic*.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command, gfx950 FETCH_SIZE x2 correction applied by
     tools/collect_profiles.py).  Counters cannot be collected from inside the timed run, hence the file; null if the
@@ -285,6 +285,10 @@ def pmc_traffic(workload, kernel_class="hjb_out"):
         return None
     key = {"hjb_out": "k_out_hbm_bytes_per_launch", "hjb_stage": "k_stageV_hbm_bytes_per_launch",
            "gcfm_forces": "k_forces_hbm_bytes_per_launch", "density": "k_density_hbm_bytes_per_launch"}.get(kernel_class)
+    if per_attempt and kernel_class == "hjb_stage":
+        # active set: all HBM bytes of the solves' stage launches over the launches that did any work -- the same set of
+        # launches `achieved` averages over (the per-launch key is the mean of the few launches that look at every tile)
+        return d.get("k_stageV_hbm_bytes_per_attempt")
     return d.get(key)
 
 
@@ -469,7 +473,8 @@ def main():
             return None
         r = {"bound": "hbm", "kernel": kernel, "achieved": k_["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": k_["achieved_GBps"] / HBM_PEAK_GBS,
-             "traffic": pmc_traffic(args.workload, name), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, "
+             "traffic": pmc_traffic(args.workload, name, per_attempt=bool(active_set)),
+             "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, "
              "profiles/; null unless taken with these kernel sources)",
              "launches_timed": k_["launches_timed"], "avg_launch_ms": k_["avg_ms"],
              "algorithmic_GB_per_launch": k_["designed_GB_per_launch"],
@@ -482,7 +487,11 @@ def main():
         stage_note = ("exact active set: only the tiles where phi is not constant are loaded and computed (bytes = the designed "
                       "passes x the solve's mean share of such tiles); with a few dozen listed tiles the launch is one tile's "
                       "trip through its block -- latency, not bandwidth; the same launch with every tile computed is in "
-                      "`dense_sweep.k_stageV`")
+                      "`dense_sweep.k_stageV`.  `traffic` = all HBM bytes of the solves' stage launches / the launches that did "
+                      "any work: ~80 % of them belong to the ~7 launches per solve that look at EVERY tile (the first "
+                      "attempt, which has no list yet, and the attempts around a change of scale, which rewrite the far "
+                      "field) and to the listed tiles that are read only to be found trivial -- bytes the algorithmic figure "
+                      "(computed tiles x designed passes) does not count")
     roofs = {
         "hjb_out": lambda: hbm_roof("hjb_out", "k_out (HJB dense output + direction-field writer)",
                                     ("exact active set: the far field's slices are written as zeros without reads -- (almost) "

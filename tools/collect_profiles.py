@@ -79,7 +79,8 @@ for d, cname in ((tag + sfx + "_pmc_fetch", "FETCH_SIZE"), (tag + sfx + "_pmc_wr
             return big or v
         return v
     traffic[cname] = {k: {"launches": len(real(k, v)), "avg_KB_per_launch": sum(real(k, v)) / len(real(k, v)),
-                          "launches_incl_early_exits": len(v)}
+                          "launches_incl_early_exits": len(v), "sum_KB": sum(v),
+                          "working_launches": sum(1 for x in v if x > 64.0)}
                       for k, v in sorted(agg.items()) if k.startswith("k_")}
 if traffic:
     # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a
@@ -89,8 +90,19 @@ if traffic:
         kw_ = traffic.get("WRITE_SIZE", {}).get(kname)
         if kf_ and kw_:
             traffic[key + "_hbm_bytes_per_launch"] = 2 * kf_["avg_KB_per_launch"] * 1024 + kw_["avg_KB_per_launch"] * 1024
+    # k_stageV with the active set: a few launches of a solve look at every tile (the first attempt, and two attempts around
+    # every change of scale) and carry most of the bytes; the roofline of the sparse launches is quoted per ATTEMPT -- all
+    # bytes of all launches over the launches that did any work (an attempt enqueued past a solve's end moves < 64 KB)
+    kf_ = traffic.get("FETCH_SIZE", {}).get("k_stageV(all six)")
+    kw_ = traffic.get("WRITE_SIZE", {}).get("k_stageV(all six)")
+    if kf_ and kw_ and "sum_KB" in kf_ and "sum_KB" in kw_:
+        n_att = max(kf_["working_launches"], 1)
+        traffic["k_stageV_hbm_bytes_per_attempt"] = (2 * kf_["sum_KB"] + kw_["sum_KB"]) * 1024 / n_att
+        traffic["k_stageV_attempts"] = n_att
+        traffic["k_stageV_every_tile_launches"] = kf_["launches"]
     traffic["note"] = ("<kernel>_hbm_bytes_per_launch = 2 x FETCH_SIZE (gfx950 correction for 16 B/lane reads) + WRITE_SIZE, "
-                       "KB -> bytes, average over the launches of a --steps 20 run (separate --pmc passes); k_forces reads "
+                       "KB -> bytes, average over the launches of a --steps 20 run (separate --pmc passes; k_stageV: over the launches that "
+                       "look at every tile, k_stageV_hbm_bytes_per_attempt: all bytes over all working launches); k_forces reads "
                        "mostly 4-16 B per lane through scattered gathers, so for it the doubled figure is an upper bound")
     traffic["csrc_sha"] = bench.csrc_hash()         # bench.py quotes the file only for the kernels it was taken with
     traffic["workload"] = workload
