@@ -473,7 +473,8 @@ def main():
             return None
         r = {"bound": "hbm", "kernel": kernel, "achieved": k_["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": k_["achieved_GBps"] / HBM_PEAK_GBS,
-             "traffic": pmc_traffic(args.workload, name, per_attempt=bool(active_set)),
+             # (the PMC passes are taken with the default float32 state: no figure for another HJB dtype)
+             "traffic": pmc_traffic(args.workload, name, per_attempt=bool(active_set)) if sim.hjb_dtype == "float32" else None,
              "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, "
              "profiles/; null unless taken with these kernel sources)",
              "launches_timed": k_["launches_timed"], "avg_launch_ms": k_["avg_ms"],
