@@ -264,3 +264,38 @@ def test_concurrent_key_solves_equal_one_after_the_other(dtype, with_m):
         assert np.abs(fa[k][0]).max() > 0.5
     for (da, ea), (db, eb) in zip(la, lb):
         assert np.array_equal(da, db) and ea == eb
+
+
+@pytest.mark.parametrize("active", [0, 2])
+def test_tail_variants_make_the_same_decisions(active):
+    """oc_set_tuning "hjb_tail": 0 = stage launch + k_control (+ k_list), 1 = the attempt's last block is its controller
+    while at most 640 blocks take part, 2 = always (two-level tickets beyond 640).  slalom at 1024 x 1024 has 520 stage
+    tiles -- under the flat ticket's range -- so the two-level path is taken on metro_station's 2048 x 2048
+    grid (BASELINE configs[3]: 1 957 tiles) with every tile computed (active = 0) and, with the active set, in its first, list-less attempt."""
+    import torch
+    setup = _setup("metro_station", 0.1)
+    cfg, room, Nx, Ny, X0, Y0, V = setup
+    assert Nx % 4 == 0 and -(-Nx // 112) * -(-Ny // 20) > 640
+    T, nt = 3.0, 150
+    res = {}
+    for tail in (0, 1, 2):
+        eng = _engine(setup, "float32", "ring")
+        eng.set_tuning("hjb_active", active)
+        eng.set_tuning("hjb_tail", tail)
+        eng.alloc_field(0, nt - 1)
+        st, phi = eng.solve(0, T, nt, keep=[0, nt - 1], want_steps=True)
+        _probe_agents(eng, room, 2000, 11)
+        look = _lookups(eng, [0, 1, nt // 2, nt - 2])
+        res[tail] = (st, phi.cpu(), look)
+        eng.close()
+        del eng
+    st0, phi0, look0 = res[0]
+    assert st0["n_accept"] > 10
+    for tail in (1, 2):
+        st, phi, look = res[tail]
+        for k in ("nfev", "n_attempt", "n_accept", "n_rescale", "final_exponent"):
+            assert st[k] == st0[k], (tail, k, st[k], st0[k])
+        assert np.array_equal(st["t_steps"], st0["t_steps"])
+        assert torch.equal(phi, phi0)
+        for (d0, e0), (d1, e1) in zip(look0, look):
+            assert e0 == e1 and np.array_equal(d0, d1)
