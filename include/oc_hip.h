@@ -349,6 +349,10 @@ int oc_set_hjb_variant(oc_handle* h, int variant);
  *                  controller and list builder (one launch per attempt instead of three); 0 = always separate launches;
  *                  2 = the fused launch at any number of blocks (two-level tickets; measured slower when every tile is
  *                  computed, kept for that comparison).  Same decisions, same results either way.
+ *   "hjb_subst"    ring solves with the exact active set: 1 (default) = the state buffers do not maintain the cells of trivial
+ *                  tiles -- a load of such a cell yields the far-field value the tile stands for -- so a change of scale
+ *                  does not put every tile on the work list to rewrite the far field; 0 = every buffer holds every tile.
+ *                  Same decisions, same results either way.
  *   "hjb_active"   exact active set of oc_hjb_solve: tiles of the grid on which phi is one constant power of two, K0 = 0
  *                  and coef = 0 -- the far field of a solve with m = 0, where optimals.py:144-164 evaluates to exactly 0
  *                  -- are not computed; every slice of the direction field is still written, and fields, step sequence

@@ -557,7 +557,10 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
     }
     // ---- active set: the next attempt's work list is built by block 0 of the k_out launch that follows (beside the output
     // blocks, off the critical path): here only the order for it
-    if (threadIdx.x == 0) c.list_todo = (active_set != 0 && !c.done) ? ((all_active || c.dense_mode) ? 2 : 1) : 0;
+    // (every tile active for the rest of the solve -- decided on an ACCEPTED attempt only: with the far-field substitution the
+    // buffer a rejected attempt leaves as y may still hold tiles that were never written)
+    if (threadIdx.x == 0)
+        c.list_todo = (active_set != 0 && !c.done) ? (((all_active && c.accepted) || c.dense_mode) ? 2 : 1) : 0;
     __syncthreads();
     if (worker && store_out) {          // (the fused tail lets the list builder work on the LDS copy first)
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
@@ -924,6 +927,10 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     OcRingSlice<T>* rslices;
     int32_t* flags_next;            // the next attempt's flags / work list (the builder's outputs)
     int32_t* work_next;
+    // ring solves with the active set: undef[b * ntile + t] = 1 -- tile t's cells in state buffer b (Y[b], KX[b]) are NOT
+    // maintained: the tile was trivial when b was last written, its y is the controller's far-field value and its K0 is 0,
+    // and whoever loads such cells substitutes exactly that (k_stageV).  NULL: every buffer holds every tile (the other paths).
+    int32_t* undef;
 };
 
 // value of the previous / next lane of the wavefront (DPP wave shifts: no LDS traffic; lane 0 / 63 get 0)
@@ -968,7 +975,7 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
                                                 int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
                                                 double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* sflag, int nbytes,
                                                 volatile double* mailbox, bool flags_ready, const ListPre* pre = nullptr,
-                                                int32_t* wsum_ext = nullptr);
+                                                int32_t* wsum_ext = nullptr, int32_t* undef = nullptr);
 __device__ __forceinline__ ListPre list_prepare(int tnbx, int tnby, const uint8_t* sflag, int32_t* wsum);
 
 // KEEP_SGPR: ONE empty asm statement whose operands must sit in scalar registers -- the loads that produce them are all
@@ -1143,7 +1150,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         static_assert(sizeof(buf) >= 12000, "the builder's flag bytes fit the tile buffers");
         if (A.active_set)
             build_work_list<T, true>(&s_tail.c, A.flags_cur, A.flags_next, A.work_next, A.partial, nbx, nby, sflag,
-                                     (int)sizeof(buf), nullptr, pre_ok, &lpre, s_wsum);
+                                     (int)sizeof(buf), nullptr, pre_ok, &lpre, s_wsum, A.undef);
         __syncthreads();
         if (threadIdx.x < 256) {
             constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
@@ -1220,14 +1227,33 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
 #pragma unroll
         for (int j = 0; j < S0; ++j) k4in[j] = ld4b(kin[j], ui);
     }
-    int32_t flag_prev = 0;
+    // Far-field substitution (ring solves): a trivial tile's cells are not kept up to date in the state buffers -- not when
+    // it is found trivial, not across a change of scale (which used to put EVERY tile on the list twice, to rewrite the far
+    // field of both buffers: 7 of a C4 solve's 103 launches carried 80 % of its HBM bytes).  Cells of a tile marked
+    // undefined in the buffer being read are replaced by what they stand for: y = the controller's far-field value (raw, as
+    // the buffer would hold it), K0 = 0.  A vector's four cells lie in one tile (TX = 4 * 28).
+    const bool subst = RING && track && A.undef != nullptr;
+    int32_t flag_prev = 0, my_undef = 0, own_undef = 0;
+    if (subst && in) my_undef = A.undef[(size_t)par * nb + (gi / TY) * nbx + gj / TX];
     if (track) {
         u_raw = uniform_load(y + ((int64_t)(bi * TY) * Nx + bj * TX));     // (the tile's first cell; y is read-only here)
         // (unconditional: behind a branch the flag's load waited for the probe's)
         flag_prev = uniform_load((A.flags_prev != nullptr ? A.flags_prev : A.flags_cur) + logical);
+        if (subst) own_undef = uniform_load(A.undef + ((size_t)par * nb + logical));
     }
     store_ctl_words();
     own_prev = A.flags_prev != nullptr && flag_prev != 0;
+    if (subst) {
+        if (own_undef) u_raw = c_ubg;
+        if (my_undef) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                y4.v[q] = c_ubg;
+#pragma unroll
+                for (int j = 0; j < S0; ++j) k4in[j].v[q] = (T)0;
+            }
+        }
+    }
     // a tile that was computed in the previous attempt is computed again without the test (the front only advances; were
     // it ever trivial again, computing it is still right): the test's barrier is paid by the ring around the active region
     const bool need_test = track && (A.flags_prev == nullptr || own_prev);
@@ -1270,7 +1296,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         if (need_test) trivial = __syncthreads_and((cell_trivial && is_pow2(u_raw) && u_raw == c_ubg) ? 1 : 0) != 0;
         if (trivial) {
             const T un = u_raw * in_scale;
-            const bool can_skip = own_prev && (c_rej != 0 || (in_scale == (T)1 && c_oiscale == (T)1));
+            const bool can_skip = subst || (own_prev && (c_rej != 0 || (in_scale == (T)1 && c_oiscale == (T)1)));
             if (!can_skip && in && ry >= HY && ry < RH - HY && vx >= HX / 4 && vx < RWV - HX / 4) {
                 V4<T> z, uu;
 #pragma unroll
@@ -1291,12 +1317,14 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                 st_part(A.partial + 2 * logical, 0.0);
                 st_part(A.partial + 2 * logical + 1, (r_hi > A.row_lo && r_lo < A.row_hi) ? (double)fabs(un) : 0.0);
                 st_flag(A.flags_cur + logical, 1);
+                if (subst) A.undef[(size_t)(par ^ 1) * nb + logical] = 1;      // (read by later launches only)
             }
             if (FUSED) fused_tail();
             return;
         }
         if (threadIdx.x == 0) {
             st_flag(A.flags_cur + logical, 0);
+            if (subst) A.undef[(size_t)(par ^ 1) * nb + logical] = 0;          // (the tile's cells of y_new / K6 are written below)
             // (ring: the tile holds data from this slot on -- it was tested just now, so it was trivial until here; a tile
             // that skips the test has been computed before and is on record)
             if (RING && need_test && rslot < A.ring_first[logical]) A.ring_first[logical] = rslot;
@@ -1545,7 +1573,7 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
                                                 int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
                                                 double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* sflag, int nbytes,
                                                 volatile double* mailbox, bool flags_ready, const ListPre* pre,
-                                                int32_t* wsum_ext) {
+                                                int32_t* wsum_ext, int32_t* undef) {
     // Called by every thread of the block (barriers inside), and every thread works: the builder is a chain of dependent
     // integer and LDS instructions per tile, so its length is the tiles per THREAD (8 per thread with 256 threads at
     // 2048 x 2048 took 8 us of the fused tail; 2 per thread with the stage block's 1024).  SC1: flags_cur was written by
@@ -1564,7 +1592,10 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
         }
         return;
     }
-    const bool skip_ok = (ctl->rejected != 0 || (ctl->in_scale == (T)1 && ctl->out_in_scale == (T)1)) && ntile <= nbytes;
+    // undef (ring solves, far-field substitution: Stage3Args): nobody reads a trivial tile's cells, so a change of scale does
+    // not have to rewrite them -- tiles may stay off the list whatever the decision was
+    const bool skip_ok =
+        (undef != nullptr || ctl->rejected != 0 || (ctl->in_scale == (T)1 && ctl->out_in_scale == (T)1)) && ntile <= nbytes;
     // every thread owns a contiguous run of tiles (an ordered list keeps neighbouring tiles in neighbouring blocks)
     const int per_thr = (ntile + nth - 1) / nth;
     int t_lo = min((int)threadIdx.x * per_thr, ntile), t_hi = min(t_lo + per_thr, ntile);
@@ -1651,6 +1682,7 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
             flags_next[t] = 1;
             parts_rw[2 * t] = 0.0;
             parts_rw[2 * t + 1] = 0.0;
+            if (undef != nullptr) undef[t] = undef[ntile + t] = 1;     // (in either state buffer: it stands for the far field)
         }
     }
     if (threadIdx.x == 0) {
@@ -1715,8 +1747,9 @@ template <typename T>
 __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, const int32_t* __restrict__ flags_cur,
                                                 int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
                                                 double* __restrict__ parts_rw, int tnbx, int tnby, uint8_t* sflag, int nbytes,
-                                                volatile double* mailbox = nullptr) {
-    build_work_list<T, false>(ctl, flags_cur, flags_next, work, parts_rw, tnbx, tnby, sflag, nbytes, mailbox, false);
+                                                volatile double* mailbox = nullptr, int32_t* undef = nullptr) {
+    build_work_list<T, false>(ctl, flags_cur, flags_next, work, parts_rw, tnbx, tnby, sflag, nbytes, mailbox, false, nullptr,
+                              nullptr, undef);
 }
 
 // With the interpolant ring no k_out launch follows an attempt: the list builder is a launch of its own (one block).
@@ -1724,9 +1757,9 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_list(HjbCtl<T>* ctl, const int32_t* __restrict__ flags_cur,
                                               int32_t* __restrict__ flags_next, int32_t* __restrict__ work,
                                               double* __restrict__ parts_rw, int tnbx, int tnby,
-                                              volatile double* mailbox) {
+                                              volatile double* mailbox, int32_t* undef) {
     __shared__ uint8_t sflag[16384];
-    build_work_list<T>(ctl, flags_cur, flags_next, work, parts_rw, tnbx, tnby, sflag, (int)sizeof(sflag), mailbox);
+    build_work_list<T>(ctl, flags_cur, flags_next, work, parts_rw, tnbx, tnby, sflag, (int)sizeof(sflag), mailbox, undef);
 }
 
 // ---- slices from the ring (oc_hjb_ring_slices; the audit output phi_keep of a ring solve) ---------------------------
@@ -2432,13 +2465,16 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // longer cover the grid: every tile is computed.
     const bool active_set = !sh && fuse == 0 && nb3 <= 12000 &&
                             (h->hjb_active == 2 || (h->hjb_active == 1 && nb3 >= 1024));
-    if (active_set && h->hjb_flags_n < (size_t)4 * nb3) {     // flags of two attempts + two work lists (alternating)
-        if (h->hjb_flags) OC_HIP_CHECK(hipFree(h->hjb_flags));
+    if (active_set && h->hjb_flags_n < (size_t)6 * nb3) {     // flags of two attempts + two work lists (alternating) +
+        if (h->hjb_flags) OC_HIP_CHECK(hipFree(h->hjb_flags));     // the undefined-tile marks of the two state buffers
         h->hjb_flags = nullptr;
         h->hjb_flags_n = 0;
-        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_flags, sizeof(int32_t) * 4 * (size_t)nb3));
-        h->hjb_flags_n = (size_t)4 * nb3;
+        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_flags, sizeof(int32_t) * 6 * (size_t)nb3));
+        h->hjb_flags_n = (size_t)6 * nb3;
     }
+    // far-field substitution (Stage3Args::undef): ring solves; every tile of both buffers starts out defined
+    SA.undef = (active_set && ring && h->hjb_subst != 0) ? h->hjb_flags + (size_t)4 * nb3 : nullptr;
+    if (SA.undef) OC_HIP_CHECK(hipMemsetAsync(SA.undef, 0, sizeof(int32_t) * 2 * (size_t)nb3, s));
     // attempt a reads work list a & 1; the builder after it writes list (a + 1) & 1 (a late block of the attempt's own launch
     // must never see the next attempt's list: the fused tail builds it while that launch is still draining)
     auto work_list = [&](int a) -> int32_t* { return active_set ? h->hjb_flags + (2 + (size_t)(a & 1)) * nb3 : nullptr; };
@@ -2561,7 +2597,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             // posted dense_mode (every tile active for the rest of the solve: C5's re-solves under the crowd's density,
             // 2 200 launches of ~5 us per run that did nothing)
             hipLaunchKernelGGL(k_list<T>, dim3(1), dim3(256), 0, s, ctl_nxt, (const int32_t*)OA.flags, OA.flags_next, OA.work,
-                               OA.parts_rw, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty, (volatile double*)mb_dev);
+                               OA.parts_rw, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty, (volatile double*)mb_dev, SA.undef);
         }
         if (prof) event();
         ++enq;

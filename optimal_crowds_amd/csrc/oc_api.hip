@@ -303,6 +303,9 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
         OC_REQUIRE(value >= 0 && value <= 1, "wall_warm out of range");
         h->wall_warm = value;
         h->wprev_valid = false;
+    } else if (!strcmp(name, "hjb_subst")) {
+        OC_REQUIRE(value >= 0 && value <= 1, "hjb_subst out of range");
+        h->hjb_subst = (int)value;
     } else if (!strcmp(name, "hjb_tail")) {
         OC_REQUIRE(value >= 0 && value <= 2, "hjb_tail out of range");
         h->hjb_tail_fuse = value;

@@ -173,6 +173,7 @@ struct oc_handle {
     int32_t* hjb_log = nullptr;
     std::vector<hipEvent_t> hjb_events;
     int32_t* hjb_tail = nullptr;     // ticket counter of the fused tail (hjb.hip: k_stageV<.., FUSED>)
+    int hjb_subst = 1;               // ring solves with the active set: far-field substitution (Stage3Args::undef) on / off
     int hjb_tail_fuse = 1;           // 1: ring solves run controller + list builder inside the stage launch when few blocks take part
     int32_t* hjb_flags = nullptr;    // active-set flags of the stage tiles, two attempts (hjb.hip: k_stageV)
     size_t hjb_flags_n = 0;

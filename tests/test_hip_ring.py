@@ -299,3 +299,41 @@ def test_tail_variants_make_the_same_decisions(active):
         assert torch.equal(phi, phi0)
         for (d0, e0), (d1, e1) in zip(look0, look):
             assert e0 == e1 and np.array_equal(d0, d1)
+
+
+@pytest.mark.parametrize("room_name,gs,dtype,with_m", [("room_test", 0.05, "float32", False), ("slalom", 0.1, "float32", False),
+                                                        ("slalom", 0.1, "mixed", True), ("exit_opposite", 0.1, "float32", False)])
+def test_far_field_substitution_changes_nothing(room_name, gs, dtype, with_m):
+    """oc_set_tuning "hjb_subst" (ring solves with the exact active set): 1 (default) = a trivial tile's cells are not kept up
+    to date in the state buffers -- whoever loads them substitutes the controller's far-field value and K0 = 0 -- so a
+    change of scale no longer puts every tile on the list to rewrite the far field; 0 = the buffers hold every tile.  Same
+    attempts, same steps, same phi, same lookups: T = 20 s with rescales (float32) and rejected attempts."""
+    import torch
+    setup = _setup(room_name, gs)
+    cfg, room, Nx, Ny, X0, Y0, V = setup
+    T, nt = 20.0, 1000
+    m = torch.as_tensor(_density_like(Ny, Nx)) if with_m else None
+    res = {}
+    for subst in (0, 1):
+        eng = _engine(setup, dtype, "ring")
+        eng.set_tuning("hjb_active", 2)
+        eng.set_tuning("hjb_subst", subst)
+        eng.alloc_field(0, nt - 1)
+        st, phi = eng.solve(0, T, nt, m=m, keep=[0, 1, nt // 2, nt - 1], want_steps=True)
+        _probe_agents(eng, room, 3000, 17)
+        look = _lookups(eng, [0, 1, 2, nt // 7, nt // 2, nt - 3, nt - 2])
+        vx, vy = eng.ring_slices(0, nt // 3, nt // 3 + 5)
+        res[subst] = (st, phi.cpu(), look, vx.cpu(), vy.cpu())
+        eng.close()
+        del eng
+    (st0, phi0, look0, vx0, vy0), (st1, phi1, look1, vx1, vy1) = res[0], res[1]
+    for k in ("nfev", "n_attempt", "n_accept", "n_rescale", "final_exponent"):
+        assert st1[k] == st0[k], (k, st1[k], st0[k])
+    assert np.array_equal(st1["t_steps"], st0["t_steps"])
+    assert st0["n_attempt"] > st0["n_accept"]                   # rejected attempts on the way
+    if dtype == "float32":
+        assert st0["n_rescale"] >= 1
+    assert torch.equal(phi1, phi0) and torch.equal(vx1, vx0) and torch.equal(vy1, vy0)
+    for (d0, e0), (d1, e1) in zip(look0, look1):
+        assert e0 == e1 and np.array_equal(d0, d1)
+    assert any(np.abs(d).max() > 0 for d, _ in look0)
