@@ -92,3 +92,21 @@ def test_agent_state_dictionary_synchronises_before_a_read():
     assert len(list(a.items())) == 9 and e.n == 7
     assert isinstance(a, dict) and "x" in a                 # (membership tests do not synchronise)
     assert e.n == 7
+
+
+def test_pmc_traffic_is_quoted_per_attempt_for_the_sparse_stage_launches():
+    """bench.pmc_traffic: with the active set the stage launch's roofline quotes all HBM bytes of the solves' stage launches
+    over the launches that did any work -- not the mean of the few launches that look at every tile -- and only from a
+    file taken on the same workload with the kernel sources in the tree (tools/collect_profiles.py stamps both)."""
+    import bench
+    d = bench.pmc_file("r*_pmc_traffic*.json", "metro_station")
+    if d is None:
+        import pytest
+        pytest.skip("no PMC summary for the kernel sources in the tree (re-take with tools/run_profiles.sh)")
+    assert d["csrc_sha"] == bench.csrc_hash() and d["workload"] == "metro_station"
+    per_attempt = bench.pmc_traffic("metro_station", "hjb_stage", per_attempt=True)
+    every_tile = bench.pmc_traffic("metro_station", "hjb_stage")
+    assert per_attempt == d["k_stageV_hbm_bytes_per_attempt"] and every_tile == d["k_stageV_hbm_bytes_per_launch"]
+    assert 0 < per_attempt < every_tile
+    assert d["k_stageV_every_tile_launches"] < d["k_stageV_attempts"]
+    assert bench.pmc_traffic("slalom", "hjb_stage", per_attempt=True) is None        # another workload: nothing to quote
