@@ -1670,8 +1670,10 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
         total += wsum[q];
     }
     // A tile off the list needs its flag (and a zero error share) in the NEXT attempt's buffers.  The active set only grows
-    // and every change of scale lists every tile twice, so from the third build of a solve on both flag buffers and the
-    // partials already hold exactly that for every tile that can be off the list: only the solve's first builds write them.
+    // -- the tiles off the list after the first attempt are all that ever will be (a change of scale without the far-field
+    // substitution lists every tile twice, and every tile then writes its own words) -- so from the third build of a solve on
+    // both flag buffers and the partials already hold exactly that for every tile that can be off the list: only the
+    // solve's first builds write them.
     const bool write_unlisted = ctl->n_attempt <= 2;
     for (int t = t_lo; t < t_hi; ++t) {
         const int q = t - t_lo;
