@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OC_ABI_VERSION 1
+#define OC_ABI_VERSION 2
 
 typedef enum { OC_OK = 0, OC_ERR_ARG = -1, OC_ERR_HIP = -2, OC_ERR_STATE = -3, OC_ERR_SOLVER = -4, OC_ERR_CAPACITY = -5 } oc_status;
 typedef enum { OC_F32 = 0, OC_F64 = 1, OC_F64_F32 = 2 } oc_dtype;
@@ -74,6 +74,10 @@ typedef struct oc_hjb_stats {
     int32_t final_exponent;       /* state carried as phi * 2^-exponent (fp32 range management) */
     int32_t n_slices_written;
     double seconds;               /* host wall time of the call (synchronous) */
+    /* the persistent launch (oc_set_tuning "hjb_persist"): attempts that ran inside it, its grid, and how it ended --
+     * 0 not used, 1 the solve finished inside, 2 handed back to the launch chain (every tile active / list too long),
+     * 3 given up at a barrier deadline (grid not co-resident); the chain continues from the controller's state either way */
+    int32_t persist_attempts, persist_blocks, persist_exit, reserved;
 } oc_hjb_stats;
 
 /* Replaces compute_optimal_velocity's solve_ivp(RK45, t_eval=linspace(T,0,nt)) + vels() fill loop,
@@ -288,6 +292,8 @@ int oc_gcfm_step_sharded(oc_handle* h, const oc_agents* a, int32_t simu_step, co
  * (0 .. 15) names the communicator in oc_hjb_shard.comm_slot / oc_step_comm.comm_slot.  Halo rows go as one grouped
  * send/recv pair per neighbour (xGMI is point-to-point). */
 #define OC_COMM_ID_BYTES 128
+/* OC_OK when librccl can be bound in this process (dlopen + symbols only: no id is drawn, no bootstrap listener started) */
+int oc_comm_available(void);
 int oc_comm_unique_id(void* id_out);
 int oc_comm_create(oc_handle* h, int slot, const void* id, int rank, int world);
 int oc_comm_destroy(oc_handle* h, int slot);

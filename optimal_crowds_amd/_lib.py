@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OC_HIP_LIB") or os.path.join(HERE, "liboc_hip.so")     # (OC_HIP_LIB: A/B builds, tools/)
 CSRC = os.path.join(HERE, "csrc")
 
+OC_ABI_VERSION = 2       # include/oc_hip.h: bumped whenever a signature or a struct of the C-ABI changes
 OC_F32, OC_F64, OC_F64_F32 = 0, 1, 2
 # opt-in corrections of reference quirks (oc_hip.h: oc_set_fix_flags); 'horizon' (Q9) is host logic in the facade
 FIX_BITS = {"lookup": 1, "wall_force": 2, "pair_force": 4, "density_norm": 8}
@@ -38,6 +39,7 @@ class OcHjbStats(C.Structure):
         ("h_abs0", C.c_double), ("h_min", C.c_double), ("h_max", C.c_double),
         ("final_exponent", C.c_int32), ("n_slices_written", C.c_int32),
         ("seconds", C.c_double),
+        ("persist_attempts", C.c_int32), ("persist_blocks", C.c_int32), ("persist_exit", C.c_int32), ("reserved", C.c_int32),
     ]
 
     def as_dict(self):
@@ -131,6 +133,7 @@ SIGNATURES = {
     "oc_xchg_doubles": (C.c_int64, [C.c_int32, C.c_int32]),
     "oc_gcfm_step_sharded": (C.c_int, [C.c_void_p, C.POINTER(OcAgents), C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.POINTER(OcStepComm), C.c_void_p]),
+    "oc_comm_available": (C.c_int, []),
     "oc_comm_unique_id": (C.c_int, [C.c_void_p]),
     "oc_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "oc_comm_destroy": (C.c_int, [C.c_void_p, C.c_int]),
@@ -187,7 +190,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.oc_abi_version() != 1:
+    if lib.oc_abi_version() != OC_ABI_VERSION:
         raise OcError("liboc_hip.so ABI version mismatch")
     _lib = lib
     return lib

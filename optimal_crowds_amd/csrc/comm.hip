@@ -75,6 +75,8 @@ oc_comm* slot_of(oc_handle* h, int slot) {
 
 }   // namespace
 
+extern "C" int oc_comm_available(void) { return rccl_load(); }
+
 extern "C" int oc_comm_unique_id(void* id_out) {
     OC_REQUIRE(id_out, "null argument");
     static_assert(OC_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "oc_hip.h: OC_COMM_ID_BYTES");

@@ -2027,9 +2027,11 @@ int carve(oc_handle* h, int N, Scratch* S, bool diag = false) {
                   1024 + 16384;
     if (need > h->gcfm_bytes) {
         if (h->state_dirty) {           // lazy_state: the snapshot about to be dropped is ahead of the caller's arrays
-            int rcf = flush_state_impl(h, nullptr);
+            // (on the stream of the step that left the snapshot: torch's side streams do not wait for the NULL stream)
+            const hipStream_t fs = h->dirty_stream;
+            int rcf = flush_state_impl(h, fs);
             if (rcf) return rcf;
-            OC_HIP_CHECK(hipStreamSynchronize(nullptr));
+            OC_HIP_CHECK(hipStreamSynchronize(fs));
         }
         if (h->gcfm_buf) OC_HIP_CHECK(hipFree(h->gcfm_buf));
         h->gcfm_buf = nullptr;
@@ -2445,6 +2447,7 @@ static int launch_step(oc_handle* h, const oc_agents* a, Scratch& S, const GcfmP
     if (lazy) {
         h->state_dirty = true;
         h->dirty_agents = *a;
+        h->dirty_stream = s;
     }
     if (h->any_ring) h->ring_step_ready = (int64_t)simu_step + 1;
     oc_timer_end(h, "gcfm_finish", s);

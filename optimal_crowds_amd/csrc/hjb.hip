@@ -9,10 +9,27 @@
 //            wall cells are frozen, so a power-of-two rescale is exact) -- keeps fp32 in range for e^{T/(mu s^2)}.
 //   vx,vy  : (nslice, Ny-2, Nx-2) direction field, slice s <-> time s*T/(nt-1).
 #include "oc_internal.h"
+#include <atomic>
 #include <cmath>
 #include <chrono>
 
 namespace {
+
+// Block slots of the chip held by persistent launches of THIS process (every handle, every host thread: Engine.solve_keys
+// solves its keys concurrently).  A persistent grid waits at a barrier inside the kernel, so its blocks must all be resident:
+// the launches of one process never ask for more slots than the chip has.  (Another process's kernels are not counted --
+// the in-kernel deadline covers that case.)
+std::atomic<int> g_persist_in_use{0};
+int oc_persist_reserve(int want, int cap) {
+    want = (want / 8) * 8;                      // (a multiple of 8: a block's items stay on its XCD)
+    for (;;) {
+        int cur = g_persist_in_use.load();
+        const int got = (std::min(want, cap - cur) / 8) * 8;
+        if (got < 8) return 0;
+        if (g_persist_in_use.compare_exchange_weak(cur, cur + got)) return got;
+    }
+}
+void oc_persist_release(int n) { g_persist_in_use.fetch_sub(n); }
 
 // ---- Dormand-Prince tables (scipy rk.py:377-404), double on the host
 const double RK_A[6][5] = {
@@ -357,12 +374,78 @@ __device__ __forceinline__ int32_t ld_flag(const int32_t* p) {
     return SC1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 
+// Short work lists (the rule of a sparse solve: ~25 tiles of 1957 at 2048 x 2048): the fused tail reads what the attempt's
+// blocks left BY LIST POSITION -- one 32-byte record per listed tile (error share, max |y_new|, tile | flag << 32) -- instead
+// of every tile's partial pair and flag: one batch of TAIL_FAST_MAX loads where 2 x 1957 partials and 1957 flags were fetched,
+// reduced and scanned (the tail was 9.8 of an attempt's 20 us).  Same sums, bit for bit: a thread adds the shares of the
+// tiles = its number mod 256 in ascending order, exactly the terms of the full reduction that are not zero.
+#define TAIL_REC_CAP 128                // records an attempt's blocks write (list positions 0 .. TAIL_REC_CAP - 1)
+#define TAIL_FAST_MAX 96                // the fast tail's range of list lengths
 template <typename T>
 struct CtlLds {
     HjbCtl<T> c;                        // the controller block is worked on in LDS (one coalesced load, one coalesced store):
-    double ls[4], lm[4], la[4];         // thread 0's serial code would otherwise pay a memory round trip per field
+                                        // thread 0's serial code would otherwise pay a memory round trip per field
+    double red_s[256];                  // the workers' shares of the error sum (reduced by wavefront 0: wave_tree_sum)
+    unsigned long long m_bits;          // max |y_new| as the bits of a non-negative double (LDS atomic max)
+    int na_cnt;                         // tiles with a non-zero error share
+    int logw;                           // the attempt's log word
+    int spec_k_hi, spec_nv, spec_n_hx;  // the accepted step's bookkeeping, formed by wavefront 1 beside the decision
+    double spec_unscale;
+    T spec_lim_s;
     int all_active;                     // every tile had an error share: all were computed, the next work list is every tile
+    int fast_total;                     // fast tail: length of the list fast_list built
+    double rec_s[TAIL_FAST_MAX], rec_m[TAIL_FAST_MAX];      // fast tail: the attempt's records
+    int32_t rec_tile[TAIL_FAST_MAX], rec_flag[TAIL_FAST_MAX];
 };
+
+// The next attempt's work list from the attempt's records, by ONE wavefront (called beside the controller's serial part): the
+// list is the 3 x 3 dilation of the tiles that were computed (flag 0) -- exactly build_work_list's rule "off the list iff
+// trivial together with all eight neighbours", given that tiles off the list are trivial -- formed as a bitmap in LDS and
+// written out in ascending tile order (the order build_work_list produces).  bits: (ntile + 31) / 32 LDS words.
+__device__ __forceinline__ void fast_list(const int32_t* rec_tile, const int32_t* rec_flag, int nrec, int tnbx, int tnby,
+                                          uint32_t* bits, int32_t* __restrict__ work_out, int* total_out, int lane) {
+    const int ntile = tnbx * tnby, nw = (ntile + 31) >> 5, per = (nw + 63) >> 6;
+    for (int w = lane; w < nw; w += 64) bits[w] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = lane; e < nrec; e += 64) {
+        if (rec_flag[e] != 0) continue;
+        const int t = rec_tile[e], bi = t / tnbx, bj = t - bi * tnbx;
+#pragma unroll
+        for (int di = -1; di <= 1; ++di)
+#pragma unroll
+            for (int dj = -1; dj <= 1; ++dj) {
+                const int ni = bi + di, nj = bj + dj;
+                if (ni >= 0 && ni < tnby && nj >= 0 && nj < tnbx) {
+                    const int n = ni * tnbx + nj;
+                    atomicOr(&bits[n >> 5], 1u << (n & 31));
+                }
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int w_lo = min(lane * per, nw), w_hi = min(w_lo + per, nw);
+    int cnt = 0;
+    for (int w = w_lo; w < w_hi; ++w) cnt += __popc(bits[w]);
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    int off = incl - cnt;
+    for (int w = w_lo; w < w_hi; ++w) {
+        uint32_t b = bits[w];
+        while (b) {
+            const int q = __ffs((int)b) - 1;
+            b &= b - 1u;
+            work_out[off++] = 32 * w + q;
+        }
+    }
+    if (lane == 63) *total_out = incl;
+}
 
 // Called by EVERY thread of the block (barriers inside); threads 0 .. 255 do the work -- the same reduction tree whatever the
 // block's size, so the launch shape never changes a decision.  ctl_in: the attempt's controller block; ctl_out: where the
@@ -376,19 +459,96 @@ struct NoHook {
 // UNR: error shares in flight per worker thread and trip (the sums are formed in the same order whatever it is).  The
 // stand-alone launch behind a sweep of every tile reads thousands of shares: 16 per trip there (4096 x 4096: 30 per thread,
 // two round trips to the L2 instead of eight); the fused tail has the stage kernel's 64 registers and keeps 4.
+#ifdef OC_DIAG_BUILD
+__shared__ unsigned long long g_cb_stamp[8];    // diagnostic build: s_memrealtime inside control_body (thread 0)
+#define CB_STAMP(k) do { if (threadIdx.x == 0) g_cb_stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CB_STAMP(k) do { } while (0)
+#endif
+
+// entry e (0 .. 42) of the attempt's coefficient tables as (table value, is it a non-zero entry): ctl_prepare_entry's
+// factors, fetched BEFORE the decision is known (constant memory: a round trip) and scaled by the new step behind it
+__device__ __forceinline__ double ctl_table_value(int e, bool& valid) {
+    valid = false;
+    double v = 0.0;
+    if (e < 18) {
+        const int q = e / 6, j = e % 6;
+        valid = j < 1 + q;
+        if (valid) v = dRK_A[1 + q][j];
+    } else if (e < 36) {
+        const int q = (e - 18) / 6, j = (e - 18) % 6;
+        valid = q < 2 ? j < 4 + q : true;
+        if (valid) v = q < 2 ? dRK_A[4 + q][j] : dRK_B[j];
+    } else if (e < 43) {
+        valid = true;
+        v = dRK_E[e - 36];
+    }
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ void ctl_set_entry(HjbCtl<T>& c, int e, T v) {
+    if (e < 18) c.cA[e / 6][e % 6] = v;
+    else if (e < 36) c.cB[(e - 18) / 6][(e - 18) % 6] = v;
+    else if (e < 43) c.he[e - 36] = v;
+}
+
+// the other lane of a quad / half row / row by DPP (no LDS round trip): v (op) partner, for both words of a double
+__device__ __forceinline__ double dpp_partner(double v, const int ctrl_case) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)b, hi = (int)(b >> 32);
+    switch (ctrl_case) {
+        case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false); break;    // quad_perm [1,0,3,2]
+        case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false); break;    // quad_perm [2,3,0,1]
+        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, false); break;  // row_half_mirror
+        default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, false); break; // row_mirror
+    }
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)b, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// sum over the 64 lanes of a wavefront in a FIXED association (every caller of the controller gets the same bits): pairs inside
+// quads, quads inside half rows, half rows inside rows -- four DPP steps, after which every lane of a row holds the row's sum --
+// then (row 0 + row 1) + (row 2 + row 3).  (Six ds_bpermute round trips per word as __shfl_down steps.)
+__device__ __forceinline__ double wave_tree_sum(double v) {
+    v += dpp_partner(v, 0);
+    v += dpp_partner(v, 1);
+    v += dpp_partner(v, 2);
+    v += dpp_partner(v, 3);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+
 template <typename T, bool SC1, typename HOOK = NoHook, int UNR = 4>
 __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_in, HjbCtl<T>* __restrict__ ctl_out,
                                              const double* parts, int nparts, double* __restrict__ t_steps, int t_cap,
                                              int32_t* __restrict__ att_log, int log_cap, volatile double* mailbox,
                                              int active_set, OcRingSlot<T>* __restrict__ rslots,
                                              OcRingSlice<T>* __restrict__ rslices, int ring_cap, CtlLds<T>& L,
-                                             bool store_out = true, bool ctl_loaded = false, HOOK beside = HOOK()) {
+                                             bool store_out = true, bool ctl_loaded = false, HOOK beside = HOOK(),
+                                             const double* recs = nullptr, int nrec = 0) {
+    // What lies between the attempt's last block and the next attempt's first load is a chain of dependent steps, so the
+    // controller is laid out for LATENCY: everything that can be known before the decision is fetched or formed before it or
+    // beside it, and thread 0's serial float64 part is the decision alone --
+    //   * the reduction: per-thread shares (tile = thread mod 256, ascending), max and count by LDS atomics (exact in any
+    //     order), the sum by ONE wavefront in a fixed DPP tree (wave_tree_sum);
+    //   * the 43 table entries of the next attempt are fetched from constant memory up front and scaled behind the decision;
+    //   * the ACCEPTED step's bookkeeping -- the t_eval points it covers (ivp.py:706-723), the dense-output factors, the ring's
+    //     slot record and slice table, the step log -- depends on t and t + h only, which are known before the attempt runs:
+    //     wavefront 1 forms it while thread 0 decides ("speculatively": what it writes to memory belongs to slot n_accept and
+    //     to slices of this step's range, all rewritten by the attempt that is finally accepted there), thread 0 commits the
+    //     scalars if the step is accepted.
+    // Same values as the strictly serial form (round 3), field by field.
     HjbCtl<T>& c = L.c;
-    double (&ls)[4] = L.ls, (&lm)[4] = L.lm, (&la)[4] = L.la;
     int& all_active = L.all_active;
     const bool worker = threadIdx.x < 256;
     const int nth = 256;
-    if (threadIdx.x == 0) all_active = 0;
+    if (threadIdx.x == 0) {
+        all_active = 0;
+        L.m_bits = 0ull;
+        L.na_cnt = 0;
+    }
     constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
     static_assert(sizeof(HjbCtl<T>) % 4 == 0, "controller block must be a whole number of words");
     if (worker && !ctl_loaded) {        // (the fused tail finds it in LDS already: copied when the block started)
@@ -396,9 +556,53 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
         uint32_t* dst = reinterpret_cast<uint32_t*>(&c);
         for (int i = threadIdx.x; i < NW32; i += nth) dst[i] = src[i];
     }
+    bool tab_valid = false;
+    const double tab = (int)threadIdx.x < 43 ? ctl_table_value((int)threadIdx.x, tab_valid) : 0.0;
     // the attempt's error sums (issued together with the block's load; unused if the solve is over)
     double s = 0.0, m = 0.0, na = 0.0;
-    if (worker) {
+    double rs = 0.0, rm = 0.0;
+    long long rtb = 0;
+    if (nrec > 0 && (int)threadIdx.x < nrec) {
+        const double* r = recs + 4 * threadIdx.x;
+        rs = ld_part<true>(r);
+        rm = ld_part<true>(r + 1);
+        rtb = __hip_atomic_load(reinterpret_cast<const long long*>(r + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                    // (the controller block and the words above are in LDS)
+    // what wavefront 1 needs of the controller block for the accepted step's bookkeeping, read while nobody writes the block
+    const bool spec_wave = ((int)threadIdx.x >> 6) == 1;
+    double z_t = 0.0, z_tnew = 0.0, z_hh = 0.0, z_unscale = 0.0;
+    T z_lim_s = (T)0, z_u = (T)0;
+    int z_knext = 0, z_nt = 0, z_nacc = 0, z_ntsteps = 0, z_done = 1, z_dense = 0;
+    if (spec_wave) {
+        z_done = c.done;
+        z_t = c.t; z_tnew = c.t_new; z_hh = c.hh;
+        z_knext = c.k_next; z_nt = c.nt; z_nacc = c.n_accept; z_ntsteps = c.n_tsteps; z_dense = c.dense_mode;
+        z_unscale = ldexp(1.0, c.expo);
+        z_lim_s = (T)(c.lim * ldexp(1.0, -c.expo));
+        z_u = c.u_bg * c.in_scale;      // what the far field reads in the buffer that is y once the step is accepted
+    }
+    if (nrec > 0) {
+        // fast tail: the listed tiles' records (CtlLds) -- every other tile's share is (0, 0), which the full reduction adds
+        // without changing a bit; thread t takes the records of the tiles = t mod 256 in list (= ascending tile) order
+        if ((int)threadIdx.x < nrec) {
+            L.rec_s[threadIdx.x] = rs;
+            L.rec_m[threadIdx.x] = rm;
+            L.rec_tile[threadIdx.x] = (int32_t)(rtb & 0xFFFFFFFFll);
+            L.rec_flag[threadIdx.x] = (int32_t)(rtb >> 32);
+        }
+        __syncthreads();
+        if (worker) {
+            for (int e = 0; e < nrec; ++e) {
+                if ((L.rec_tile[e] & (nth - 1)) == (int)threadIdx.x) {
+                    const double vs = L.rec_s[e];
+                    s += vs;
+                    m = fmax(m, L.rec_m[e]);
+                    na += vs > 0.0 ? 1.0 : 0.0;
+                }
+            }
+        }
+    } else if (worker) {
         for (int i0 = threadIdx.x; i0 < nparts; i0 += UNR * nth) {
             double2 v[UNR];
 #pragma unroll
@@ -414,154 +618,167 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
                 na += v[u].x > 0.0 ? 1.0 : 0.0;
             }
         }
-        s = wave_sum(s);
-        m = wave_max(m);
-        na = wave_sum(na);
-        if ((threadIdx.x & 63) == 0) {
-            ls[threadIdx.x >> 6] = s;
-            lm[threadIdx.x >> 6] = m;
-            la[threadIdx.x >> 6] = na;
-        }
     }
+    if (worker) {
+        L.red_s[threadIdx.x] = s;
+        if (m > 0.0) atomicMax(&L.m_bits, (unsigned long long)__double_as_longlong(m));     // (non-negative doubles order like their bits)
+        if (na > 0.0) atomicAdd(&L.na_cnt, (int)na);
+    }
+    CB_STAMP(0);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int logw = 0;
-        if (c.done) {                               // an attempt enqueued past the end of the solve
-            c.accepted = 0;
-            c.do_scale = 0;
-        } else {
-            double esum = 0.0, ymax = 0.0;
-            // (active set: tiles off the work list took no part in the launch -- their share is 0 and the far field's u)
-            if (active_set != 0 && c.work_count < nparts) ymax = fabs((double)c.u_bg * (double)c.in_scale);
-            double nact = 0.0;
-            for (int q = 0; q < (nth + 63) / 64; ++q) {
-                esum += ls[q];
-                ymax = fmax(ymax, lm[q]);
-                nact += la[q];
-            }
-            c.act_sum += nact;
-            all_active = (active_set != 0 && nact == (double)nparts) ? 1 : 0;
-            const double err = sqrt(esum) / sqrt(c.n_rms);
-            ++c.n_attempt;
-            c.accepted = 0;
-            c.do_scale = 0;
-            logw = 1;
-            if (!(err == err)) {
-                c.status = OC_ERR_SOLVER - 100;     // NaN error norm (state overflow)
-                c.done = 1;
-            } else if (err < 1) {
-                double factor = (err == 0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
-                if (c.rejected) factor = fmin(1.0, factor);
-                const double hstep = fabs(c.hh);
-                c.h_abs *= factor;
-                c.h_min = fmin(c.h_min, hstep);
-                c.h_max = fmax(c.h_max, hstep);
-                c.accepted = 1;
-                c.out_parity = c.parity;
-                c.parity ^= 1;
-                c.out_t = c.t;
-                c.out_hh = c.hh;
-                c.out_unscale = ldexp(1.0, c.expo);
-                c.out_lim_s = (T)(c.lim * ldexp(1.0, -c.expo));
-                c.k_lo = c.k_next;
-                int nv = 0;
-                while (c.k_next < c.nt && ctl_te(c, c.k_next) >= c.t_new) {
-                    nv += c.k_next >= 1 ? 1 : 0;
-                    ++c.k_next;
-                }
-                c.k_hi = c.k_next;
-                c.n_hx = (c.k_hi - c.k_lo <= HJB_MAXS) ? c.k_hi - c.k_lo : 0;      // (table: the lanes, below)
-                c.out_in_scale = c.in_scale;
-                c.u_bg *= c.in_scale;               // what the far field reads in the buffer that is y from now on
-                c.in_scale = (T)1;
-                c.t = c.t_new;
-                ++c.n_accept;
-                if (c.n_tsteps < t_cap) t_steps[c.n_tsteps++] = c.t;
-                if (c.is_f32 && ymax > 0x1p64) {    // range management: keep max |y| near 2^32
-                    const int e = (int)floor(log2(ymax)) - 32;
-                    c.in_scale = (T)ldexp(1.0, -e);
-                    c.do_scale = 1;
-                    c.expo += e;
-                    ++c.n_rescale;
-                }
-                c.rejected = 0;
-                logw |= 2 | (nv << 8);
-                bool ring_full = false;
-                if (rslots != nullptr) {            // interpolant ring: what the step's dense output is made of stays in slot
-                    const int slot = c.n_accept - 1;            // n_accept - 1 (the stage launch wrote y, K0, Q1 .. Q3 there)
-                    if (slot >= ring_cap) {
-                        ring_full = true;
-                    } else {
-                        OcRingSlot<T> rs;
-                        rs.out_t = c.out_t;
-                        rs.out_hh = c.out_hh;
-                        rs.out_unscale = c.out_unscale;
-                        rs.k_lo = c.k_lo;
-                        rs.k_hi = c.k_hi;
-                        rs.dense = (active_set == 0 || c.dense_mode != 0) ? 1 : 0;
-                        rs.pad = 0;
-                        rs.lim_s = c.out_lim_s;
-                        rs.u = c.u_bg;              // the far field's y in the step's own scale (in_scale applied above)
-                        rslots[slot] = rs;
-                    }
-                }
-                if (ring_full) {
-                    c.status = OC_ERR_SOLVER - 200; // more accepted steps than ring slots: the caller retries with a larger ring
-                    c.accepted = 0;
-                    c.done = 1;
-                } else if (-(c.t - c.tf) >= 0) c.done = 1; // direction = -1
-                else ctl_prepare_step(c, true);
+    CB_STAMP(1);
+    if (threadIdx.x < 64) {
+        const int l = (int)threadIdx.x;
+        const double esum = wave_tree_sum(((L.red_s[l] + L.red_s[l + 64]) + L.red_s[l + 128]) + L.red_s[l + 192]);
+        if (threadIdx.x == 0) {
+            if (c.done) {                               // an attempt enqueued past the end of the solve
+                c.accepted = 0;
+                c.do_scale = 0;
+                L.logw = 0;
             } else {
-                c.h_abs *= fmax(0.2, 0.9 * pow(err, -0.2));
-                c.rejected = 1;
-                ctl_prepare_step(c, false);
+                double ymax = __longlong_as_double((long long)L.m_bits);
+                // (active set: tiles off the work list took no part in the launch -- their share is 0 and the far field's u)
+                if (active_set != 0 && c.work_count < nparts) ymax = fmax(ymax, fabs((double)c.u_bg * (double)c.in_scale));
+                const double nact = (double)L.na_cnt;
+                c.act_sum += nact;
+                all_active = (active_set != 0 && nact == (double)nparts) ? 1 : 0;
+                const double err = sqrt(esum) / sqrt(c.n_rms);
+                ++c.n_attempt;
+                c.accepted = 0;
+                c.do_scale = 0;
+                L.logw = 1;
+                if (!(err == err)) {
+                    c.status = OC_ERR_SOLVER - 100;     // NaN error norm (state overflow)
+                    c.done = 1;
+                } else if (err < 1) {
+                    double factor = (err == 0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+                    if (c.rejected) factor = fmin(1.0, factor);
+                    const double hstep = fabs(c.hh);
+                    c.h_abs *= factor;
+                    c.h_min = fmin(c.h_min, hstep);
+                    c.h_max = fmax(c.h_max, hstep);
+                    c.accepted = 1;
+                    c.out_parity = c.parity;
+                    c.parity ^= 1;
+                    c.out_t = c.t;
+                    c.out_hh = c.hh;
+                    c.out_in_scale = c.in_scale;
+                    c.u_bg *= c.in_scale;               // what the far field reads in the buffer that is y from now on
+                    c.in_scale = (T)1;
+                    c.t = c.t_new;
+                    ++c.n_accept;
+                    // (k_lo, k_next, k_hi, n_hx, out_unscale, out_lim_s, n_tsteps: committed below from wavefront 1's results)
+                    if (c.is_f32 && ymax > 0x1p64) {    // range management: keep max |y| near 2^32
+                        const int e = (int)floor(log2(ymax)) - 32;
+                        c.in_scale = (T)ldexp(1.0, -e);
+                        c.do_scale = 1;
+                        c.expo += e;
+                        ++c.n_rescale;
+                    }
+                    c.rejected = 0;
+                    L.logw |= 2;
+                    // (interpolant ring: the slot's record and the slice table are wavefront 1's; here only the capacity)
+                    const bool ring_full = rslots != nullptr && c.n_accept - 1 >= ring_cap;
+                    if (ring_full) {
+                        c.status = OC_ERR_SOLVER - 200; // more accepted steps than ring slots: the caller retries with a larger ring
+                        c.accepted = 0;
+                        c.done = 1;
+                    } else if (-(c.t - c.tf) >= 0) c.done = 1; // direction = -1
+                    else ctl_prepare_step(c, true);
+                } else {
+                    c.h_abs *= fmax(0.2, 0.9 * pow(err, -0.2));
+                    c.rejected = 1;
+                    ctl_prepare_step(c, false);
+                }
+            }
+            // ---- active set: the order for the list builder (every tile active for the rest of the solve -- decided on an
+            // ACCEPTED attempt only: with the far-field substitution the buffer a rejected attempt leaves as y may still hold
+            // tiles that were never written)
+            c.list_todo = (active_set != 0 && !c.done) ? (((all_active && c.accepted) || c.dense_mode) ? 2 : 1) : 0;
+        }
+    } else if (spec_wave && !z_done) {
+        // ---- the ACCEPTED step's bookkeeping, beside the decision.  Lane 0 of this wavefront walks the t_eval points ...
+        const int l = (int)threadIdx.x & 63;
+        int k_hi = z_knext, nv = 0;
+        if (l == 0) {
+            while (k_hi < z_nt && ctl_te(c, k_hi) >= z_tnew) {      // (ctl_te reads nt, te_step, Tfinal: never written here)
+                nv += k_hi >= 1 ? 1 : 0;
+                ++k_hi;
             }
         }
-        const int tk = ++c.ticks;
-        if (tk - 1 < log_cap) att_log[tk - 1] = logw;
-        if (mailbox) mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
-    }
-    beside();
-    __syncthreads();
-    // what does not depend on anything but the decision's scalars is dealt to the lanes: the next attempt's 43
-    // coefficients (threads 0..42) and the accepted step's dense-output factors (threads 64..; rk.py:560-575:
-    // x = (t_eval - t_old) / h, h x^1..4)
-    if (!c.done && (int)threadIdx.x < 43) ctl_prepare_entry(c, (int)threadIdx.x);
-    if (c.accepted && threadIdx.x >= 64 && worker && (int)threadIdx.x - 64 < c.n_hx) {
-        const int q = (int)threadIdx.x - 64;
-        const double x = (ctl_te(c, c.k_lo + q) - c.out_t) / c.out_hh;
-        double xp = x;
-        for (int pp = 0; pp < 4; ++pp) {
-            c.hx[q][pp] = (T)(c.out_hh * xp);
-            xp *= x;
+        k_hi = __builtin_amdgcn_readfirstlane(k_hi);
+        nv = __builtin_amdgcn_readfirstlane(nv);
+        const int k_lo = z_knext, n_hx = (k_hi - k_lo <= HJB_MAXS) ? k_hi - k_lo : 0;
+        const int slot = z_nacc;                        // the slot of the step this attempt tries
+        if (l == 0) {
+            L.spec_k_hi = k_hi;
+            L.spec_nv = nv;
+            L.spec_n_hx = n_hx;
+            L.spec_unscale = z_unscale;
+            L.spec_lim_s = z_lim_s;
+            if (z_ntsteps < t_cap) t_steps[z_ntsteps] = z_tnew;
+            if (rslots != nullptr && slot < ring_cap) {     // what the step's dense output is made of stays in this slot
+                OcRingSlot<T> rs_;
+                rs_.out_t = z_t;
+                rs_.out_hh = z_hh;
+                rs_.out_unscale = z_unscale;
+                rs_.k_lo = k_lo;
+                rs_.k_hi = k_hi;
+                rs_.dense = (active_set == 0 || z_dense != 0) ? 1 : 0;
+                rs_.pad = 0;
+                rs_.lim_s = z_lim_s;
+                rs_.u = z_u;                            // the far field's y in the step's own scale
+                rslots[slot] = rs_;
+            }
         }
-    }
-    // interpolant ring: the slice table -- for every t_eval point of the accepted step its slot and the same four factors
-    // (slice nt - 1 - k <-> t_eval[k], optimals.py:200-204; k = 0 is never looked up)
-    if (rslices != nullptr && c.accepted && threadIdx.x >= 64 && worker) {
-        const int slot = c.n_accept - 1;
-        for (int q = (int)threadIdx.x - 64; q < c.k_hi - c.k_lo; q += nth - 64) {
-            const int k = c.k_lo + q;
-            if (k < 1) continue;
-            const double x = (ctl_te(c, k) - c.out_t) / c.out_hh;
+        // ... the lanes the dense-output factors of those points (rk.py:560-575: x = (t_eval - t_old) / h, h x^1..4) and the
+        // ring's slice table (slice nt - 1 - k <-> t_eval[k], optimals.py:200-204; k = 0 is never looked up)
+        for (int q = l; q < k_hi - k_lo; q += 64) {
+            const int k = k_lo + q;
+            const double x = (ctl_te(c, k) - z_t) / z_hh;
             double xp = x;
-            OcRingSlice<T> e;
-            e.slot = slot;
-            e.pad = 0;
+            T hq[4];
+#pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
-                e.h[pp] = (T)(c.out_hh * xp);
+                hq[pp] = (T)(z_hh * xp);
                 xp *= x;
             }
-            rslices[c.nt - 1 - k] = e;
+            if (q < n_hx) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) c.hx[q][pp] = hq[pp];
+            }
+            if (rslices != nullptr && k >= 1 && slot < ring_cap) {
+                OcRingSlice<T> e;
+                e.slot = slot;
+                e.pad = 0;
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) e.h[pp] = hq[pp];
+                rslices[z_nt - 1 - k] = e;
+            }
         }
     }
-    // ---- active set: the next attempt's work list is built by block 0 of the k_out launch that follows (beside the output
-    // blocks, off the critical path): here only the order for it
-    // (every tile active for the rest of the solve -- decided on an ACCEPTED attempt only: with the far-field substitution the
-    // buffer a rejected attempt leaves as y may still hold tiles that were never written)
-    if (threadIdx.x == 0)
-        c.list_todo = (active_set != 0 && !c.done) ? (((all_active && c.accepted) || c.dense_mode) ? 2 : 1) : 0;
+    CB_STAMP(2);
+    beside();
     __syncthreads();
+    CB_STAMP(3);
+    // behind the decision: the accepted step's scalars are committed, the next attempt's 43 coefficients scaled
+    if (threadIdx.x == 0) {
+        if (c.accepted) {
+            c.k_lo = c.k_next;
+            c.k_next = c.k_hi = L.spec_k_hi;
+            c.n_hx = L.spec_n_hx;
+            c.out_unscale = L.spec_unscale;
+            c.out_lim_s = L.spec_lim_s;
+            if (c.n_tsteps < t_cap) ++c.n_tsteps;
+            L.logw |= L.spec_nv << 8;
+        }
+        const int tk = ++c.ticks;
+        if (tk - 1 < log_cap) att_log[tk - 1] = L.logw;
+        if (mailbox) mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
+    }
+    if (!c.done && (int)threadIdx.x < 43) ctl_set_entry(c, (int)threadIdx.x, tab_valid ? (T)(tab * c.hh) : (T)0);
+    __syncthreads();
+    CB_STAMP(4);
     if (worker && store_out) {          // (the fused tail lets the list builder work on the LDS copy first)
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
         uint32_t* dst = reinterpret_cast<uint32_t*>(ctl_out);
@@ -931,7 +1148,30 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     // maintained: the tile was trivial when b was last written, its y is the controller's far-field value and its K0 is 0,
     // and whoever loads such cells substitutes exactly that (k_stageV).  NULL: every buffer holds every tile (the other paths).
     int32_t* undef;
+    // persistent launch (PERSIST kernels): ONE launch runs attempts p_a0 .. p_amax - 1 of a sparse ring solve on a co-resident
+    // grid -- the blocks deal the attempt's work list among themselves, meet at a ticket barrier whose last arrival is the
+    // attempt's controller and list builder (the fused tail), and go on to the next attempt without leaving the chip.  The
+    // per-attempt pointers (controller block pair, flag / list / mark arrays) rotate inside the kernel exactly as the host
+    // rotates them between launches (hjb_solve_dev: enqueue_attempt).
+    HjbCtl<T>* p_ctl[2];
+    int32_t* p_flags;               // 6 * nb words: flags of two attempts, two work lists, the two buffers' undefined marks
+    int32_t* p_sync;                // [0]: attempts whose tail has run (absolute index + 1), [1]: abort (a wait timed out)
+    int32_t p_a0, p_amax;
+    int32_t p_max_items;            // a list longer than this is the launch chain's business (every CU busy anyway)
+    int32_t p_wait_ticks;           // s_memrealtime ticks (100 MHz) a block waits at the barrier before it gives the launch up
+    // OC_DIAG_BUILD (liboc_hip_diag.so, OC_PERSIST_STAMPS=<file>): 16 words per attempt -- the LAST block's s_memrealtime
+    // stamps [0..5] = attempt entered, controller block read, items done, ticket drawn, tail done, generation stored,
+    // [6] = its blockIdx, [7] = the attempt's items; [8..15] the same of block 0 (tools/persist_stamps.py)
+    unsigned long long* p_stamps;
+    // fused tail, short lists: 4 doubles per list position (error share, max |y_new|, tile | flag << 32, spare) written by the
+    // block that takes the position (TAIL_REC_CAP of them), or NULL
+    double* tail_rec;
 };
+#ifdef OC_DIAG_BUILD
+#define P_STAMP(k) do { if (PERSIST && A.p_stamps != nullptr && threadIdx.x == 0) p_st[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define P_STAMP(k) do { } while (0)
+#endif
 
 // value of the previous / next lane of the wavefront (DPP wave shifts: no LDS traffic; lane 0 / 63 get 0)
 __device__ __forceinline__ float lane_prev(float v) {
@@ -1013,56 +1253,185 @@ __device__ __forceinline__ T uniform_load(const T* p) {
 //   NQ = 3: two launches per attempt (A: K1..K3 from y, K0; B: Q1..Q3, y_new, K6 + error), region 128 x 32 -> tile 120 x 26
 //   NQ = 6: one launch (writes Q1..Q3, K6, y_new: 3 arrays read, 5 written), region 128 x 32 -> tile 112 x 20
 // Same arithmetic per cell as k_stage (one stage per launch, the cross-check variant): bit-identical results.
-template <typename T, int NQ, int S0, bool FINAL, int RWV, int RH, bool RING = false, bool FUSED = false>
-__global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Stage3Args<T> A) {      // float: 64 VGPRs, two blocks per CU
+// a wave-uniform value that reached a vector register (an LDS word, an sc1 load of one address) back in scalar registers
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uni(double v) {
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)b), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// one word that another CU wrote a moment ago, inside this very launch (persistent launch: never through the scalar cache)
+__device__ __forceinline__ int32_t ld_fresh(const int32_t* p) {
+    return uni(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ float ld_fresh(const float* p) {
+    return uni(__int_as_float(__hip_atomic_load(reinterpret_cast<const int32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+}
+__device__ __forceinline__ double ld_fresh(const double* p) {
+    return uni(__longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+}
+
+// PERSIST (FUSED ring kernels): the launch is a co-resident grid that runs attempt after attempt of a sparse solve -- see
+// Stage3Args::p_ctl.  What changes against the one-attempt launch: the per-attempt pointers rotate in here; everything the
+// previous attempt's blocks wrote is read behind an agent-scope acquire and never through the scalar cache or a load the
+// compiler may take for invariant (the controller block comes through LDS, single words through ld_fresh); a block takes the
+// items blockIdx.x, blockIdx.x + gridDim.x, ... of the attempt's list; the ticket barrier is taken by EVERY block, once per
+// attempt, behind an agent-scope release of the block's stores; the blocks that are not last wait for the generation word --
+// with a deadline: a grid that is not co-resident after all (another process's kernels on the chip) gives the launch up
+// instead of hanging, and the host goes on with the launch chain from the controller's last state.
+// (The persistent variant gets twice the registers -- ONE block per CU: with the attempt and item loops around it the tile
+// code spilled 155 vector registers at 64; a sparse attempt lists fewer tiles than the chip has CUs anyway.)
+template <typename T, int NQ, int S0, bool FINAL, int RWV, int RH, bool RING = false, bool FUSED = false, bool PERSIST = false>
+__global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST ? 2 : 1)) k_stageV(Stage3Args<T> A) {      // float: 64 VGPRs, two blocks per CU
     static_assert(!RING || (NQ == 6 && FINAL), "the ring is written by the one-launch attempt");
     static_assert(!FUSED || RING, "the fused tail belongs to the ring path");
+    static_assert(!PERSIST || FUSED, "the persistent launch is the fused-tail launch in a loop");
     __shared__ int s_last;
     __shared__ CtlLds<T> s_tail;        // FUSED: the controller's LDS block (unreferenced, hence absent, otherwise)
+    __shared__ int32_t s_wsum[16];      // FUSED: the list builder's wavefront sums
     constexpr int HX = 4 * ((NQ + 3) / 4), HY = NQ, RW = 4 * RWV, NT = RWV * RH;
     constexpr int TX = RW - 2 * HX, TY = RH - 2 * HY, LS = RW + 8;
     constexpr int NK = S0 + NQ;                     // stage derivatives alive at the end of the launch
     static_assert(NQ == 3 || (NQ == 6 && S0 == 1 && FINAL), "three stages per launch, or the whole attempt");
     __shared__ alignas(16) T buf[2][RH + 2][LS];    // slot of region cell (r, c): [r + 1][c + 4]; one spare ring
-    const HjbCtl<T>* __restrict__ ctl = A.ctl;
+    constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4), CW = (NW32 + 255) / 256;
+    __shared__ T s_p[6][3];             // PERSIST: the dense output's P columns (kernel arguments: 18 scalar registers held
+    if (PERSIST && threadIdx.x < 18)    // across the attempt and item loops otherwise; the first barrier below publishes them)
+        s_p[threadIdx.x / 3][threadIdx.x % 3] = A.p[threadIdx.x / 3][threadIdx.x % 3];
+#ifdef OC_DIAG_BUILD
+    unsigned long long p_st[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  for (int att = PERSIST ? A.p_a0 : 0;; ++att) {    // (PERSIST: the attempts of this launch; otherwise ONE pass)
+    if (PERSIST && att >= A.p_amax) return;
+    P_STAMP(0);
+    // the attempt's controller block, flags, work list (PERSIST: rotated here as hjb_solve_dev rotates them between launches)
+    const HjbCtl<T>* __restrict__ ctl = PERSIST ? A.p_ctl[att & 1] : A.ctl;
+    HjbCtl<T>* const ctl_out = PERSIST ? A.p_ctl[(att + 1) & 1] : A.ctl_out;
+    const int nb_all = ((A.Nx + TX - 1) / TX) * ((A.Ny + TY - 1) / TY);
+    const bool p_act = PERSIST && A.active_set != 0;
+    const int32_t* const flags_prev = PERSIST ? (p_act && att > 0 ? A.p_flags + (size_t)((att - 1) & 1) * nb_all : nullptr) : A.flags_prev;
+    int32_t* const flags_cur = PERSIST ? (p_act ? A.p_flags + (size_t)(att & 1) * nb_all : nullptr) : A.flags_cur;
+    const int32_t* const work = PERSIST ? (p_act && att > 0 ? A.p_flags + (size_t)(2 + (att & 1)) * nb_all : nullptr) : A.work;
+    int32_t* const flags_next = PERSIST ? (p_act ? A.p_flags + (size_t)((att + 1) & 1) * nb_all : nullptr) : A.flags_next;
+    int32_t* const work_next = PERSIST ? (p_act ? A.p_flags + (size_t)(2 + ((att + 1) & 1)) * nb_all : nullptr) : A.work_next;
     // Everything the launch reads of the controller block (264 contiguous bytes, fresh in every attempt: the first wavefront
     // of a CU misses the scalar cache on each of its lines) is loaded in ONE batch up front, together with this block's entry
     // of the work list: left to itself the compiler issues these loads where the values are first used, behind the early
     // exits -- a chain of five dependent round trips to the L2 (3 - 5 us) before a block of a sparse attempt, alone on its CU,
     // issues its first vector load.  (keep_sgpr: an empty asm statement that needs the values in scalar registers.)
-    const int c_done = ctl->done, par = ctl->parity, c_dense = ctl->dense_mode, c_wcount = ctl->work_count,
-              c_nacc = ctl->n_accept, c_rej = ctl->rejected;
-    const T c_oiscale = ctl->out_in_scale, c_ubg = ctl->u_bg;
-    T cc[NQ][6], he[7];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            if (NQ == 6) cc[q][j] = q < 3 ? ctl->cA[q][j] : ctl->cB[q - 3][j];
-            else cc[q][j] = FINAL ? ctl->cB[q][j] : ctl->cA[q][j];
-        }
-#pragma unroll
-    for (int j = 0; j < 7; ++j) he[j] = FINAL ? ctl->he[j] : (T)0;
-    const T atol_s = ctl->atol_s, in_scale = ctl->in_scale;
     const int Ny = A.Ny, Nx = A.Nx;
     const int nbx = (Nx + TX - 1) / TX, nby = (Ny + TY - 1) / TY, nb = nbx * nby;
     const int per = (nb + 7) / 8;
     int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);              // XCD-aware order (tile_of_block)
-    const bool listed = NQ == 6 && A.flags_cur != nullptr && A.work != nullptr;
-    const int w_entry = listed ? A.work[min(logical, nb - 1)] : 0;      // (read before it is known to be needed: in bounds)
-    asm volatile("" ::SB(c_done), SB(par), SB(c_dense), SB(c_wcount), SB(c_nacc), SB(c_rej), SB(w_entry), SB(c_oiscale), SB(c_ubg),
-                 SB(atol_s), SB(in_scale), SB(cc[0][0]), SB(cc[NQ / 2 - 1][5]), SB(cc[NQ / 2][0]), SB(cc[NQ - 1][5]), SB(he[0]),
-                 SB(he[6]), SB(A.coef), SB(A.flags_prev));
-    if (c_done) return;                             // an attempt enqueued past the end of the solve
+    const bool listed = NQ == 6 && flags_cur != nullptr && work != nullptr;
+    int c_done, par, c_dense, c_wcount, c_nacc, c_rej, w_entry;
+    T c_oiscale, c_ubg, atol_s, in_scale;
+    T cc[NQ][6], he[7];
+    if (PERSIST) {
+        // every block copies the attempt's controller block into LDS -- sc1 loads: the previous attempt's tail, on another CU,
+        // wrote it a moment ago -- together with its first entry of the work list; the fields then come out of LDS into scalar
+        // registers (a plain load here could be taken for invariant across the attempts, a scalar load could hit a stale line)
+        uint32_t cwp[CW];
+        if (threadIdx.x < 256) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
+#pragma unroll
+            for (int q = 0; q < CW; ++q)
+                cwp[q] = ((int)threadIdx.x + 256 * q < NW32)
+                             ? __hip_atomic_load(src + threadIdx.x + 256 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        }
+        w_entry = listed ? ld_fresh(work + min((int)blockIdx.x, nb - 1)) : 0;
+        if (threadIdx.x < 256) {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tail.c);
+#pragma unroll
+            for (int q = 0; q < CW; ++q)
+                if ((int)threadIdx.x + 256 * q < NW32) dst[threadIdx.x + 256 * q] = cwp[q];
+        }
+        __syncthreads();
+        const HjbCtl<T>& lc = s_tail.c;
+        c_done = uni(lc.done); par = uni(lc.parity); c_dense = uni(lc.dense_mode); c_wcount = uni(lc.work_count);
+        c_nacc = uni(lc.n_accept); c_rej = uni(lc.rejected);
+        c_oiscale = uni(lc.out_in_scale); c_ubg = uni(lc.u_bg); atol_s = uni(lc.atol_s); in_scale = uni(lc.in_scale);
+        P_STAMP(1);
+        // (the 43 coefficients of the attempt are NOT taken into registers here: with the attempt and item loops around the
+        // tile code they -- and the splat pairs the packed instructions want -- were alive all the way and the scalar registers
+        // overflowed: 330 spilled, 300 v_readlane in the tile code.  A stage fetches its own from the LDS copy: coef_of)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) cc[q][j] = (T)0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) he[j] = (T)0;
+    } else {
+        c_done = ctl->done; par = ctl->parity; c_dense = ctl->dense_mode; c_wcount = ctl->work_count;
+        c_nacc = ctl->n_accept; c_rej = ctl->rejected;
+        c_oiscale = ctl->out_in_scale; c_ubg = ctl->u_bg;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if (NQ == 6) cc[q][j] = q < 3 ? ctl->cA[q][j] : ctl->cB[q - 3][j];
+                else cc[q][j] = FINAL ? ctl->cB[q][j] : ctl->cA[q][j];
+            }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) he[j] = FINAL ? ctl->he[j] : (T)0;
+        atol_s = ctl->atol_s; in_scale = ctl->in_scale;
+        w_entry = listed ? work[min(logical, nb - 1)] : 0;      // (read before it is known to be needed: in bounds)
+        asm volatile("" ::SB(c_done), SB(par), SB(c_dense), SB(c_wcount), SB(c_nacc), SB(c_rej), SB(w_entry), SB(c_oiscale), SB(c_ubg),
+                     SB(atol_s), SB(in_scale), SB(cc[0][0]), SB(cc[NQ / 2 - 1][5]), SB(cc[NQ / 2][0]), SB(cc[NQ - 1][5]), SB(he[0]),
+                     SB(he[6]), SB(A.coef), SB(flags_prev));
+    }
+    if (c_done) return;                             // an attempt enqueued past the end of the solve (PERSIST: every block sees it)
     const T* __restrict__ y = A.Y[par];
     const T* kin[4] = {A.KX[par], A.KM[0], A.KM[1], A.KM[2]};
-    asm volatile("" ::SB(y), SB(kin[0]));           // (the two pointers picked by the parity: in registers before the loads
+    if (!PERSIST) asm volatile("" ::SB(y), SB(kin[0]));   // (the two pointers picked by the parity: in registers before the loads
                                                     // below are issued, or a late scalar load would wait for all of those)
     T* ynew = A.Y[par ^ 1];
-    if ((int)(blockIdx.x / 8) >= per || logical >= nb) return;
-    const bool sparse = NQ == 6 && A.flags_cur != nullptr && c_dense == 0;
+    if (!PERSIST && ((int)(blockIdx.x / 8) >= per || logical >= nb)) return;
+    const bool sparse = NQ == 6 && flags_cur != nullptr && c_dense == 0;
+    // PERSIST: the launch is for sparse attempts -- once every tile is active, or the list outgrows what this grid should
+    // carry, the launch chain takes over (the controller block is between two attempts: every block reads the same words)
+    const int n_items = (sparse && work != nullptr) ? min(c_wcount, nb) : nb;
+    if (PERSIST && ((p_act && c_dense != 0) || n_items > A.p_max_items)) return;
     // blocks that take part in the attempt (the others have returned above or do so just below): what the tail waits for
-    const int n_part = (sparse && A.work != nullptr) ? min(c_wcount, nb) : nb;
+    // (PERSIST: the blocks that have an item -- the others neither draw a ticket nor poll eagerly: they look in on the
+    // generation word now and then and take part again when the list has grown to reach them)
+    const int n_part = PERSIST ? min((sparse && work != nullptr) ? n_items : 8 * per, (int)gridDim.x) : n_items;
+    // PERSIST: wait for the attempt's tail (generation > att) -- with a deadline; false: the launch is given up
+    auto wait_gen = [&](const int nap) __attribute__((always_inline)) -> bool {
+        if (threadIdx.x == 0) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            int ok = 1;
+            for (;;) {
+                const long long w = __hip_atomic_load(reinterpret_cast<const long long*>(A.p_sync), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(w >> 32) != 0) {          // somebody's deadline passed
+                    ok = 0;
+                    break;
+                }
+                if ((int)(w & 0xFFFFFFFFll) > att) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)(uint32_t)A.p_wait_ticks) {
+                    __hip_atomic_store(A.p_sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+                if (nap) __builtin_amdgcn_s_sleep(32);
+                else __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_last = ok ? 0 : -1;
+        }
+        __syncthreads();
+        const bool ok = s_last == 0;
+        __syncthreads();                    // (s_last is written again by the next barrier's ticket)
+        return ok;
+    };
+    if constexpr (PERSIST) {
+        if ((int)blockIdx.x >= n_part) {    // no item for this block in this attempt
+            if (!wait_gen(1)) return;
+            continue;
+        }
+    }
     auto st_part = [&](double* p, double v) {           // a word for the controller (thread 0 only)
         if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *p = v;
@@ -1075,23 +1444,94 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     // turns out to be the last one has it at hand instead of behind another round trip.  The words are LOADED here and stored
     // below, behind the tile's own loads (store_ctl_words) -- stored on the spot, the first four wavefronts of every block sat
     // out a round trip to the L2 before they issued anything else.
-    constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4), CW = (NW32 + 255) / 256;
     uint32_t cw[CW];
-    if (FUSED && threadIdx.x < 256) {
+    if (FUSED && !PERSIST && threadIdx.x < 256) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
 #pragma unroll
         for (int q = 0; q < CW; ++q) cw[q] = ((int)threadIdx.x + 256 * q < NW32) ? src[threadIdx.x + 256 * q] : 0u;
     }
     auto store_ctl_words = [&]() {
-        if (FUSED && threadIdx.x < 256) {
+        if (FUSED && !PERSIST && threadIdx.x < 256) {
             uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tail.c);
 #pragma unroll
             for (int q = 0; q < CW; ++q)
                 if ((int)threadIdx.x + 256 * q < NW32) dst[threadIdx.x + 256 * q] = cw[q];
         }
     };
+    auto tail_work = [&]() __attribute__((always_inline)) {                            // the attempt's controller and list builder: every thread of ONE block
+        // Everything the tail reads of the other blocks goes out in ONE batch: the tiles' flags for the list builder here,
+        // the error partials inside control_body right behind them -- two dependent round trips to the L2 otherwise.
+        // (the flags by wavefronts 4 .. 7, idle otherwise, straight into the builder's LDS bytes, while wavefronts 0 .. 3 run
+        // the controller: its error partials and the flags are in flight together)
+        uint8_t* const sflag = reinterpret_cast<uint8_t*>(&buf[0][0][0]);
+        static_assert(NT >= 512, "the tail's helper wavefronts");
+        // short lists (the rule of a sparse solve): reduction and list from the listed tiles' records -- CtlLds, fast_list.
+        // From the solve's third build on (the first two also write the words of the tiles they leave off the list), with the
+        // far-field substitution (tiles may stay off the list whatever the decision).
+        const int nrec = (FUSED && sparse && work != nullptr && A.tail_rec != nullptr && n_items <= TAIL_FAST_MAX) ? n_items : 0;
+        const bool fast_ok = nrec > 0 && A.active_set != 0 && A.undef != nullptr && s_tail.c.n_attempt + 1 > 2;
+        uint32_t* const lbits = reinterpret_cast<uint32_t*>(&buf[1][0][0]);
+        static_assert(sizeof(buf) / 2 >= 4 * ((12000 + 31) / 32), "the fast list's bitmap fits one tile buffer");
+        const bool pre_ok = !fast_ok && sparse && A.active_set != 0 && nb <= (int)sizeof(buf);     // (dense mode: no flags, no list)
+        if (pre_ok && threadIdx.x >= 256 && threadIdx.x < 512) {
+            for (int t0 = (int)threadIdx.x - 256; t0 < nb; t0 += 8 * 256) {
+                int32_t f[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) f[u] = (t0 + u * 256 < nb) ? ld_flag<true>(flags_cur + t0 + u * 256) : 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (t0 + u * 256 < nb) sflag[t0 + u * 256] = f[u] != 0 ? 1 : 0;
+            }
+        }
+        // While thread 0 runs the controller's serial float64 part (~2.7 us), the other wavefronts form the list builder's
+        // decision-independent half from the flags just fetched: which tiles go on the next list if tiles may stay off it,
+        // the counts, the wavefronts' prefix sums (list_prepare; the barrier inside control_body that precedes the serial
+        // part has made the flag bytes visible, the one behind it publishes wsum).
+        ListPre lpre;
+        lpre.valid = false;
+        auto beside = [&]() {
+            if (fast_ok) {
+                if (((int)threadIdx.x >> 6) == 2)       // (wavefront 1 is busy with the accepted step's bookkeeping)
+                    fast_list(s_tail.rec_tile, s_tail.rec_flag, nrec, nbx, nby, lbits, work_next, &s_tail.fast_total, (int)threadIdx.x & 63);
+            } else if (pre_ok && s_tail.c.dense_mode == 0) lpre = list_prepare(nbx, nby, sflag, s_wsum);
+        };
+        control_body<T, true>(ctl, ctl_out, A.partial, nb, A.t_steps, A.t_cap, A.att_log, A.log_cap, nullptr, A.active_set,
+                              A.rslots, A.rslices, A.ring_cap, s_tail, false, true, beside, A.tail_rec, nrec);
+        // (the tile buffers are free: the builder's flag bytes)
+        static_assert(sizeof(buf) >= 12000, "the builder's flag bytes fit the tile buffers");
+        if (A.active_set) {
+            if (fast_ok && s_tail.c.list_todo == 1) {       // the list is written (fast_list, beside the decision): its length
+                if (threadIdx.x == 0) s_tail.c.work_count = s_tail.fast_total;
+            } else {
+                build_work_list<T, true>(&s_tail.c, flags_cur, flags_next, work_next, A.partial, nbx, nby, sflag,
+                                         (int)sizeof(buf), nullptr, pre_ok, &lpre, s_wsum, A.undef);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_tail.c);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(ctl_out);
+            for (int i = threadIdx.x; i < NW32; i += 256) dst[i] = src[i];
+            if (s_tail.c.done) {        // (both blocks: see control_body)
+                uint32_t* dst2 = reinterpret_cast<uint32_t*>(const_cast<HjbCtl<T>*>(ctl));
+                for (int i = threadIdx.x; i < NW32; i += 256) dst2[i] = src[i];
+            }
+        }
+        // the host's mailbox last (pinned host memory: writes over PCIe -- the launch cannot end, and the persistent launch's
+        // next barrier cannot be passed, before they are acknowledged: ~1 us).  The host only paces its enqueuing by it and
+        // needs to see the end: every 4th tick, a change of mode, the end.  The persistent launch posts nothing per attempt
+        // (the host waits for the launch and reads the controller block).
+        if (threadIdx.x == 0 && !PERSIST) {
+            const HjbCtl<T>& c = s_tail.c;
+            if ((c.ticks & 3) == 0 || c.done || c.dense_mode || c.work_count > TAIL_FLAT_MAX) {
+                A.mailbox[1] = A.active_set ? (c.dense_mode ? (double)nb + 0.5 : (double)c.work_count) : (double)nb;
+                A.mailbox[0] = (double)c.ticks + (c.done ? 4294967296.0 : 0.0);
+            }
+        }
+    };
     const int part_pos = logical;                       // this block's number among the participants (0 .. n_part - 1)
-    auto fused_tail = [&]() {                           // called by every thread of a participating block, at its end
+    auto fused_tail = [&]() __attribute__((always_inline)) {                           // called by every thread of a participating block, at its end
         if (threadIdx.x == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this block's sc1 words have left
             // One counter takes ~90 tickets per us: fine for the active set's short lists, not for a launch of thousands of
@@ -1117,62 +1557,77 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
         __syncthreads();
         if (!s_last) return;
         if (threadIdx.x == 0) __hip_atomic_store(A.tail_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // Everything the tail reads of the other blocks goes out in ONE batch: the tiles' flags for the list builder here,
-        // the error partials inside control_body right behind them -- two dependent round trips to the L2 otherwise.
-        // (the flags by wavefronts 4 .. 7, idle otherwise, straight into the builder's LDS bytes, while wavefronts 0 .. 3 run
-        // the controller: its error partials and the flags are in flight together)
-        uint8_t* const sflag = reinterpret_cast<uint8_t*>(&buf[0][0][0]);
-        static_assert(NT >= 512, "the tail's helper wavefronts");
-        const bool pre_ok = sparse && A.active_set != 0 && nb <= (int)sizeof(buf);     // (dense mode: no flags, no list)
-        if (pre_ok && threadIdx.x >= 256 && threadIdx.x < 512) {
-            for (int t0 = (int)threadIdx.x - 256; t0 < nb; t0 += 8 * 256) {
-                int32_t f[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) f[u] = (t0 + u * 256 < nb) ? ld_flag<true>(A.flags_cur + t0 + u * 256) : 0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (t0 + u * 256 < nb) sflag[t0 + u * 256] = f[u] != 0 ? 1 : 0;
-            }
-        }
-        // While thread 0 runs the controller's serial float64 part (~2.7 us), the other wavefronts form the list builder's
-        // decision-independent half from the flags just fetched: which tiles go on the next list if tiles may stay off it,
-        // the counts, the wavefronts' prefix sums (list_prepare; the barrier inside control_body that precedes the serial
-        // part has made the flag bytes visible, the one behind it publishes wsum).
-        __shared__ int32_t s_wsum[16];
-        ListPre lpre;
-        lpre.valid = false;
-        auto beside = [&]() {
-            if (pre_ok && s_tail.c.dense_mode == 0) lpre = list_prepare(nbx, nby, sflag, s_wsum);
-        };
-        control_body<T, true>(ctl, A.ctl_out, A.partial, nb, A.t_steps, A.t_cap, A.att_log, A.log_cap, nullptr, A.active_set,
-                              A.rslots, A.rslices, A.ring_cap, s_tail, false, true, beside);
-        // (the tile buffers are free: the builder's flag bytes)
-        static_assert(sizeof(buf) >= 12000, "the builder's flag bytes fit the tile buffers");
-        if (A.active_set)
-            build_work_list<T, true>(&s_tail.c, A.flags_cur, A.flags_next, A.work_next, A.partial, nbx, nby, sflag,
-                                     (int)sizeof(buf), nullptr, pre_ok, &lpre, s_wsum, A.undef);
-        __syncthreads();
-        if (threadIdx.x < 256) {
-            constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_tail.c);
-            uint32_t* dst = reinterpret_cast<uint32_t*>(A.ctl_out);
-            for (int i = threadIdx.x; i < NW32; i += 256) dst[i] = src[i];
-            if (s_tail.c.done) {        // (both blocks: see control_body)
-                uint32_t* dst2 = reinterpret_cast<uint32_t*>(const_cast<HjbCtl<T>*>(ctl));
-                for (int i = threadIdx.x; i < NW32; i += 256) dst2[i] = src[i];
-            }
-        }
-        // the host's mailbox last (pinned host memory: posted writes over PCIe, nothing of the tail waits behind them)
-        if (threadIdx.x == 0) {
-            const HjbCtl<T>& c = s_tail.c;
-            A.mailbox[1] = A.active_set ? (c.dense_mode ? (double)nb + 0.5 : (double)c.work_count) : (double)nb;
-            A.mailbox[0] = (double)c.ticks + (c.done ? 4294967296.0 : 0.0);
-        }
+        tail_work();
     };
-    if (sparse && A.work != nullptr) {              // active set: entry `logical` of the work list, or nothing to do
+    // PERSIST: the attempt's barrier.  Every block that has an item arrives once per attempt: its waves' stores are out (the barrier's own
+    // workgroup release), one lane writes them back for the other XCDs and draws the ticket; the last arrival runs the tail
+    // and publishes the generation, the others wait for it -- behind a deadline.  false: the launch is given up.
+    auto persist_barrier = [&]() __attribute__((always_inline)) -> bool {
+        __syncthreads();
+        P_STAMP(2);
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const int ticket = __hip_atomic_fetch_add(A.tail_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (ticket == n_part - 1) ? 1 : 0;
+        }
+        P_STAMP(3);
+        __syncthreads();
+#ifdef OC_DIAG_BUILD
+        (void)0;
+#endif
+        if (s_last) {
+            // (no acquire here: everything the tail reads of the other blocks it reads with sc1 loads; the invalidation this
+            // block needs before ITS next tile loads comes behind the publication, off everybody else's path)
+            if (threadIdx.x == 0) __hip_atomic_store(A.tail_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tail_work();
+            __syncthreads();
+            P_STAMP(4);
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(A.p_sync, att + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            P_STAMP(5);
+            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+#ifdef OC_DIAG_BUILD
+            if (A.p_stamps != nullptr && threadIdx.x == 0) {
+                unsigned long long* o = A.p_stamps + (size_t)att * 16;
+                for (int k = 0; k < 6; ++k) o[k] = p_st[k];
+                o[6] = blockIdx.x;
+                o[7] = (unsigned long long)n_items;
+                for (int k = 0; k < 5; ++k) o[8 + k] = g_cb_stamp[k];
+                o[15] = 1;
+            }
+#endif
+            return true;
+        }
+        return wait_gen(0);
+    };
+    if (!PERSIST && sparse && work != nullptr) {    // active set: entry `logical` of the work list, or nothing to do
         if (logical >= c_wcount) return;
         logical = w_entry;
     }
+    // the attempt's coefficients where a stage needs them (PERSIST: out of the block's LDS copy of the controller block)
+    auto coef_of = [&](int q, int j) __attribute__((always_inline)) -> T {
+        if constexpr (PERSIST) return uni(q < 3 ? s_tail.c.cA[q][j] : s_tail.c.cB[q - 3][j]);
+        else return cc[q][j];
+    };
+    auto he_of = [&](int j) __attribute__((always_inline)) -> T {
+        if constexpr (PERSIST) return uni(s_tail.c.he[j]);
+        else return he[j];
+    };
+    // the tile's record for the fused tail's short-list path (thread 0; e_pos: the tile's position on the work list, or -1)
+    auto put_rec = [&](int e_pos, int tile, double es, double ym, int flag) __attribute__((always_inline)) {
+        if (FUSED && A.tail_rec != nullptr && e_pos >= 0 && e_pos < TAIL_REC_CAP) {
+            double* r = A.tail_rec + 4 * e_pos;
+            __hip_atomic_store(r, es, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(r + 1, ym, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<long long*>(r + 2), (long long)(uint32_t)tile | ((long long)flag << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // ---- one tile of the attempt (every thread of the block; block-uniform control flow)
+    auto do_tile = [&](const int logical, const int e_pos) {
     const int vx = (int)threadIdx.x % RWV, ry = (int)threadIdx.x / RWV;
     const int gi = (logical / nbx) * TY - HY + ry, gj = (logical % nbx) * TX - HX + 4 * vx;
     const bool in = gi >= 0 && gi < Ny && gj >= 0 && gj < Nx;      // (Nx % 4 == 0: a vector is inside or outside as a whole)
@@ -1236,13 +1691,19 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     int32_t flag_prev = 0, my_undef = 0, own_undef = 0;
     if (subst && in) my_undef = A.undef[(size_t)par * nb + (gi / TY) * nbx + gj / TX];
     if (track) {
-        u_raw = uniform_load(y + ((int64_t)(bi * TY) * Nx + bj * TX));     // (the tile's first cell; y is read-only here)
+        // (PERSIST: other blocks of this launch wrote these words in the previous attempt -- ld_fresh, not the scalar cache)
+        const T* const probe = y + ((int64_t)(bi * TY) * Nx + bj * TX);     // (the tile's first cell; y is read-only here)
+        u_raw = PERSIST ? ld_fresh(probe) : uniform_load(probe);
         // (unconditional: behind a branch the flag's load waited for the probe's)
-        flag_prev = uniform_load((A.flags_prev != nullptr ? A.flags_prev : A.flags_cur) + logical);
-        if (subst) own_undef = uniform_load(A.undef + ((size_t)par * nb + logical));
+        const int32_t* const fp = (flags_prev != nullptr ? flags_prev : flags_cur) + logical;
+        flag_prev = PERSIST ? ld_fresh(fp) : uniform_load(fp);
+        if (subst) {
+            const int32_t* const up = A.undef + ((size_t)par * nb + logical);
+            own_undef = PERSIST ? ld_fresh(up) : uniform_load(up);
+        }
     }
     store_ctl_words();
-    own_prev = A.flags_prev != nullptr && flag_prev != 0;
+    own_prev = flags_prev != nullptr && flag_prev != 0;
     if (subst) {
         if (own_undef) u_raw = c_ubg;
         if (my_undef) {
@@ -1256,7 +1717,7 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
     }
     // a tile that was computed in the previous attempt is computed again without the test (the front only advances; were
     // it ever trivial again, computing it is still right): the test's barrier is paid by the ring around the active region
-    const bool need_test = track && (A.flags_prev == nullptr || own_prev);
+    const bool need_test = track && (flags_prev == nullptr || own_prev);
     bool cell_trivial = true;
     if (in) {
         if (need_test) {
@@ -1314,16 +1775,18 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             }
             if (threadIdx.x == 0) {
                 const int r_lo = bi * TY, r_hi = min(r_lo + TY, Ny);
+                const double um = (r_hi > A.row_lo && r_lo < A.row_hi) ? (double)fabs(un) : 0.0;
                 st_part(A.partial + 2 * logical, 0.0);
-                st_part(A.partial + 2 * logical + 1, (r_hi > A.row_lo && r_lo < A.row_hi) ? (double)fabs(un) : 0.0);
-                st_flag(A.flags_cur + logical, 1);
-                if (subst) A.undef[(size_t)(par ^ 1) * nb + logical] = 1;      // (read by later launches only)
+                st_part(A.partial + 2 * logical + 1, um);
+                st_flag(flags_cur + logical, 1);
+                put_rec(e_pos, logical, 0.0, um, 1);
+                if (subst) A.undef[(size_t)(par ^ 1) * nb + logical] = 1;      // (read by later attempts only)
             }
-            if (FUSED) fused_tail();
+            if constexpr (FUSED && !PERSIST) fused_tail();
             return;
         }
         if (threadIdx.x == 0) {
-            st_flag(A.flags_cur + logical, 0);
+            st_flag(flags_cur + logical, 0);
             if (subst) A.undef[(size_t)(par ^ 1) * nb + logical] = 0;          // (the tile's cells of y_new / K6 are written below)
             // (ring: the tile holds data from this slot on -- it was tested just now, so it was trivial until here; a tile
             // that skips the test has been computed before and is on record)
@@ -1349,7 +1812,8 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             T2 acc0 = zero2, acc1 = zero2;
 #pragma unroll
             for (int j = 0; j < S0 + q; ++j) {
-                const T2 c2 = {cc[q][j], cc[q][j]};
+                const T cqj = coef_of(q, j);
+                const T2 c2 = {cqj, cqj};
                 acc0 = __builtin_elementwise_fma(c2, kv[j][0], acc0);
                 acc1 = __builtin_elementwise_fma(c2, kv[j][1], acc1);
             }
@@ -1407,7 +1871,8 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
                 T2 q0 = zero2, q1 = zero2;
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const T2 p2 = {A.p[j][pp], A.p[j][pp]};
+                    const T pj = PERSIST ? uni(s_p[j][pp]) : A.p[j][pp];
+                    const T2 p2 = {pj, pj};
                     q0 = __builtin_elementwise_fma(kv[rows[j]][0], p2, q0);
                     q1 = __builtin_elementwise_fma(kv[rows[j]][1], p2, q1);
                 }
@@ -1425,9 +1890,13 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             if (gi >= A.row_lo && gi < A.row_hi) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    T2 e = (T2){he[6], he[6]} * kv[NK - 1][p];
+                    const T he6 = he_of(6);
+                    T2 e = (T2){he6, he6} * kv[NK - 1][p];
 #pragma unroll
-                    for (int j = 0; j < NK - 1; ++j) e = __builtin_elementwise_fma((T2){he[j], he[j]}, kv[j][p], e);
+                    for (int j = 0; j < NK - 1; ++j) {
+                        const T hej = he_of(j);
+                        e = __builtin_elementwise_fma((T2){hej, hej}, kv[j][p], e);
+                    }
                     const T e2[2] = {e.x, e.y}, y2[2] = {yv[p].x, yv[p].y}, t2[2] = {t[p].x, t[p].y};
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
@@ -1462,13 +1931,33 @@ __global__ void __launch_bounds__(RWV * RH, sizeof(T) == 4 ? 8 : 4) k_stageV(Sta
             if (threadIdx.x == 0) {
                 st_part(A.partial + 2 * logical, a);
                 st_part(A.partial + 2 * logical + 1, b);
+                put_rec(e_pos, logical, a, b, 0);
             }
         }
-        if (FUSED) {
+        if constexpr (FUSED && !PERSIST) {
             __syncthreads();            // (the tail reuses the tile buffers and the reduction's LDS words)
             fused_tail();
         }
     }
+    };      // do_tile
+    if constexpr (!PERSIST) {
+        do_tile(logical, (sparse && work != nullptr) ? part_pos : -1);
+        return;
+    } else {
+    // PERSIST: this block's items of the attempt -- entries blockIdx.x, blockIdx.x + gridDim.x, ... of the work list, or of
+    // all tiles in the XCD-aware order of the one-attempt launch (a block stays on its XCD: gridDim.x is a multiple of 8)
+    {
+        const bool from_list = sparse && work != nullptr;
+        const int n_loop = from_list ? n_items : 8 * per;
+        for (int e = (int)blockIdx.x; e < n_loop; e += (int)gridDim.x) {
+            const int lg = from_list ? (e == (int)blockIdx.x ? w_entry : ld_fresh(work + e)) : (e % 8) * per + e / 8;
+            if (lg < nb) do_tile(lg, from_list ? e : -1);
+            __syncthreads();            // (the next tile, or the tail, reuses the tile buffers and the reduction's words)
+        }
+    }
+    if (!persist_barrier()) return;
+    }
+  }
 }
 
 // Dense output + direction field for every t_eval point of one accepted step, in one pass: the quartic
@@ -2280,8 +2769,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     if (!h->hjb_tsteps) OC_HIP_CHECK(hipMalloc((void**)&h->hjb_tsteps, sizeof(double) * T_CAP));
     if (!h->hjb_log) OC_HIP_CHECK(hipMalloc((void**)&h->hjb_log, sizeof(int32_t) * LOG_CAP));
     if (!h->hjb_tail) {
-        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_tail, TAIL_COUNTER_BYTES));
-        OC_HIP_CHECK(hipMemset(h->hjb_tail, 0, TAIL_COUNTER_BYTES));
+        OC_HIP_CHECK(hipMalloc((void**)&h->hjb_tail, TAIL_COUNTER_BYTES + 64));     // (+ the persistent launch's two words)
+        OC_HIP_CHECK(hipMemset(h->hjb_tail, 0, TAIL_COUNTER_BYTES + 64));
     }
     static_assert(sizeof(HjbCtl<T>) <= 2048, "controller block too large");
     // two controller blocks: attempt a reads ctlb[a & 1], its controller leaves the next attempt's in ctlb[(a + 1) & 1]
@@ -2491,6 +2980,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     const double FUSED_MAX = h->hjb_tail_fuse == 2 ? 1e18 : (double)TAIL_FLAT_MAX;
     const bool can_fuse = ring != nullptr && !sh && h->hjb_tail_fuse != 0;
     SA.tail_counter = h->hjb_tail;
+    SA.tail_rec = (can_fuse && h->hjb_tail_fast != 0) ? h->red_partial + 2 * (size_t)h->red_blocks : nullptr;
     SA.t_steps = h->hjb_tsteps;
     SA.att_log = h->hjb_log;
     SA.t_cap = T_CAP;
@@ -2605,8 +3095,109 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         ++enq;
         return OC_OK;
     };
-    const int BURST = sh ? 8 : 4, LAG = 6;
+    const int BURST = sh ? 8 : 4, LAG = 8;     // (the fused tail posts its tick count every 4th attempt)
     bool done = false;
+    // ---- the persistent launch (hjb_persist): the attempts of a ring solve inside ONE launch of a co-resident grid
+    // (k_stageV<.., PERSIST>), attempt after attempt, instead of one launch each.  The first attempt of an active-set solve
+    // (every tile is looked at once, no list yet) goes through the launch chain, the persistent launch takes over from
+    // attempt 1 and hands back (dense mode, a list that outgrew it, the deadline of a grid that turned out not to be
+    // co-resident) with the controller between two attempts: the chain below continues there.
+    // MEASURED (round 4, C4 2048 x 2048, ~25 listed tiles per attempt, profiles/r04_hjb_persist_stamps.txt): an attempt of the
+    // persistent launch takes 18.4 us -- controller block re-read 1.1, one tile's trip 7.5, release + ticket 0.9, tail 7.7,
+    // publication 0.5, the waiting blocks' wake-up 0.8 -- against 17.5 us in the launch chain: on this chip back-to-back
+    // launches of one stream overlap their dispatch with the previous launch's end (~0.5 us between two attempts), and the
+    // in-kernel barrier (write-back of the L2 for the other XCDs, ticket round trip, publication, poll, invalidation) costs
+    // more than that.  It pays only where every tile has its own block and no list is kept: grids of a few dozen tiles
+    // (room_test 200 x 200, 433 attempts: 6.85 against 7.10 ms per solve).  hjb_persist = 1 (default): those grids only;
+    // 2: wherever the launch can run; 0: never.
+    stats.persist_exit = 0;
+    double persist_ms = 0.0;            // profiling: the persistent launch's time and the attempts it ran
+    int persist_n = 0;
+    if (can_fuse && h->hjb_persist != 0 && !(prof_on && (h->prof_mode & 16))) {
+        const void* kfn = (const void*)k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true, true, true>;
+        int& cap = sizeof(T) == 4 ? h->persist_cap_f32 : h->persist_cap_f64;
+        if (cap < 0) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, OC_ST_RWV * OC_ST_RH, 0) != hipSuccess) per_cu = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 0;
+            cap = std::max(per_cu, 0) * std::max(cus, 0);
+        }
+        const int want = h->hjb_persist_blocks > 0 ? h->hjb_persist_blocks : 128;  // (half the CUs: two keys solved concurrently both fit)
+        const int G = oc_persist_reserve(std::min(want, active_set ? nb3 : 8 * ((nb3 + 7) / 8)), cap);
+        // (without the active set every attempt computes every tile: worth it while a block carries at most two)
+        const bool p_ok = h->hjb_persist == 2 ? (active_set || nb3 <= 2 * G) : (!active_set && nb3 <= G);
+        if (G >= 8 && p_ok) {
+            if (active_set && (rc = enqueue_attempt())) {
+                oc_persist_release(G);
+                return rc;
+            }
+            int32_t* const psync = h->hjb_tail + TAIL_COUNTER_BYTES / 4;     // (two words behind the ticket counters)
+            int32_t* const psync_host = (int32_t*)((char*)h->hjb_ctl_host + 2048);
+            psync_host[0] = enq;
+            psync_host[1] = 0;
+            OC_HIP_CHECK(hipMemcpyAsync(psync, psync_host, 8, hipMemcpyHostToDevice, s));
+            SA.p_ctl[0] = ctlb[0];
+            SA.p_ctl[1] = ctlb[1];
+            SA.p_flags = active_set ? h->hjb_flags : nullptr;
+            SA.p_sync = psync;
+            SA.p_a0 = enq;
+            SA.p_amax = LOG_CAP - 2 * BURST;
+            SA.p_max_items = 2 * G;
+            SA.p_wait_ticks = (int32_t)std::min<int64_t>((int64_t)h->hjb_persist_wait_us * 100, 2000000000);
+            SA.p_stamps = nullptr;
+#ifdef OC_DIAG_BUILD
+            const char* stamp_file = getenv("OC_PERSIST_STAMPS");
+            const size_t stamp_bytes = sizeof(unsigned long long) * 16 * 4096;
+            if (stamp_file) {
+                OC_HIP_CHECK(hipMalloc((void**)&SA.p_stamps, stamp_bytes));
+                OC_HIP_CHECK(hipMemsetAsync(SA.p_stamps, 0, stamp_bytes, s));
+                SA.p_amax = std::min(SA.p_amax, 4096);
+            }
+#endif
+            hipEvent_t pe0 = nullptr, pe1 = nullptr;
+            if (prof_on) pe0 = event();
+            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true, true, true>), dim3(G), dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
+            if (prof_on) pe1 = event();
+            HjbCtl<T> hc2[2];
+            OC_HIP_CHECK(hipMemcpyAsync(&hc2[0], ctlb[0], sizeof(hc), hipMemcpyDeviceToHost, s));
+            OC_HIP_CHECK(hipMemcpyAsync(&hc2[1], ctlb[1], sizeof(hc), hipMemcpyDeviceToHost, s));
+            OC_HIP_CHECK(hipMemcpyAsync(psync_host, psync, 8, hipMemcpyDeviceToHost, s));
+            const hipError_t pse = hipStreamSynchronize(s);
+            oc_persist_release(G);
+            OC_HIP_CHECK(pse);
+#ifdef OC_DIAG_BUILD
+            if (SA.p_stamps) {
+                std::vector<unsigned long long> st(16 * 4096);
+                OC_HIP_CHECK(hipMemcpy(st.data(), SA.p_stamps, stamp_bytes, hipMemcpyDeviceToHost));
+                if (FILE* f = fopen(stamp_file, "wb")) {
+                    fwrite(st.data(), 1, stamp_bytes, f);
+                    fclose(f);
+                }
+                (void)hipFree(SA.p_stamps);
+                SA.p_stamps = nullptr;
+            }
+#endif
+            const HjbCtl<T>& last = hc2[0].ticks >= hc2[1].ticks ? hc2[0] : hc2[1];
+            const int a0 = enq;
+            enq = std::max((int)last.ticks, a0);        // attempts whose controller has run: the chain continues with this one
+            done = last.done != 0;
+            stats.persist_attempts = enq - a0;
+            stats.persist_blocks = G;
+            stats.persist_exit = done ? 1 : (psync_host[1] != 0 ? 3 : 2);
+            // (a launch that was given up leaves tickets behind)
+            OC_HIP_CHECK(hipMemsetAsync(h->hjb_tail, 0, TAIL_COUNTER_BYTES, s));
+            if (prof_on && enq > a0) {
+                float e = 0.f;
+                (void)hipEventElapsedTime(&e, pe0, pe1);
+                persist_ms = e;
+                persist_n = enq - a0;
+            }
+            ev_used = 0;        // (the chain's bookkeeping expects groups of four events per profiled attempt)
+            ev_attempt.clear();
+        } else if (G > 0) {
+            oc_persist_release(G);
+        }
+    }
     while (!done) {
         for (int b = 0; b < BURST; ++b)
             if ((rc = enqueue_attempt())) return rc;
@@ -2695,6 +3286,15 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     if (prof_on) {
         oc_timer& ts = h->timers["hjb_stage"];
         oc_timer& to = h->timers["hjb_out"];
+        if (persist_n > 0) {            // the persistent launch's attempts: one "stage launch" each, priced like the others
+            const double share = active_set && n_real > 0 ? std::min(1.0, hc.act_sum / ((double)n_real * nb3)) : 1.0;
+            ts.add_ms += persist_ms;
+            ts.add_n += persist_n;
+            ts.bytes += 10.0 * sizeof(T) * (double)n * share * persist_n;
+            oc_timer& tp = h->timers["hjb_persist"];
+            tp.add_ms += persist_ms;
+            tp.add_n += persist_n;
+        }
         for (size_t g = 0; g < ev_attempt.size() && 4 * g + 3 < ev_used; ++g) {
             const int a = ev_attempt[g];
             if ((size_t)a >= log.size()) break;

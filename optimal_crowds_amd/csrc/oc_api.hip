@@ -53,7 +53,7 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
         h->axes_linspace = is_linspace(X0_host, cfg->Nx, cfg->room_length) && is_linspace(Y0_host, cfg->Ny, cfg->room_height);
     }
     h->red_blocks = std::max(1024, ((cfg->Nx + 31) / 32) * ((cfg->Ny + 15) / 16));
-    OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * 2 * h->red_blocks));
+    OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * (2 * (size_t)h->red_blocks + 4 * 128)));     // (+ the fused tail's records: hjb.hip TAIL_REC_CAP)
     OC_HIP_CHECK(hipMalloc(&h->red_out, sizeof(double) * 16));
     OC_HIP_CHECK(hipHostMalloc(&h->red_host, sizeof(double) * (2 * OC_MAX_WORLD + 8), hipHostMallocMapped));
     memset(h->red_host, 0, sizeof(double) * (2 * OC_MAX_WORLD + 8));
@@ -271,9 +271,10 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     if (!strcmp(name, "lazy_state")) {
         OC_REQUIRE(value == 0 || value == 1, "lazy_state must be 0 or 1");
         if (value == 0 && h->state_dirty) {     // (back to "every step leaves the arrays current": make them so now)
-            int rcf = oc_flush_state(h, nullptr);
+            const hipStream_t fs = h->dirty_stream;      // (the stream of the step that left the snapshot)
+            int rcf = oc_flush_state(h, fs);
             if (rcf) return rcf;
-            OC_HIP_CHECK(hipStreamSynchronize(nullptr));
+            OC_HIP_CHECK(hipStreamSynchronize(fs));
         }
         h->lazy_state = value;
     } else if (!strcmp(name, "pair_split")) {
@@ -306,6 +307,18 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     } else if (!strcmp(name, "hjb_subst")) {
         OC_REQUIRE(value >= 0 && value <= 1, "hjb_subst out of range");
         h->hjb_subst = (int)value;
+    } else if (!strcmp(name, "hjb_tail_fast")) {
+        OC_REQUIRE(value >= 0 && value <= 1, "hjb_tail_fast must be 0 or 1");
+        h->hjb_tail_fast = value;
+    } else if (!strcmp(name, "hjb_persist")) {
+        OC_REQUIRE(value >= 0 && value <= 2, "hjb_persist must be 0, 1 or 2");
+        h->hjb_persist = value;
+    } else if (!strcmp(name, "hjb_persist_blocks")) {
+        OC_REQUIRE(value >= 0 && value <= 4096, "hjb_persist_blocks out of range");
+        h->hjb_persist_blocks = value;
+    } else if (!strcmp(name, "hjb_persist_wait_us")) {
+        OC_REQUIRE(value >= 10 && value <= 10000000, "hjb_persist_wait_us out of range");
+        h->hjb_persist_wait_us = value;
     } else if (!strcmp(name, "hjb_tail")) {
         OC_REQUIRE(value >= 0 && value <= 2, "hjb_tail out of range");
         h->hjb_tail_fuse = value;

@@ -175,6 +175,12 @@ struct oc_handle {
     int32_t* hjb_tail = nullptr;     // ticket counter of the fused tail (hjb.hip: k_stageV<.., FUSED>)
     int hjb_subst = 1;               // ring solves with the active set: far-field substitution (Stage3Args::undef) on / off
     int hjb_tail_fuse = 1;           // 1: ring solves run controller + list builder inside the stage launch when few blocks take part
+    int hjb_tail_fast = 1;           // 1: the fused tail reads short work lists by list position (hjb.hip: TailRec) instead of every tile's words
+    int hjb_persist = 1;             // the attempts of a ring solve inside ONE persistent launch (hjb.hip: k_stageV<.., PERSIST>): 0 never,
+                                     // 1 grids of a few dozen tiles (where it measures faster), 2 wherever it can run
+    int hjb_persist_blocks = 0;      // its grid (0: 128 blocks, half the CUs -- two keys solved concurrently both fit)
+    int hjb_persist_wait_us = 50000; // deadline of a block's wait at the in-kernel barrier (a grid that is not co-resident gives up)
+    int persist_cap_f32 = -1, persist_cap_f64 = -1;     // block slots of the chip for that kernel (occupancy x CUs), -1: not asked yet
     int32_t* hjb_flags = nullptr;    // active-set flags of the stage tiles, two attempts (hjb.hip: k_stageV)
     size_t hjb_flags_n = 0;
     // ---- per-key data
@@ -197,6 +203,8 @@ struct oc_handle {
     int lazy_state = 0;         // 1: oc_gcfm_step leaves the caller's state arrays to k_flush_state (oc_set_tuning "lazy_state")
     bool state_dirty = false;   // the caller's x / y / vx / vy / agent_time are behind the packed snapshot (flush_state)
     oc_agents dirty_agents;     // ... namely these arrays
+    hipStream_t dirty_stream = nullptr;     // ... left behind by a step on this stream (a flush that is not ordered by the
+                                            // caller's stream -- reallocation, oc_set_tuning -- runs there)
     bool wprev_valid = false;   // the wall searches' incumbents (gcfm.hip: Scratch::wprev) belong to the packed agents
     int wall_warm = 1;          // 1: a wall search starts from the cell the previous step found (oc_set_tuning "wall_warm")
     bool packed_seq = false;    // the snapshot has only been advanced by sequential steps since its re-sort

@@ -39,6 +39,10 @@ def hjb_state_dtype(cfg, T, requested="float32"):
     return "float32" if bits - 64.0 <= 118.0 else "mixed"
 
 
+class _RingTooSmall(Exception):
+    """a lane's solve ran out of ring slots (OC_ERR_CAPACITY): solve_keys grows the ring in the caller's thread"""
+
+
 class _Field:
     """Direction field of one key, indexed like the list it replaces: [0], [1] = vx, vy as (nslice, rows, Nx) device
     tensors, [2] = allocated slices, [3] = current horizon nt_opt.  In 'ring' mode the key holds an interpolant ring
@@ -487,7 +491,8 @@ class Engine:
         kp = keep_arr.ctypes.data_as(C.c_void_p) if keep_arr is not None else None
         tp = tsteps.ctypes.data_as(C.c_void_p) if cap else None
         if f.is_ring:
-            f.vx = f.vy = None                      # (a materialised copy of the previous solve)
+            if lane is None:
+                f.vx = f.vy = None                  # (a materialised copy of the previous solve; a lane's caller did this)
             ring = self._ring(key, T)
             while True:
                 rcode = self.lib.oc_hjb_solve_ring(h, self.solve_dtype, _ptr(coef), float(T), int(nt),
@@ -495,6 +500,8 @@ class Engine:
                                                    C.byref(stats), self.stream())
                 if rcode != OC_ERR_CAPACITY:
                     break
+                if lane is not None:                # a lane thread allocates and frees nothing: the caller's thread grows
+                    raise _RingTooSmall(key)        # the ring under ITS stream and solves the key again (solve_keys)
                 ring = self._ring(key, T, grow=True)        # more accepted steps than slots: a larger ring, again
             check(rcode)
         else:
@@ -550,11 +557,14 @@ class Engine:
             if m is not None and id(m) not in on_dev:
                 on_dev[id(m)] = m.to(device=self.device, dtype=self.tdtype).contiguous()
             if self.fields[key].is_ring:
+                self.fields[key].vx = self.fields[key].vy = None    # (a materialised copy of the previous solve)
                 self._ring(key, T)
         jobs = [(key, T, nt, on_dev.get(id(m), m) if m is not None else None) for key, T, nt, m in jobs]
         ready = torch.cuda.Event()
         ready.record(main)                  # the potentials, the density and the last steps' lookups of the old rings
         errs = [None] * n_lanes
+        regrow = []                         # keys whose ring was too small (OC_ERR_CAPACITY in a lane): redone below
+        lane0 = dict(h=self.h, coef=self.coef)      # (lane 0 = this handle on the caller's stream, under the lanes' rule)
 
         def work(li):
             try:
@@ -566,7 +576,10 @@ class Engine:
                         st.wait_event(ready)
                     for q in par[li::n_lanes]:
                         key, T, nt, m = jobs[q]
-                        out[q] = self._solve_whole(key, T, nt, m, None, False, ln)[0]
+                        try:
+                            out[q] = self._solve_whole(key, T, nt, m, None, False, ln if ln is not None else lane0)[0]
+                        except _RingTooSmall:
+                            regrow.append(q)
             except BaseException as e:      # noqa: BLE001  (re-raised by the caller's thread)
                 errs[li] = e
         th = [threading.Thread(target=work, args=(li,)) for li in range(1, n_lanes)]
@@ -578,6 +591,10 @@ class Engine:
         for e in errs:
             if e is not None:
                 raise e
+        for q in sorted(regrow):            # by the caller's thread on the caller's stream: the larger ring belongs to its pool
+            key, T, nt, m = jobs[q]
+            self._ring(key, T, grow=True)
+            out[q] = self._solve_whole(key, T, nt, m, None, False, None)[0]
         # (every solve call returned after its stream had drained: whatever follows on the caller's stream is ordered
         # behind all of them by the host)
         for q in par:
@@ -654,6 +671,12 @@ class Engine:
         N = len(x)
         mk = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         st = np.ones(N, dtype=np.uint8) if status is None else np.ascontiguousarray(status, dtype=np.uint8)
+        # lazy_state: the library may still owe the OLD tensors a flush (state_dirty + raw pointers to them).  Pay it while
+        # they are alive, then drop the pending state -- a later flush would write into blocks the allocator has handed on.
+        if getattr(self, "agents", None) is not None:
+            self.flush_state()
+            check(self.lib.oc_agents_sync(self.h, self.stream()))
+        check(self.lib.oc_agents_changed(self.h))
         self._state_behind = False
         self.agents = _AgentState(
             self, N=N, x=mk(x), y=mk(y), vx=mk(vx), vy=mk(vy), v_des=mk(v_des),

@@ -378,15 +378,26 @@ def native_comm(eng, slot, group=None, ranks=None):
         dist.broadcast_object_list(box, src=ranks[0], group=group)
     from ._lib import check
     buf = (C_.c_ubyte * 128).from_buffer_copy(box[0])
-    check(eng.lib.oc_comm_create(eng.h, int(slot), buf, ranks.index(me), len(ranks)))
+    rc = eng.lib.oc_comm_create(eng.h, int(slot), buf, ranks.index(me), len(ranks))
+    if rc != 0 and len(ranks) > 1:
+        # ncclCommInitRank is a collective: the other members are blocked inside it and no agreement can be reached any more.
+        # End the job loudly (the launcher tears the other ranks down) instead of raising here and leaving them waiting.
+        import os
+        import sys
+        sys.stderr.write("optimal_crowds_amd.parallel: rank %d could not create the library's RCCL communicator for ranks %s "
+                         "(error %d: %s) -- aborting the job\n"
+                         % (me, ranks, rc, eng.lib.oc_last_error().decode(errors="replace")))
+        sys.stderr.flush()
+        os._exit(70)
+    check(rc)
     return int(slot)
 
 
 def _rccl_usable(eng):
-    """can liboc_hip bind librccl in this process? (oc_comm_unique_id dlopens it and draws an id)"""
-    import ctypes as C_
+    """can liboc_hip bind librccl in this process? (oc_comm_available: dlopen + symbols -- no unique id is drawn: each
+    ncclGetUniqueId starts a bootstrap listener that is never joined)"""
     try:
-        return eng.lib.oc_comm_unique_id((C_.c_ubyte * 128)()) == 0
+        return eng.lib.oc_comm_available() == 0
     except Exception:       # noqa: BLE001
         return False
 

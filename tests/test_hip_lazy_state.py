@@ -63,3 +63,30 @@ def test_lazy_state_equals_the_scatter_in_every_step():
     assert np.isfinite(fin["x"]).all() and fin["agent_time"].max() == pytest.approx(78 * 0.02)
     gone = ~sb[-1]["status"].astype(bool)
     assert 50 < gone.sum() <= eb and (sb[-1]["agent_time"][gone] < 71 * 0.02 + 1e-12).all()     # (their clocks stopped)
+
+
+def test_replacing_the_agents_after_a_lazy_step_writes_nowhere_else():
+    """A lazy step leaves the library owing the caller's arrays a flush (raw pointers to them).  Replacing the agent set
+    (Engine.set_agents, a different N) must pay or drop that debt BEFORE the old tensors are released: a later flush into
+    freed blocks lands in whatever the caching allocator handed them to next (advisor finding, round 3)."""
+    import torch
+    eng = _fresh(True)
+    for s in range(3):
+        eng.step(s, noise=None, seed=5, sync=False)
+    old = eng.get_state()                                               # (synchronises: what the old arrays must end up as)
+    for s in range(3, 5):
+        eng.step(s, noise=None, seed=5, sync=False)                     # ... and the debt is back
+    n_old = eng.agents["N"]
+    # a smaller crowd: the old tensors are released by set_agents; grab the allocator's blocks right away with canaries
+    x = np.linspace(20.0, 30.0, 1000); y = np.full(1000, 25.0)
+    eng.set_agents(x, y, np.zeros(1000), np.zeros(1000), np.full(1000, 1.3), np.zeros(1000, dtype=np.int32))
+    canaries = [torch.full((n_old,), 7.25, dtype=torch.float64, device=eng.device) for _ in range(12)]
+    eng.step(5, noise=None, seed=5)
+    eng.step(6, noise=None, seed=5)
+    new = eng.get_state()
+    torch.cuda.synchronize()
+    for c in canaries:
+        assert bool((c == 7.25).all()), "a flush of the replaced agent set wrote into reallocated memory"
+    assert new["x"].shape == (1000,) and np.isfinite(new["x"]).all() and np.allclose(new["y"], 25.0, atol=0.2)
+    assert old["x"].shape == (n_old,)
+    eng.close()

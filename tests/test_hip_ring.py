@@ -266,6 +266,38 @@ def test_concurrent_key_solves_equal_one_after_the_other(dtype, with_m):
         assert np.array_equal(da, db) and ea == eb
 
 
+def test_concurrent_key_solves_grow_a_ring_that_is_too_small_in_the_callers_thread():
+    """A lane thread of Engine.solve_keys allocates and frees nothing (its tensors would belong to the lane stream's pool while
+    the step kernels read them on the caller's stream): a ring that runs out of slots in a lane (OC_ERR_CAPACITY) is grown and
+    its key solved again by the CALLER's thread -- same statistics and slices as with rings that were large enough."""
+    import torch
+    from optimal_crowds_amd.engine import Engine
+    cfg, room, Nx, Ny, X0, Y0, _ = _setup("gold_b", 0.05)
+    X, Y = np.meshgrid(X0, Y0)
+    names = list(room["targets"].keys())
+    Vs = [oc.finalize_potential(oc.create_potential(room, ks, X, Y), cfg) for ks in ([names[0]], [names[-1]])]
+    T, nt = 3.0, 150
+    res = []
+    for tiny in (False, True):
+        eng = Engine(cfg, room["room_length"], room["room_height"], Nx, Ny, X0, Y0, len(Vs), 4096, dtype="float32")
+        for k, V in enumerate(Vs):
+            eng.set_potential(k, V, np.zeros((0, 4)))
+            eng.alloc_field(k, nt - 1)
+            if tiny:
+                eng.make_ring(k, 2)                     # (both lanes -- the caller's own and the auxiliary one -- run out)
+        stats = eng.solve_keys([(k, T, nt, None) for k in range(len(Vs))])
+        if tiny:
+            assert all(eng.fields[k].ring["slots"] >= stats[k]["n_accept"] > 2 for k in range(len(Vs)))
+        res.append((stats, [tuple(t.cpu().numpy() for t in eng.ring_slices(k, 0, nt - 1)) for k in range(len(Vs))]))
+        eng.close()
+    (sa, fa), (sb, fb) = res
+    for x, y in zip(sa, sb):
+        for name in ("nfev", "n_attempt", "n_accept", "h_abs0", "h_min", "h_max"):
+            assert x[name] == y[name], name
+    for k in range(len(Vs)):
+        assert np.array_equal(fa[k][0], fb[k][0]) and np.array_equal(fa[k][1], fb[k][1])
+
+
 @pytest.mark.parametrize("active", [0, 2])
 def test_tail_variants_make_the_same_decisions(active):
     """oc_set_tuning "hjb_tail": 0 = stage launch + k_control (+ k_list), 1 = the attempt's last block is its controller
@@ -299,6 +331,50 @@ def test_tail_variants_make_the_same_decisions(active):
         assert torch.equal(phi, phi0)
         for (d0, e0), (d1, e1) in zip(look0, look):
             assert e0 == e1 and np.array_equal(d0, d1)
+
+
+@pytest.mark.parametrize("room_name,gs,active,T,nt", [("room_test", 0.05, 0, 20.0, 1000), ("metro_station", 0.1, 2, 6.0, 300),
+                                                      ("exit_opposite", 0.1, 2, 20.0, 1000)])
+def test_persistent_launch_and_fast_tail_make_the_same_decisions(room_name, gs, active, T, nt):
+    """oc_set_tuning "hjb_persist" = 2: the attempts of a ring solve inside ONE launch of a co-resident grid (k_stageV<..,
+    PERSIST>: items dealt to the blocks, ticket barrier, the last arrival runs controller and list builder, the others wait for
+    the generation word) -- and "hjb_tail_fast" = 0 / 1: the fused tail reading every tile's words or the listed tiles' records.
+    All of them leave the ring, the statistics and the lookups of the launch chain, bit for bit; a barrier deadline that
+    passes at once (hjb_persist_wait_us = 10) makes the launch give up and the chain finish the solve -- with the same bits.
+    room_test: no active set, one tile per block, rescales and rejected attempts over T = 20; metro_station: active set, short
+    lists (the fast tail's range); exit_opposite with the active set forced: lists beyond the fast tail's range, blocks
+    that carry two tiles."""
+    import torch
+    setup = _setup(room_name, gs)
+    cfg, room, Nx, Ny, X0, Y0, V = setup
+    res = {}
+    variants = {"chain": dict(hjb_persist=0, hjb_tail_fast=0), "chain+fast": dict(hjb_persist=0, hjb_tail_fast=1),
+                "persist": dict(hjb_persist=2, hjb_tail_fast=0), "persist+fast": dict(hjb_persist=2, hjb_tail_fast=1),
+                "deadline": dict(hjb_persist=2, hjb_tail_fast=1, hjb_persist_wait_us=10)}
+    for name, knobs in variants.items():
+        eng = _engine(setup, "float32", "ring")
+        eng.set_tuning("hjb_active", active)
+        for k, v in knobs.items():
+            eng.set_tuning(k, v)
+        eng.alloc_field(0, nt - 1)
+        st, phi = eng.solve(0, T, nt, keep=[0, nt // 3, nt - 1], want_steps=True)
+        _probe_agents(eng, room, 2000, 11)
+        look = _lookups(eng, [0, 1, nt // 2, nt - 2])
+        res[name] = (st, phi.cpu(), look)
+        eng.close()
+        del eng
+    st0, phi0, look0 = res["chain"]
+    assert st0["n_accept"] > 10 and st0["persist_exit"] == 0
+    assert res["persist"][0]["persist_exit"] in (1, 2) and res["persist"][0]["persist_attempts"] > 10
+    assert res["deadline"][0]["persist_exit"] in (1, 2, 3)
+    for name in variants:
+        st, phi, look = res[name]
+        for k in ("nfev", "n_attempt", "n_accept", "n_rescale", "final_exponent", "h_abs0", "h_min", "h_max"):
+            assert st[k] == st0[k], (name, k, st[k], st0[k])
+        assert np.array_equal(st["t_steps"], st0["t_steps"]), name
+        assert torch.equal(phi, phi0), name
+        for (d0, e0), (d1, e1) in zip(look0, look):
+            assert e0 == e1 and np.array_equal(d0, d1), name
 
 
 @pytest.mark.parametrize("room_name,gs,dtype,with_m", [("room_test", 0.05, "float32", False), ("slalom", 0.1, "float32", False),
