@@ -312,7 +312,9 @@ def measure(sim, args, nt, world, dist, red_dev, keep_state=False, levels=None):
     if W > 0:
         run_steps(sim, W, nt, update=upd)
     barrier()
-    eng.set_profiling(1 | 4)        # HJB kernels on every 8th attempt, GCFM kernels on every 16th step (events cost gaps)
+    # HJB kernels on every 8th attempt; GCFM kernels on every 16th step -- every 4th in a short region (the driver's --steps 20:
+    # 5 samples instead of 1): event records cost gaps, so a long run samples sparsely
+    eng.set_profiling(1 | (8 if K <= 64 else 4))
     eng.reset_kernel_stats()
     stats = []
     state0 = eng.get_state() if keep_state else None        # the crowd the timed region starts from (CPU baseline's input)
@@ -445,7 +447,7 @@ def main():
     first = mine[0] if mine else None
     ring = any(f is not None and f.is_ring for f in eng.fields)
     kstats = {}
-    for name in ("hjb_out", "hjb_stage", "hjb_list", "gcfm_forces", "gcfm_finish", "density"):
+    for name in ("hjb_out", "hjb_stage", "hjb_list", "hjb_persist", "gcfm_forces", "gcfm_finish", "density"):
         nl, ms, by = eng.kernel_stats(name)
         kstats[name] = {"launches_timed": nl, "avg_ms": (ms / nl if nl else None),
                         "designed_GB_per_launch": (by / nl / 1e9 if nl else None),
@@ -454,13 +456,18 @@ def main():
     # every 8th attempt, the step's every 16th step; the launch counts are exact)
     n_att = sum(s_["n_attempt"] for s_ in mine)
     n_acc = sum(s_["n_accept"] for s_ in mine)
-    launches = {"gcfm_forces": K, "gcfm_finish": K, "hjb_stage": n_att, "hjb_list": n_att if ring else 0,
+    # (the list builder is a launch of its own only where a ring solve's attempt is NOT fused -- lists beyond the flat ticket's
+    # range before the solve goes dense: none at the BASELINE rooms; with the fused tail it runs inside the stage launch)
+    launches = {"gcfm_forces": K, "gcfm_finish": K, "hjb_stage": n_att,
                 "hjb_out": 0 if ring else n_acc, "density": max(len(stats) - max(1, -(-K // nt)), 0) if sim.recompute else 0}
+    kstats.pop("hjb_list", None)
+    kp = kstats.pop("hjb_persist")
+    n_persist = sum(s_.get("persist_attempts", 0) for s_ in mine)
     for name, n_l in launches.items():
         kstats[name]["launches_in_timed_region"] = n_l
         kstats[name]["est_total_ms"] = (kstats[name]["avg_ms"] or 0.0) * n_l
     # (the controller / list-builder launches and k_finish are latency-sized helpers: reported, never "the" kernel)
-    dominant = max((n_ for n_ in launches if n_ not in ("hjb_list", "gcfm_finish")), key=lambda n_: kstats[n_]["est_total_ms"])
+    dominant = max((n_ for n_ in launches if n_ != "gcfm_finish"), key=lambda n_: kstats[n_]["est_total_ms"])
     kf = kstats["gcfm_forces"]
     gw = None
     if rank == 0 and kf.get("avg_ms") and not args.no_work_count and not sharded:
@@ -538,6 +545,19 @@ def main():
                        else "ensemble of %d replicas, one per GPU" % world)
     kn = kstats["gcfm_finish"]
     kernel_step_ms = (kf["avg_ms"] + kn["avg_ms"]) if kf["avg_ms"] and kn["avg_ms"] else None
+    # the complete run (one solve round of all keys + nt steps) from this region's own parts -- the wall time of
+    # its solve rounds and the step kernels' event times (the steps of a short region drain behind the host: their wall time
+    # is not separable) -- so that a --steps 20 record carries the figure a --steps 1000 run measures directly
+    projected = None
+    if kernel_step_ms and stats and not sim.recompute:
+        rounds = [max(s_["seconds"] for s_ in rnd if s_ is not None) for rnd in stats if any(s_ is not None for s_ in rnd)]
+        if rounds:
+            t_round = float(np.mean(rounds))
+            projected = {"steps_per_s": nt / (t_round + nt * kernel_step_ms * 1e-3), "t_solve_round_s": t_round,
+                         "t_step_kernels_s": kernel_step_ms * 1e-3, "nt": nt,
+                         "formula": "nt / (t_solve_round + nt * t_step_kernels); t_solve_round = the longest key's library time per "
+                                    "round (keys are solved concurrently), t_step_kernels = k_forces + k_finish event times; the "
+                                    "re-sort every 32 steps (~0.1 ms) is not included"}
     result = {
         "metric": "sim steps/sec (HJB sweep + GCFM update), %s %d^2 grid x %d agents" % (args.workload, sim.Nx, sim.N),
         "value": (1 if sharded or world == 1 else world) * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K,
@@ -570,6 +590,12 @@ def main():
                       "gcfm_kernel_ms_note": "k_forces + k_finish HIP-event times, sampled every 16th step (the steps are "
                                              "enqueued and drain behind later host work, so wall-clock differences do not "
                                              "isolate them)",
+                      "hjb_persistent_launch": {"attempts_inside": n_persist, "blocks": max((s_.get("persist_blocks", 0) for s_ in mine), default=0),
+                                                "exits": sorted(set(s_.get("persist_exit", 0) for s_ in mine)),
+                                                "avg_ms_per_attempt": kp["avg_ms"],
+                                                "note": "attempts that ran inside ONE co-resident launch (oc_set_tuning hjb_persist; "
+                                                        "default: grids of a few dozen tiles only -- csrc/hjb.hip)"},
+                      "projected_complete_run": projected,
                       "nfev": first["nfev"] if first else None, "rk_attempts": first["n_attempt"] if first else None,
                       "rk_accepted": first["n_accept"] if first else None, "kernels": kstats, "init_s": t_init,
                       "active_agents_end": int(eng.counters.cpu()[2]), "csrc_sha": csrc_hash()},

@@ -77,7 +77,8 @@ typedef struct oc_hjb_stats {
     /* the persistent launch (oc_set_tuning "hjb_persist"): attempts that ran inside it, its grid, and how it ended --
      * 0 not used, 1 the solve finished inside, 2 handed back to the launch chain (every tile active / list too long),
      * 3 given up at a barrier deadline (grid not co-resident); the chain continues from the controller's state either way */
-    int32_t persist_attempts, persist_blocks, persist_exit, reserved;
+    int32_t persist_attempts, persist_blocks, persist_exit;
+    int32_t grid_resyncs;         /* sparse attempts whose launch was too small for the work list (drained and re-enqueued) */
 } oc_hjb_stats;
 
 /* Replaces compute_optimal_velocity's solve_ivp(RK45, t_eval=linspace(T,0,nt)) + vels() fill loop,
@@ -161,6 +162,27 @@ typedef struct oc_hjb_ring {
 int64_t oc_hjb_ring_slot_elems(const oc_handle* h, int32_t rows);
 int64_t oc_hjb_ring_meta_bytes(const oc_handle* h, int dtype, int32_t slots, int32_t nslice, int32_t rows);
 int32_t oc_hjb_ring_slots_hint(const oc_handle* h, double T);
+/* Several independent whole-grid ring solves at the same time -- the reference solves its keys one after the other
+ * (simulations.py:419-420: `for key in self.targets: self.targets[key].compute_optimal_velocity(...)`); they share nothing.
+ * One job = oc_hjb_make_coef(h, coef_dtype, V, m, coef) + oc_hjb_solve_ring(h, dtype, coef, T, nt, ring, stats) on `stream`;
+ * every job needs its own handle (solver scratch), coef buffer and stream.  The library runs the jobs on host threads of its
+ * own (job 0 on the caller's) and returns when all have drained; rc / error / stats are per job.  Returns the first failing
+ * job's code. */
+typedef struct oc_hjb_ring_job {
+    oc_handle* h;
+    int32_t coef_dtype, dtype;      /* oc_hjb_make_coef's / oc_hjb_solve_ring's dtype */
+    const float* V;                 /* the key's finalised potential (Ny, Nx) */
+    const void* m;                  /* density term (Ny, Nx) of coef_dtype's element type, or NULL */
+    void* coef;                     /* (Ny, Nx) scratch of the job */
+    double T;
+    int32_t nt, rc;
+    const oc_hjb_ring* ring;
+    void* stream;
+    oc_hjb_stats stats;
+    char error[256];
+} oc_hjb_ring_job;
+int oc_hjb_solve_ring_many(oc_hjb_ring_job* jobs, int32_t n);
+
 /* oc_hjb_solve / oc_hjb_solve_rows with a ring in the place of vx_out / vy_out (same arguments otherwise; phi_keep is
  * produced from the ring after the solve). */
 int oc_hjb_solve_ring(oc_handle* h, int dtype, const void* coef, double T, int32_t nt, const oc_hjb_ring* ring,

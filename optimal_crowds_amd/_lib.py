@@ -39,7 +39,7 @@ class OcHjbStats(C.Structure):
         ("h_abs0", C.c_double), ("h_min", C.c_double), ("h_max", C.c_double),
         ("final_exponent", C.c_int32), ("n_slices_written", C.c_int32),
         ("seconds", C.c_double),
-        ("persist_attempts", C.c_int32), ("persist_blocks", C.c_int32), ("persist_exit", C.c_int32), ("reserved", C.c_int32),
+        ("persist_attempts", C.c_int32), ("persist_blocks", C.c_int32), ("persist_exit", C.c_int32), ("grid_resyncs", C.c_int32),
     ]
 
     def as_dict(self):
@@ -77,6 +77,13 @@ class OcHjbRing(C.Structure):
                 ("slots", C.c_int32), ("nslice", C.c_int32), ("rows", C.c_int32), ("reserved", C.c_int32)]
 
 
+class OcHjbRingJob(C.Structure):
+    """oc_hip.h: oc_hjb_ring_job -- one of several ring solves oc_hjb_solve_ring_many runs at the same time"""
+    _fields_ = [("h", C.c_void_p), ("coef_dtype", C.c_int32), ("dtype", C.c_int32), ("V", C.c_void_p), ("m", C.c_void_p),
+                ("coef", C.c_void_p), ("T", C.c_double), ("nt", C.c_int32), ("rc", C.c_int32),
+                ("ring", C.POINTER(OcHjbRing)), ("stream", C.c_void_p), ("stats", OcHjbStats), ("error", C.c_char * 256)]
+
+
 OC_ERR_CAPACITY = -5
 
 
@@ -108,6 +115,7 @@ SIGNATURES = {
     "oc_hjb_solve_ring": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int32, C.POINTER(OcHjbRing),
                                     C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                     C.POINTER(OcHjbStats), C.c_void_p]),
+    "oc_hjb_solve_ring_many": (C.c_int, [C.POINTER(OcHjbRingJob), C.c_int32]),
     "oc_hjb_solve_rows_ring": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int32, C.POINTER(OcHjbRing),
                                          C.POINTER(OcHjbShard), C.c_void_p, C.c_int32, C.c_void_p,
                                          C.POINTER(OcHjbStats), C.c_void_p]),

@@ -500,7 +500,14 @@ __device__ __forceinline__ void pair_term2(f2v Rx, f2v Ry, float vxi, float vyi,
     }
 }
 
+#ifndef OC_PAIR_WALK
+#define OC_PAIR_WALK 1          // phase 2 walks the candidate masks (pair_share); 0: round 3's compacted candidate list (A/B builds)
+#endif
 #define PAIR_LIST_CAP 1024      // list entries (two candidates of one agent each): 64 agents x 32 j always fit
+#ifndef OC_FORCES_OCC
+#define OC_FORCES_OCC 4         // k_forces: wavefronts per SIMD the register budget is set for (A/B builds)
+#endif
+#define PAIR_UNIT_CAP 132       // units of a virtual tile (64 lanes x 2 mask words) + the end marker
 #define PAIR_SPLIT_MAX 4
 
 struct JRec {                   // one lane's share of a staged j-tile (prefetched into registers)
@@ -518,12 +525,25 @@ struct PairLds {
     float4 li_vel[TPB][64];
     float4 li_aux[TPB][64];     // (hx, hy, 1/b_i^2, 1/v_des_i)
     double accx[TPB][64], accy[TPB][64];
+#if !OC_PAIR_WALK
     double2 l_pos[4][64];       // per wavefront: the staged virtual j-tile (64 records)
     float4 l_vel[4][64];
     float2 l_head[4][64];
+#endif
     alignas(16) float l_rx[4][64];
     alignas(16) float l_ry[4][64];
+#if OC_PAIR_WALK
+    uint2 l_unit[4][PAIR_UNIT_CAP];     // per wavefront: the virtual tile's units (mask word, running entry count << 8 | lane << 1 | word)
+    uint8_t l_start[4][64];             // ... and per lane the unit its share of the entries starts in
+    // the staged records once more, field by field: phase 2 reads the fields of TWO records (the entry's candidates) into the
+    // two halves of packed operands -- from an array of structures every field cost a register move on top of the wide load
+    // (30 moves per trip of 156 vector instructions), and two records' wide loads collide in the banks; field arrays give
+    // conflict-free 4-byte loads straight into the register pairs
+    double l_px[4][64], l_py[4][64];
+    float l_f[4][6][64];                // vx, vy, |v|, 1/a^2, hx, hy
+#else
     uint32_t list[4][PAIR_LIST_CAP];
+#endif
 };
 
 // the i-tile in LDS (in phase 2 any lane works on any agent) and zeroed force sums: one wavefront per tile
@@ -586,7 +606,9 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
     const float xi_f = (float)(pi.x - ox), yi_f = (float)(pi.y - oy);
     const f2v xi2 = {xi_f, xi_f}, yi2 = {yi_f, yi_f};
     const float my_speed = L.li_vel[tl][lane].z;
+#if !OC_PAIR_WALK
     uint32_t* lst = L.list[w];
+#endif
     int work = 0;                                   // list entries processed: the tile's measured work
     const int j0 = sub * NJ;                        // this share's records of a j-tile: j0 .. j0 + NJ - 1
     const int jl = lane & (NJ - 1);                 // lanes >= NJ duplicate the loads of lanes < NJ (same cache lines)
@@ -645,11 +667,22 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
         for (;;) {
             // ---- stage the virtual tile (registers -> wave-private LDS; LDS ops of one wavefront complete in order,
             // so the single buffer is safe: the previous tile's reads were issued before these writes)
+#if OC_PAIR_WALK
+            L.l_px[w][lane] = cur.pos.x;
+            L.l_py[w][lane] = cur.pos.y;
+            L.l_f[w][0][lane] = cur.vel.x;
+            L.l_f[w][1][lane] = cur.vel.y;
+            L.l_f[w][2][lane] = cur.vel.z;
+            L.l_f[w][3][lane] = cur.vel.w;
+            L.l_f[w][4][lane] = cur.head.x;
+            L.l_f[w][5][lane] = cur.head.y;
+#else
             L.l_pos[w][lane] = cur.pos;
-            L.l_rx[w][lane] = (float)(cur.pos.x - ox);
-            L.l_ry[w][lane] = (float)(cur.pos.y - oy);
             L.l_vel[w][lane] = cur.vel;
             L.l_head[w][lane] = cur.head;
+#endif
+            L.l_rx[w][lane] = (float)(cur.pos.x - ox);
+            L.l_ry[w][lane] = (float)(cur.pos.y - oy);
             const float extt = (ext + ext_i) * 1.0001f;
             const float c2f = (float)c2 * 1.00001f + 1e-6f * extt * (extt + (float)c);
             const f2v nc2 = {-c2f, -c2f};
@@ -706,6 +739,134 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
 #pragma unroll
                 for (int h = 0; h < NW; ++h) mw[h] = 0u;
             }
+#if OC_PAIR_WALK
+            // ---- phase 2 without a candidate list: the lanes WALK the masks.  (Round 3: the masks were turned into an LDS list of
+            // entries, every lane appending its own candidates -- a loop as long as the BUSIEST lane's count, 424 vector
+            // instructions per virtual tile of which 87 wrote entries: a fifth of the launch's instructions.)  A UNIT is one
+            // lane's mask word that has candidates; as before two candidates of a word make an entry (an odd last one is paired
+            // with itself, masked).  The units go to a wave-private table in lane order -- sorted by agent -- with the running
+            // entry count; every lane takes the same number R of consecutive ENTRIES: a binary search in the running counts
+            // finds the unit its share starts in, the entries of that unit that belong to the lane before it are dropped from
+            // the mask, and from there the lane takes two candidates off the current unit's mask per trip and moves on to the
+            // next unit when the mask is empty (fetched one unit ahead).  Same pairs, same agent order, same float64 sums.
+            {
+                uint32_t m0 = mw[0], m1 = mw[1];
+                if (OC_DIAG(P, 4u)) m0 = m1 = 0u;
+                const int c0 = (__popc(m0) + 1) >> 1, c1 = (__popc(m1) + 1) >> 1, cntl = c0 + c1;
+                const int incl = wave_incl_scan(cntl);
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                if (total != 0) {
+                    work += total;
+                    uint2* const ut = L.l_unit[w];
+                    const unsigned long long b0 = __ballot(m0 != 0u), b1 = __ballot(m1 != 0u);
+                    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                                      (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+                    const int nunit = __popcll(b0) + __popcll(b1);
+                    // unit: (mask, running entry count incl. this unit << 8 | lane << 1 | word)
+                    if (m0 != 0u) ut[below] = make_uint2(m0, ((uint32_t)(incl - c1) << 8) | ((uint32_t)lane << 1));
+                    if (m1 != 0u) ut[below + (m0 != 0u ? 1 : 0)] = make_uint2(m1, ((uint32_t)incl << 8) | ((uint32_t)lane << 1) | 1u);
+                    if (lane == 0) ut[nunit] = make_uint2(0u, (uint32_t)total << 8);      // (read ahead by the last unit's walker)
+                    const int R = (total + 63) >> 6;
+                    const int e_beg = lane * R, e_end = min(e_beg + R, total);
+                    // Where does lane L's share (entries L R ...) start?  The unit that holds entry L R tells L: a unit with
+                    // entries [a, b) is the start of the lanes ceil(a / R) .. ceil(b / R) - 1 (at most 17 of them, 2 - 4 as a
+                    // rule) -- a short scatter by the units' owners where a binary search in the running counts cost every
+                    // lane seven dependent LDS reads.  (x / R for x <= 2111, R <= 32 as (x m) >> 16, m = ceil(2^16 / R): exact.)
+                    {
+                        const uint32_t mg = (65536u + (uint32_t)R - 1u) / (uint32_t)R;         // (wave-uniform)
+                        uint8_t* const stt = L.l_start[w];
+                        const int a0 = incl - cntl, a1 = incl - c1, a2 = incl;      // word 0: [a0, a1), word 1: [a1, a2)
+                        const int f0 = (int)(((uint32_t)(a0 + R - 1) * mg) >> 16), f1 = (int)(((uint32_t)(a1 + R - 1) * mg) >> 16),
+                                  f2 = (int)(((uint32_t)(a2 + R - 1) * mg) >> 16);
+                        for (int q = f0; q < min(f1, 64); ++q) stt[q] = (uint8_t)below;
+                        const int below1 = below + (m0 != 0u ? 1 : 0);
+                        for (int q = f1; q < min(f2, 64); ++q) stt[q] = (uint8_t)below1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    int u = e_beg < total ? (int)L.l_start[w][lane] : nunit;
+                    uint2 cur = ut[min(u, nunit)];
+                    uint2 nxt = ut[min(u + 1, nunit)];
+                    uint32_t m = e_beg < total ? cur.x : 0u;
+                    uint32_t id = cur.y & 255u;
+                    {   // the unit's entries that lie before the share: two candidates each, off the mask's top
+                        int k = e_beg < total ? e_beg - ((int)(cur.y >> 8) - ((__popc(m) + 1) >> 1)) : 0;
+                        while (k > 0) {
+                            m &= ~(0x80000000u >> __clz((int)m));
+                            m &= ~(0x80000000u >> __clz((int)m));
+                            --k;
+                        }
+                    }
+                    int il_cur = -1;
+                    double2 pa = make_double2(0.0, 0.0);
+                    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), aux = va;
+                    // the share's sums are float64: every pair's float32 force is added exactly, so the result does not
+                    // depend on how the launch shape (pair_split, share boundaries) groups the pairs
+                    double sfx = 0.0, sfy = 0.0;
+                    for (int tt = e_beg; tt < (OC_DIAG(P, 1u) ? e_beg : e_end); ++tt) {
+                        if (m == 0u) {                          // the unit is used up: the next one (non-empty by construction)
+                            m = nxt.x;
+                            id = nxt.y & 255u;
+                            ++u;
+                            nxt = ut[min(u + 1, nunit)];
+                        }
+                        const int il = (int)(id >> 1), jb = (int)(id & 1u) << 5;
+                        const int q1 = __clz((int)m);
+                        m &= ~(0x80000000u >> q1);
+                        const bool two = m != 0u;
+                        const int q2 = two ? __clz((int)m) : q1;
+                        m &= ~(0x80000000u >> q2);
+                        const int jA = jb + q1, jB = jb + q2;
+                        const double2 pbA = make_double2(L.l_px[w][jA], L.l_py[w][jA]), pbB = make_double2(L.l_px[w][jB], L.l_py[w][jB]);
+                        const float4 vbA = make_float4(L.l_f[w][0][jA], L.l_f[w][1][jA], L.l_f[w][2][jA], L.l_f[w][3][jA]),
+                                     vbB = make_float4(L.l_f[w][0][jB], L.l_f[w][1][jB], L.l_f[w][2][jB], L.l_f[w][3][jB]);
+                        const float2 hbA = make_float2(L.l_f[w][4][jA], L.l_f[w][5][jA]), hbB = make_float2(L.l_f[w][4][jB], L.l_f[w][5][jB]);
+                        if (il != il_cur) {
+                            if (il_cur >= 0) {
+                                atomicAdd(&L.accx[tl][il_cur], sfx);
+                                atomicAdd(&L.accy[tl][il_cur], sfy);
+                            }
+                            il_cur = il;
+                            sfx = sfy = 0.0;
+                            pa = L.li_pos[tl][il];
+                            va = L.li_vel[tl][il];
+                            aux = L.li_aux[tl][il];
+                        }
+                        const double dxA = pbA.x - pa.x, dyA = pbA.y - pa.y, dxB = pbB.x - pa.x, dyB = pbB.y - pa.y;
+                        // the reference's decision sqrt(d2) < cutoff (pedestrians.py:352-356, simulations.py:291) from the
+                        // float32 square of the float64-differenced vector wherever that cannot be wrong (it is good to
+                        // 3e-7 relative); the exact float64 comparison decides inside the band.  Coincident agents (d2 = 0:
+                        // NaN in the reference) are skipped (deviation D1).
+                        const f2v Rx = {(float)dxA, (float)dxB}, Ry = {(float)dyA, (float)dyB};
+                        const f2v r2f = __builtin_elementwise_fma(Rx, Rx, Ry * Ry);
+                        bool okA = r2f.x < c2lo, okB = r2f.y < c2lo;
+                        if ((!okA && r2f.x < c2hi) || (!okB && r2f.y < c2hi)) {         // (rare: |d - cutoff| < 4e-6 m)
+                            okA = okA || dxA * dxA + dyA * dyA <= P.cut_d2max;
+                            okB = okB || dxB * dxB + dyB * dyB <= P.cut_d2max;
+                        }
+                        okA = okA && r2f.x > 0.f;
+                        okB = okB && two && r2f.y > 0.f;
+                        if (okA || okB) {
+                            f2v fx, fy;
+                            pair_term2(Rx, Ry, va.x, va.y, va.z, aux.x,
+                                       aux.y, va.w, aux.z, aux.w, (f2v){vbA.x, vbB.x}, (f2v){vbA.y, vbB.y},
+                                       (f2v){vbA.z, vbB.z}, (f2v){vbA.w, vbB.w}, (f2v){hbA.x, hbB.x}, (f2v){hbA.y, hbB.y},
+                                       b_max, db, neg_inv_eta_log2e, unit_dir, fx, fy, okA, okB);
+                            sfx += (double)fx.x + (double)fx.y;
+                            sfy += (double)fy.x + (double)fy.y;
+                        }
+                    }
+                    if (il_cur >= 0) {
+                        atomicAdd(&L.accx[tl][il_cur], sfx);
+                        atomicAdd(&L.accy[tl][il_cur], sfy);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+#else
             // list entries hold TWO candidates of one agent (an odd last one is paired with itself, masked).  Dense
             // tile pairs do not fit the list: rounds of 32 j each (64 agents x 16 entries = PAIR_LIST_CAP always fit)
             // (whether the rounds are needed is known from the first pass's own prefix sum: no separate reduction)
@@ -813,6 +974,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+#endif
             if (!more) break;
         }
     }
@@ -1467,7 +1629,7 @@ struct TileShare {              // which tiles this launch works on (the whole s
 // CU resident.
 // FIX = false: the OC_FIX_* corrections are compiled out (the default, bug-compatible kernel pays nothing for them)
 template <int NS, bool FIX>
-__global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
+__global__ void __launch_bounds__(256, OC_FORCES_OCC) k_forces(GcfmParams P, Scratch S, const KeyDev* __restrict__ keys,
                                                 const KeyStep* __restrict__ ksteps, int step, const Axis X0, const Axis Y0,
                                                 int nprep, TileShare sh, int32_t* __restrict__ cnt_out) {
     __shared__ PairLds<NS> L;
@@ -1490,6 +1652,11 @@ __global__ void __launch_bounds__(256, 4) k_forces(GcfmParams P, Scratch S, cons
         }
         return;
     }
+    // (Round 4, measured and not kept: PERSISTENT pair blocks -- as many as the chip holds at once, each drawing tile after tile
+    // from a counter, heaviest first -- to close the half-empty second "generation" of blocks at the launch's end: 110 us
+    // against 80.  A tile takes ~42 us on a CU that holds four pair blocks and ~25 us on one that holds fewer: the launch is
+    // bound by what a CU gets done, ~10 us of CU time per tile, not by how the blocks are packed; the queue keeps every CU
+    // full to the end, where the one-block-per-tile launch lets the last blocks run on emptier CUs.)
     const int tl = w / NS, sub = w % NS, ord = ((int)blockIdx.x - nprep) * (4 / NS) + tl;
     const bool live = ord < sh.hi - sh.lo;
     // heavy tiles first: the launch ends with its slowest wavefront

@@ -12,6 +12,8 @@
 #include <atomic>
 #include <cmath>
 #include <chrono>
+#include <cstring>
+#include <thread>
 
 namespace {
 
@@ -1163,6 +1165,7 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     // stamps [0..5] = attempt entered, controller block read, items done, ticket drawn, tail done, generation stored,
     // [6] = its blockIdx, [7] = the attempt's items; [8..15] the same of block 0 (tools/persist_stamps.py)
     unsigned long long* p_stamps;
+    int32_t att_expected;           // one-attempt launches: the attempt number (controller ticks) this launch was enqueued for, or -1
     // fused tail, short lists: 4 doubles per list position (error share, max |y_new|, tile | flag << 32, spare) written by the
     // block that takes the position (TAIL_REC_CAP of them), or NULL
     double* tail_rec;
@@ -1323,9 +1326,13 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
     const int Ny = A.Ny, Nx = A.Nx;
     const int nbx = (Nx + TX - 1) / TX, nby = (Ny + TY - 1) / TY, nb = nbx * nby;
     const int per = (nb + 7) / 8;
-    int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);              // XCD-aware order (tile_of_block)
+    // this block's position among the launch's blocks in the XCD-aware order (tile_of_block; gridDim.x is a multiple of 8): the
+    // tile of that number, or the entry of that number of the work list -- and, where the launch has fewer blocks than the
+    // attempt has items (the host sizes a sparse attempt's grid by the list length it last saw), every gridDim.x-th one after it
+    const int per_g = (int)gridDim.x / 8;
+    const int logical = PERSIST ? 0 : (int)(blockIdx.x % 8) * per_g + (int)(blockIdx.x / 8);
     const bool listed = NQ == 6 && flags_cur != nullptr && work != nullptr;
-    int c_done, par, c_dense, c_wcount, c_nacc, c_rej, w_entry;
+    int c_done, par, c_dense, c_wcount, c_nacc, c_rej, w_entry, c_ticks = 0;
     T c_oiscale, c_ubg, atol_s, in_scale;
     T cc[NQ][6], he[7];
     if (PERSIST) {
@@ -1364,7 +1371,7 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
         for (int j = 0; j < 7; ++j) he[j] = (T)0;
     } else {
         c_done = ctl->done; par = ctl->parity; c_dense = ctl->dense_mode; c_wcount = ctl->work_count;
-        c_nacc = ctl->n_accept; c_rej = ctl->rejected;
+        c_nacc = ctl->n_accept; c_rej = ctl->rejected; c_ticks = ctl->ticks;
         c_oiscale = ctl->out_in_scale; c_ubg = ctl->u_bg;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
@@ -1377,7 +1384,7 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
         for (int j = 0; j < 7; ++j) he[j] = FINAL ? ctl->he[j] : (T)0;
         atol_s = ctl->atol_s; in_scale = ctl->in_scale;
         w_entry = listed ? work[min(logical, nb - 1)] : 0;      // (read before it is known to be needed: in bounds)
-        asm volatile("" ::SB(c_done), SB(par), SB(c_dense), SB(c_wcount), SB(c_nacc), SB(c_rej), SB(w_entry), SB(c_oiscale), SB(c_ubg),
+        asm volatile("" ::SB(c_done), SB(par), SB(c_dense), SB(c_wcount), SB(c_nacc), SB(c_rej), SB(c_ticks), SB(w_entry), SB(c_oiscale), SB(c_ubg),
                      SB(atol_s), SB(in_scale), SB(cc[0][0]), SB(cc[NQ / 2 - 1][5]), SB(cc[NQ / 2][0]), SB(cc[NQ - 1][5]), SB(he[0]),
                      SB(he[6]), SB(A.coef), SB(flags_prev));
     }
@@ -1387,7 +1394,6 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
     if (!PERSIST) asm volatile("" ::SB(y), SB(kin[0]));   // (the two pointers picked by the parity: in registers before the loads
                                                     // below are issued, or a late scalar load would wait for all of those)
     T* ynew = A.Y[par ^ 1];
-    if (!PERSIST && ((int)(blockIdx.x / 8) >= per || logical >= nb)) return;
     const bool sparse = NQ == 6 && flags_cur != nullptr && c_dense == 0;
     // PERSIST: the launch is for sparse attempts -- once every tile is active, or the list outgrows what this grid should
     // carry, the launch chain takes over (the controller block is between two attempts: every block reads the same words)
@@ -1396,7 +1402,23 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
     // blocks that take part in the attempt (the others have returned above or do so just below): what the tail waits for
     // (PERSIST: the blocks that have an item -- the others neither draw a ticket nor poll eagerly: they look in on the
     // generation word now and then and take part again when the list has grown to reach them)
-    const int n_part = PERSIST ? min((sparse && work != nullptr) ? n_items : 8 * per, (int)gridDim.x) : n_items;
+    const int n_part = min(PERSIST && !(sparse && work != nullptr) ? 8 * per : n_items, (int)gridDim.x);
+    if constexpr (!PERSIST) {
+        // The host sizes a sparse attempt's grid by the list length it last saw and enqueues attempts ahead of the device.  A
+        // launch that finds itself too small for the attempt's items does NOTHING -- no tile, no ticket, no controller -- but
+        // say so in the mailbox; the launches enqueued behind it find a controller block that is not theirs (ticks !=
+        // att_expected) and do nothing either; the host drains the stream and goes on from the controller's state with a
+        // grid that fits (hjb_solve_dev).  (Never seen in practice: the list grows by a tile every few attempts.)
+        if (A.att_expected >= 0 && c_ticks != A.att_expected) return;
+        if (n_items > (int)gridDim.x) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                A.mailbox[1] = (double)n_items;
+                A.mailbox[2] = (double)(c_ticks + 1);
+            }
+            return;
+        }
+        if (logical >= n_items) return;             // no item for this block
+    }
     // PERSIST: wait for the attempt's tail (generation > att) -- with a deadline; false: the launch is given up
     auto wait_gen = [&](const int nap) __attribute__((always_inline)) -> bool {
         if (threadIdx.x == 0) {
@@ -1603,10 +1625,6 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
         }
         return wait_gen(0);
     };
-    if (!PERSIST && sparse && work != nullptr) {    // active set: entry `logical` of the work list, or nothing to do
-        if (logical >= c_wcount) return;
-        logical = w_entry;
-    }
     // the attempt's coefficients where a stage needs them (PERSIST: out of the block's LDS copy of the controller block)
     auto coef_of = [&](int q, int j) __attribute__((always_inline)) -> T {
         if constexpr (PERSIST) return uni(q < 3 ? s_tail.c.cA[q][j] : s_tail.c.cB[q - 3][j]);
@@ -1782,7 +1800,6 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
                 put_rec(e_pos, logical, 0.0, um, 1);
                 if (subst) A.undef[(size_t)(par ^ 1) * nb + logical] = 1;      // (read by later attempts only)
             }
-            if constexpr (FUSED && !PERSIST) fused_tail();
             return;
         }
         if (threadIdx.x == 0) {
@@ -1934,14 +1951,18 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
                 put_rec(e_pos, logical, a, b, 0);
             }
         }
-        if constexpr (FUSED && !PERSIST) {
-            __syncthreads();            // (the tail reuses the tile buffers and the reduction's LDS words)
-            fused_tail();
-        }
     }
     };      // do_tile
     if constexpr (!PERSIST) {
-        do_tile(logical, (sparse && work != nullptr) ? part_pos : -1);
+        // this block's item: position `logical` of the work list, or tile `logical` (NO loop over further items here: with a
+        // loop around it the tile code's invariants are hoisted and spilled -- 20 % on the whole solve; a launch too small
+        // for its list does nothing and says so: att_expected above)
+        const bool from_list = sparse && work != nullptr;
+        do_tile(from_list ? w_entry : logical, from_list ? logical : -1);
+        if constexpr (FUSED) {
+            __syncthreads();            // (the tail reuses the tile buffers and the reduction's LDS words)
+            fused_tail();
+        }
         return;
     } else {
     // PERSIST: this block's items of the attempt -- entries blockIdx.x, blockIdx.x + gridDim.x, ... of the work list, or of
@@ -2868,9 +2889,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     OC_HIP_CHECK(hipMemsetAsync(h->hjb_tail, 0, TAIL_COUNTER_BYTES, s));   // (a solve that failed half-way may have left tickets)
     if (dev_init)
         hipLaunchKernelGGL(k_init_step<T>, dim3(1), dim3(64), 0, s, ctl, h->red_out, 1, n_rms, std::fabs(tf - t0));
-    volatile double* mb = h->red_host + 2 * OC_MAX_WORLD + 4;      // [0] ticks + 2^32 * done (k_control), [1] listed tiles
-    mb[0] = 0.0;
+    volatile double* mb = h->red_host + 2 * OC_MAX_WORLD + 4;      // [0] ticks + 2^32 * done (k_control), [1] listed tiles,
+    mb[0] = 0.0;                                                   // [2] 1 + ticks of an attempt whose launch was too small
     mb[1] = 1e9;
+    mb[2] = 0.0;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     double* mb_dev = (double*)h->red_mailbox_dev + 4;
 
@@ -2997,29 +3019,33 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // known only afterwards (att_log), so the sums are formed after the solve
     // (an event record between two kernels costs 3-6 us of stream time: every 8th attempt is timed, the averages are the same)
     const bool prof_on = h->profiling && (h->prof_mode & 1);
-    const int PROF_EVERY = 8;
+    const int PROF_EVERY = 16;
     std::vector<hipEvent_t>& ev = h->hjb_events;
     size_t ev_used = 0;
-    auto event = [&]() -> hipEvent_t {
+    auto event = [&](bool record = true) -> hipEvent_t {       // (record = false: the group's slot is taken, nothing is enqueued)
         if (ev_used == ev.size()) {
             hipEvent_t e;
             (void)hipEventCreate(&e);
             ev.push_back(e);
         }
         hipEvent_t e = ev[ev_used++];
-        (void)hipEventRecord(e, s);
+        if (record) (void)hipEventRecord(e, s);
         return e;
     };
     int enq = 0;
+    int grid_floor = 8;                             // blocks a sparse attempt's launch has at least (raised when one was too small)
     std::vector<int> ev_attempt;                   // attempt index of every group of 4 events
+    std::vector<char> ev_list;                     // ... and whether the group's second interval holds a k_list launch
     auto enqueue_attempt = [&]() -> int {
         const bool prof = prof_on && (enq % PROF_EVERY == 0);
         if (prof) ev_attempt.push_back(enq);
+        if (prof) ev_list.push_back(0);
         if (prof) event();
         HjbCtl<T>* const ctl_cur = ctlb[enq & 1];
         HjbCtl<T>* const ctl_nxt = ctlb[(enq + 1) & 1];
         SA.ctl = ctl_cur;
         SA.ctl_out = ctl_nxt;
+        SA.att_expected = enq;
         OA.ctl = ctl_nxt;                               // (k_out / the list builder act on the controller's decision)
         if (active_set) {
             SA.flags_cur = h->hjb_flags + (size_t)(enq & 1) * nb3;
@@ -3037,7 +3063,15 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         const double seen = active_set ? (enq > 0 ? (double)mb[1] : (double)nb3) : (double)nb3;
         const bool fused = can_fuse && seen <= FUSED_MAX;
         if (ring && fused) {
-            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true, true>), grid3, dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
+            // a sparse attempt's grid follows the list: the blocks beyond it would be dispatched -- 16 wavefronts and 40 KB of
+            // LDS each -- only to return at once (1957 of them per attempt at 2048 x 2048 for ~25 listed tiles).  Any size is
+            // correct (a block takes every gridDim.x-th item); this one leaves room for the list to grow until the host sees it.
+            dim3 gridf = grid3;
+            if (active_set && enq > 0 && h->hjb_grid_fit != 0) {
+                const int want = std::max((int)(seen * 1.5) + h->hjb_grid_margin, grid_floor);
+                gridf = dim3(std::min(8u * (unsigned)((std::max(want, 8) + 7) / 8), grid3.x));
+            }
+            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true, true>), gridf, dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
         } else if (ring) {
             hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true>), grid3, dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
         } else if (fuse == 0) {
@@ -3081,17 +3115,20 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             hipLaunchKernelGGL((k_halo_stage<T, false>), gh, dim3(256), 0, s, (const HjbCtl<T>*)ctl_nxt, Y[0], Y[1], KX[0], KX[1],
                                (T*)sh->recv_up, (T*)sh->recv_dn, lo, hi, hn, sh->has_up, sh->has_dn);
         }
-        if (prof) event();
+        // (the group's second interval -- k_out, or the list builder's own launch -- is bracketed only where such a launch follows)
+        const bool second = !ring || (active_set && !fused && seen != (double)nb3 + 0.5);
+        if (prof) event(second);
         if (!ring) {
             launch_out<T, TO, true>(h->out_tile, S.Nx, S.Ny, s, OA);
         } else if (active_set && !fused && seen != (double)nb3 + 0.5) {
+            if (prof) ev_list.back() = 1;
             // no slice writer beside which the list could be built: its own (one-block) launch -- until the device has
             // posted dense_mode (every tile active for the rest of the solve: C5's re-solves under the crowd's density,
             // 2 200 launches of ~5 us per run that did nothing)
             hipLaunchKernelGGL(k_list<T>, dim3(1), dim3(256), 0, s, ctl_nxt, (const int32_t*)OA.flags, OA.flags_next, OA.work,
                                OA.parts_rw, (S.Nx + tx - 1) / tx, (S.Ny + ty - 1) / ty, (volatile double*)mb_dev, SA.undef);
         }
-        if (prof) event();
+        if (prof) event(second);
         ++enq;
         return OC_OK;
     };
@@ -3194,6 +3231,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             }
             ev_used = 0;        // (the chain's bookkeeping expects groups of four events per profiled attempt)
             ev_attempt.clear();
+            ev_list.clear();
         } else if (G > 0) {
             oc_persist_release(G);
         }
@@ -3214,7 +3252,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             auto t_seen = std::chrono::steady_clock::now();
             for (long spin = 0;; ++spin) {
                 const double w = mb[0];
-                if (w >= 4294967296.0 || w >= (double)(enq - LAG)) break;
+                if (w >= 4294967296.0 || w >= (double)(enq - LAG) || mb[2] != 0.0) break;
                 if ((spin & 4095) == 4095) {            // drained (mailbox not visible?) or failed: never spin on a dead stream
                     const hipError_t q = hipStreamQuery(s);
                     if (q == hipSuccess) break;
@@ -3238,6 +3276,21 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (mb[2] != 0.0) {
+            // a sparse attempt's launch was too small for its list (k_stageV: att_expected): it and everything enqueued
+            // behind it did nothing.  Drain, take the attempt number from the controller blocks, go on with grids that fit.
+            OC_HIP_CHECK(hipStreamSynchronize(s));
+            HjbCtl<T> two[2];
+            OC_HIP_CHECK(hipMemcpy(&two[0], ctlb[0], sizeof(hc), hipMemcpyDeviceToHost));
+            OC_HIP_CHECK(hipMemcpy(&two[1], ctlb[1], sizeof(hc), hipMemcpyDeviceToHost));
+            enq = std::max(two[0].ticks, two[1].ticks);
+            grid_floor = std::max(grid_floor, (int)mb[1]);
+            ++stats.grid_resyncs;
+            mb[2] = 0.0;
+            __atomic_thread_fence(__ATOMIC_SEQ_CST);
+            OC_HIP_CHECK(hipMemsetAsync(h->hjb_tail, 0, TAIL_COUNTER_BYTES, s));
+            continue;
+        }
         done = mb[0] >= 4294967296.0;
         if (!done && hipStreamQuery(s) == hipSuccess && mb[0] < (double)enq) {
             // the stream drained but the mailbox did not move: mapped memory is not visible -> read the device copy
@@ -3300,7 +3353,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             if ((size_t)a >= log.size()) break;
             float e1 = 0.f, e2 = 0.f;
             (void)hipEventElapsedTime(&e1, ev[4 * g], ev[4 * g + 1]);
-            (void)hipEventElapsedTime(&e2, ev[4 * g + 2], ev[4 * g + 3]);
+            // (the second interval was bracketed only where a launch followed: k_out, or the list builder's own)
+            if (!ring || (g < ev_list.size() && ev_list[g])) (void)hipEventElapsedTime(&e2, ev[4 * g + 2], ev[4 * g + 3]);
             // (active set: the state arrays are only moved on the non-trivial tiles -- priced with the solve's mean share
             // of tiles that had an error contribution; the direction field is written in full either way)
             const double share = active_set && n_real > 0 ? std::min(1.0, hc.act_sum / ((double)n_real * nb3)) : 1.0;
@@ -3309,8 +3363,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                 ts.add_n += 1;
                 ts.bytes += (ring ? 10.0 : (fuse == 0 ? 8.0 : 17.0)) * sizeof(T) * (double)n * share;    // ring: 3 read, 7 written
             }
-            if (ring) {                 // (the second interval is the list builder's launch)
-                if (log[a] & 1) {
+            if (ring) {                 // (the second interval is the list builder's launch, where there was one)
+                if ((log[a] & 1) && g < ev_list.size() && ev_list[g]) {
                     oc_timer& tl = h->timers["hjb_list"];
                     tl.add_ms += e2;
                     tl.add_n += 1;
@@ -3837,6 +3891,39 @@ extern "C" int oc_hjb_solve_ring(oc_handle* h, int dtype, const void* coef, doub
         if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     return rc;
+}
+
+// Several independent whole-grid ring solves at the same time (the reference solves its keys one after the other,
+// simulations.py:419-420; they share nothing): one host thread per job INSIDE the library -- job 0 on the caller's -- so that
+// nothing of the interpreter lies between the solves' launches (threads started from Python cost 0.3 - 0.7 ms per round of
+// two 2 ms solves: thread start and join, the calls around the solve).  Every job needs its own handle (solver scratch) and
+// stream.  Returns the first job's error code that is not OC_OK (each job's own is in jobs[i].rc, its message in .error).
+extern "C" int oc_hjb_solve_ring_many(oc_hjb_ring_job* jobs, int32_t n) {
+    OC_REQUIRE(jobs != nullptr && n >= 1 && n <= 64, "bad job list");
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) OC_REQUIRE(jobs[i].h != jobs[j].h, "two jobs on one handle (each needs its own solver scratch)");
+    auto run = [](oc_hjb_ring_job* jb) {
+        jb->error[0] = 0;
+        jb->rc = oc_hjb_make_coef(jb->h, jb->coef_dtype, jb->V, jb->m, jb->coef, jb->stream);
+        if (jb->rc == OC_OK)
+            jb->rc = oc_hjb_solve_ring(jb->h, jb->dtype, jb->coef, jb->T, jb->nt, jb->ring, nullptr, 0, nullptr, nullptr, 0, &jb->stats,
+                                       jb->stream);
+        if (jb->rc != OC_OK) {
+            strncpy(jb->error, oc_last_error(), sizeof(jb->error) - 1);
+            jb->error[sizeof(jb->error) - 1] = 0;
+        }
+    };
+    std::vector<std::thread> th;
+    th.reserve(n > 1 ? n - 1 : 0);
+    for (int i = 1; i < n; ++i) th.emplace_back(run, jobs + i);
+    run(jobs);
+    for (auto& t : th) t.join();
+    for (int i = 0; i < n; ++i)
+        if (jobs[i].rc != OC_OK) {
+            oc_set_error("job %d: %s", i, jobs[i].error);
+            return jobs[i].rc;
+        }
+    return OC_OK;
 }
 
 extern "C" int oc_hjb_solve_rows_ring(oc_handle* h, int dtype, const void* coef_rows, double T, int32_t nt,

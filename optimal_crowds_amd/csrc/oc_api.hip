@@ -113,12 +113,14 @@ extern "C" int oc_set_profiling(oc_handle* h, int mode) {
     return OC_OK;
 }
 
-// mode bits: 1 = HJB kernels, 2 = GCFM kernels every step, 4 = GCFM kernels every 16th step (event records
-// between the 2 launches of a step cost ~14 us of a 144 us step, so the bench samples them)
+// mode bits: 1 = HJB kernels, 2 = GCFM kernels every step, 4 = GCFM kernels every 16th step, 8 = every 4th step (event
+// records between the 2 launches of a step cost ~14 us of a 144 us step, so the bench samples them), 16 = HJB: no persistent
+// launch (every attempt is a launch of its own and can be bracketed)
 static bool timer_on(oc_handle* h, const char* name) {
     if (!h->profiling) return false;
     if (name[0] == 'h' || name[0] == 'd') return (h->prof_mode & 1) != 0;     // HJB kernels, density
     if (h->prof_mode & 2) return true;
+    if ((h->prof_mode & 8) && (h->prof_tick % 4 == 0)) return true;
     return (h->prof_mode & 4) && (h->prof_tick % 16 == 0);
 }
 
@@ -307,6 +309,12 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     } else if (!strcmp(name, "hjb_subst")) {
         OC_REQUIRE(value >= 0 && value <= 1, "hjb_subst out of range");
         h->hjb_subst = (int)value;
+    } else if (!strcmp(name, "hjb_grid_fit")) {
+        OC_REQUIRE(value >= 0 && value <= 1, "hjb_grid_fit must be 0 or 1");
+        h->hjb_grid_fit = value;
+    } else if (!strcmp(name, "hjb_grid_margin")) {
+        OC_REQUIRE(value >= -100000 && value <= 100000, "hjb_grid_margin out of range");
+        h->hjb_grid_margin = value;
     } else if (!strcmp(name, "hjb_tail_fast")) {
         OC_REQUIRE(value >= 0 && value <= 1, "hjb_tail_fast must be 0 or 1");
         h->hjb_tail_fast = value;

@@ -10,14 +10,13 @@ Buffers in HBM (row-major, N agents, K keys, grid Ny x Nx, nt0 = round(T/dt)):
 """
 import ctypes as C
 import os
-import threading
 
 import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (FIX_BITS, OC_ERR_CAPACITY, OC_F32, OC_F64, OC_F64_F32, OcAgents, OcConfig, OcHjbRing, OcHjbStats,
-                   check)
+from ._lib import (FIX_BITS, OC_ERR_CAPACITY, OC_F32, OC_F64, OC_F64_F32, OcAgents, OcConfig, OcError, OcHjbRing, OcHjbRingJob,
+                   OcHjbStats, check)
 
 LIM = 10e-3          # reference optimals.py:95
 
@@ -533,13 +532,14 @@ class Engine:
         """Solve several keys: jobs = [(key, T, nt, m), ...] -> list of stats (None for a key another rank group holds).
         The reference solves its keys one after the other (simulations.py:419-420, 432-435); the solves are independent,
         and with the interpolant ring and the exact active set one of them is a chain of ~100 short, latency-bound
-        launches that leaves most of the chip idle -- so keys whose whole grid lives on this GPU are solved CONCURRENTLY,
-        each on its own handle and stream from its own host thread (the library call is synchronous; ctypes releases the
-        GIL).  Same kernels, same arithmetic, same results as solve() key by key (tests/test_hip_ring.py).
-        OC_OVERLAP_SOLVES=0 / overlap_solves = False: one after the other."""
+        launches that leaves most of the chip idle -- so keys whose whole grid lives on this GPU (ring fields) are solved
+        CONCURRENTLY, each on its own handle and stream, by ONE library call per round of `max_lanes` keys
+        (oc_hjb_solve_ring_many: the host threads are the library's).  Same kernels, same arithmetic, same results as
+        solve() key by key (tests/test_hip_ring.py).  OC_OVERLAP_SOLVES=0 / overlap_solves = False: one after the other."""
         jobs = list(jobs)
         par = [q for q, (key, T, nt, m) in enumerate(jobs)
-               if self.holds_key(key) and self._key_rows(key) is None and nt - 1 <= self.fields[key].nslice]
+               if self.holds_key(key) and self._key_rows(key) is None and nt - 1 <= self.fields[key].nslice
+               and self.fields[key].is_ring]
         if not self.overlap_solves or len(par) < 2:
             return [self.solve(key, T, nt, m=m)[0] for key, T, nt, m in jobs]
         out = [None] * len(jobs)
@@ -562,35 +562,39 @@ class Engine:
         jobs = [(key, T, nt, on_dev.get(id(m), m) if m is not None else None) for key, T, nt, m in jobs]
         ready = torch.cuda.Event()
         ready.record(main)                  # the potentials, the density and the last steps' lookups of the old rings
-        errs = [None] * n_lanes
         regrow = []                         # keys whose ring was too small (OC_ERR_CAPACITY in a lane): redone below
-        lane0 = dict(h=self.h, coef=self.coef)      # (lane 0 = this handle on the caller's stream, under the lanes' rule)
-
-        def work(li):
-            try:
-                torch.cuda.set_device(self.device)
+        # ONE library call per round of n_lanes keys (oc_hjb_solve_ring_many): the library runs the jobs on host threads of its
+        # own -- nothing of the interpreter lies between the solves' launches (threads started from here cost 0.3 - 0.7 ms per
+        # round of two 2 ms solves).  Lane 0 = this handle on the caller's stream.
+        for r0 in range(0, len(par), n_lanes):
+            batch = par[r0:r0 + n_lanes]
+            arr = (OcHjbRingJob * len(batch))()
+            keep_alive = []
+            for li, q in enumerate(batch):
+                key, T, nt, m = jobs[q]
                 ln = lanes[li]
                 st = main if ln is None else ln["stream"]
-                with torch.cuda.stream(st):
-                    if ln is not None:
-                        st.wait_event(ready)
-                    for q in par[li::n_lanes]:
-                        key, T, nt, m = jobs[q]
-                        try:
-                            out[q] = self._solve_whole(key, T, nt, m, None, False, ln if ln is not None else lane0)[0]
-                        except _RingTooSmall:
-                            regrow.append(q)
-            except BaseException as e:      # noqa: BLE001  (re-raised by the caller's thread)
-                errs[li] = e
-        th = [threading.Thread(target=work, args=(li,)) for li in range(1, n_lanes)]
-        for t in th:
-            t.start()
-        work(0)
-        for t in th:
-            t.join()
-        for e in errs:
-            if e is not None:
-                raise e
+                if ln is not None:
+                    st.wait_event(ready)
+                jb = arr[li]
+                jb.h = (self.h if ln is None else ln["h"]).value
+                jb.coef_dtype, jb.dtype = self.dtype, self.solve_dtype
+                jb.V = self.V[key].data_ptr()
+                jb.m = m.data_ptr() if m is not None else None
+                jb.coef = (self.coef if ln is None else ln["coef"]).data_ptr()
+                jb.T, jb.nt = float(T), int(nt)
+                jb.ring = C.pointer(self.fields[key].ring["struct"])
+                jb.stream = st.cuda_stream
+                keep_alive.append(m)
+            rcode = self.lib.oc_hjb_solve_ring_many(arr, len(batch))
+            for li, q in enumerate(batch):
+                if arr[li].rc == OC_ERR_CAPACITY:
+                    regrow.append(q)
+                elif arr[li].rc != 0:
+                    raise OcError("liboc_hip: error %d: %s" % (arr[li].rc, arr[li].error.decode(errors="replace")))
+                else:
+                    out[q] = arr[li].stats.as_dict()
+            del rcode
         for q in sorted(regrow):            # by the caller's thread on the caller's stream: the larger ring belongs to its pool
             key, T, nt, m = jobs[q]
             self._ring(key, T, grow=True)

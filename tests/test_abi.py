@@ -38,14 +38,15 @@ def test_struct_layout_matches_header():
     import tempfile
     from optimal_crowds_amd import _lib
     src = ('#include <stdio.h>\n#include "oc_hip.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(oc_config), '
-           'sizeof(oc_hjb_stats), sizeof(oc_agents));return 0;}\n')
+           'sizeof(oc_hjb_stats), sizeof(oc_agents));printf("%zu %zu\\n", sizeof(oc_hjb_ring_job), sizeof(oc_hjb_ring));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    assert sizes == [ctypes.sizeof(_lib.OcConfig), ctypes.sizeof(_lib.OcHjbStats), ctypes.sizeof(_lib.OcAgents)]
+    assert sizes == [ctypes.sizeof(_lib.OcConfig), ctypes.sizeof(_lib.OcHjbStats), ctypes.sizeof(_lib.OcAgents),
+                     ctypes.sizeof(_lib.OcHjbRingJob), ctypes.sizeof(_lib.OcHjbRing)]
 
 
 def test_no_gpu_fails_loudly(lib):
