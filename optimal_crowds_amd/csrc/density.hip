@@ -13,9 +13,12 @@ namespace {
 
 struct DensParams {
     int32_t Ny, Nx;
-    double cell;
+    double cell;                // side of the coarse cells the agents are ordered by (a third of the truncation radius)
+    double rcut;                // truncation radius trunc_sigmas * sigma: a tile sums the agents of the cells that meet tile +- rcut
     int32_t ncx, ncy;
     double inv2s2, invC;
+    double hx, hy, kx, ky;      // grid steps and exp(-h^2 / sigma^2): the Gaussian's factors along a grid line by recurrence
+    int32_t recur, pad;         // 1: the axes are equally spaced (np.linspace): recurrence; 0: a true exponential per factor
 };
 
 __global__ void k_dens_keys(const double* __restrict__ x, const double* __restrict__ y,
@@ -56,75 +59,103 @@ __global__ void k_dens_cellstart(const uint32_t* __restrict__ keys_sorted, int N
 }
 
 // The Gaussian is separable: exp(-(dx^2 + dy^2)/(2 s^2)) = ex(column, agent) * ey(row, agent).  A block
-// owns DT_X x DT_Y = 32 x 16 output cells; per batch of DB agents it evaluates the 48 one-dimensional factors of every
-// agent once (24 exp per thread instead of one per cell and agent: 512 -> 48 per agent and tile) into LDS and then adds
-// the rank-one products: 2 outputs per thread, one float64 FMA and 1.5 LDS reads per output and agent.
-#define DT_X 32
-#define DT_Y 16
-#define DB 128
+// owns DT x DT = 64 x 64 output cells, a thread a 4 x 4 block of them (rows ty + 16 a, columns tx + 16 b); per batch of DB
+// agents the block evaluates the 128 one-dimensional factors of every agent once into LDS and then adds the rank-one
+// products: 8 LDS reads for 16 float64 FMAs per agent and thread.
+// (Round 3's kernel -- 32 x 16 tiles, 2 outputs per thread -- was bound by LDS: 1.5 reads per FMA, 83 % of the index unit's
+// cycles; and a tile that small sums, with its margin of 6 sigma on every side, the agents of 21 x its own area, where a 64 x 64
+// tile sums 4.4 x: the work per output fell by more than the reads per FMA did.)
+#define DT 64
+#define DB 64
 template <typename T>
 __global__ void __launch_bounds__(256) k_density(DensParams P, const double2* __restrict__ spos,
                                                  const int32_t* __restrict__ cs, const double* __restrict__ X0,
                                                  const double* __restrict__ Y0, const float* __restrict__ Vall,
                                                  T* __restrict__ out) {
-    // (rows padded by one double: the factor table is WRITTEN one row per lane -- agent fq = lane -- and an unpadded row of
-    // 32 doubles put all 64 lanes of a store on the same banks: a third of the LDS cycles of the launch were conflicts)
-    __shared__ double lex[DB][DT_X + 1], ley[DB][DT_Y + 1];    // 51 KB
+    // (rows padded by one double: the factor table is WRITTEN one row per lane -- agent fq = lane -- and an unpadded row
+    // put all 64 lanes of a store on the same banks)
+    __shared__ double lex[DB][DT + 1], ley[DB][DT + 1];    // 66.6 KB
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int j0 = blockIdx.x * DT_X, i0 = blockIdx.y * DT_Y;
-    const int j1 = min(j0 + DT_X - 1, P.Nx - 1), i1 = min(i0 + DT_Y - 1, P.Ny - 1);
+    const int j0 = blockIdx.x * DT, i0 = blockIdx.y * DT;
+    const int j1 = min(j0 + DT - 1, P.Nx - 1), i1 = min(i0 + DT - 1, P.Ny - 1);
     // coarse cells intersecting tile +- cell
     auto cc = [&](double v, int n) {
         double f = floor(v / P.cell);
         return f < 0 ? 0 : (f > n - 1 ? n - 1 : (int)f);
     };
-    const int cx0 = cc(X0[j0] - P.cell, P.ncx), cx1 = cc(X0[j1] + P.cell, P.ncx);
-    const int cy0 = cc(Y0[i0] - P.cell, P.ncy), cy1 = cc(Y0[i1] + P.cell, P.ncy);
-    // this thread's share of the factor table: agent fq of the batch, 24 of its 48 factors
-    const int fq = threadIdx.x & (DB - 1), fpart = threadIdx.x >> 7;
-    double acc0 = 0.0, acc1 = 0.0;
+    const int cx0 = cc(X0[j0] - P.rcut, P.ncx), cx1 = cc(X0[j1] + P.rcut, P.ncx);
+    const int cy0 = cc(Y0[i0] - P.rcut, P.ncy), cy1 = cc(Y0[i1] + P.rcut, P.ncy);
+    // this thread's share of the factor table: agent fq of the batch, 32 of its 128 factors (part 0, 1: columns; 2, 3: rows)
+    const int fq = threadIdx.x & (DB - 1), fpart = threadIdx.x >> 6;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
     for (int cy = cy0; cy <= cy1; ++cy) {
         const int s0 = cs[cy * P.ncx + cx0], s1 = cs[cy * P.ncx + cx1 + 1];
         for (int base = s0; base < s1; base += DB) {
             const int cnt = min(DB, s1 - base);
             __syncthreads();
             if (fq < cnt) {
+                // The factors of one agent along a grid line are a Gaussian sampled at equal steps h: g(c + 1) = g(c) r(c),
+                // r(c + 1) = r(c) k with r(c) = exp(-(2 d_c h + h^2) / 2 sigma^2), k = exp(-h^2 / sigma^2) -- two multiplications
+                // per factor where a float64 exp costs ~40 instructions (the exponentials were four fifths of round 3's
+                // kernel).  Restarted from true exponentials on the grid's own axis value every 16 factors: the drift stays
+                // below 1e-14 relative, and what the axis deviates from equal steps (an ulp of its values) below 2e-12 of a
+                // factor that is e^-18 itself there.
                 const double2 p = spos[base + fq];
-                if (fpart == 0) {
-#pragma unroll 4
-                    for (int c = 0; c < 24; ++c) {
-                        const double d = X0[min(j0 + c, P.Nx - 1)] - p.x;
-                        lex[fq][c] = exp(-(d * d) * P.inv2s2) * P.invC;
-                    }
-                } else {
-#pragma unroll 4
-                    for (int c = 24; c < DT_X; ++c) {
-                        const double d = X0[min(j0 + c, P.Nx - 1)] - p.x;
-                        lex[fq][c] = exp(-(d * d) * P.inv2s2) * P.invC;
-                    }
-#pragma unroll 4
-                    for (int c = 0; c < DT_Y; ++c) {
-                        const double d = Y0[min(i0 + c, P.Ny - 1)] - p.y;
-                        ley[fq][c] = exp(-(d * d) * P.inv2s2);
+                const int c0 = 32 * (fpart & 1);
+                const bool xs_ = fpart < 2;
+                const double pc = xs_ ? p.x : p.y, h = xs_ ? P.hx : P.hy, k = xs_ ? P.kx : P.ky, sc = xs_ ? P.invC : 1.0;
+                const double* __restrict__ ax = xs_ ? X0 : Y0;
+                const int a0 = (xs_ ? j0 : i0), amax = (xs_ ? P.Nx : P.Ny) - 1;
+                double* const row = xs_ ? lex[fq] : ley[fq];
+#pragma unroll
+                for (int seg = 0; seg < 2; ++seg) {
+                    const int cb = c0 + 16 * seg;
+                    const double d = ax[min(a0 + cb, amax)] - pc;
+                    double g = exp(-(d * d) * P.inv2s2) * sc;
+                    if (P.recur) {
+                        double r = exp(-(2.0 * d * h + h * h) * P.inv2s2);
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            row[cb + c] = g;
+                            g *= r;
+                            r *= k;
+                        }
+                    } else {
+                        for (int c = 0; c < 16; ++c) {
+                            const double dc = ax[min(a0 + cb + c, amax)] - pc;
+                            row[cb + c] = exp(-(dc * dc) * P.inv2s2) * sc;
+                        }
                     }
                 }
             }
             __syncthreads();
             for (int q = 0; q < cnt; ++q) {
-                const double ey = ley[q][ty];
-                acc0 += lex[q][tx] * ey;
-                acc1 += lex[q][tx + 16] * ey;
+                double ex[4], ey[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) ex[b] = lex[q][tx + 16 * b];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) ey[a] = ley[q][ty + 16 * a];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] += ex[b] * ey[a];
             }
         }
     }
-    const int i = i0 + ty;
-    if (i < P.Ny) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = j0 + tx + 16 * u;
+    for (int a = 0; a < 4; ++a) {
+        const int i = i0 + ty + 16 * a;
+        if (i >= P.Ny) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + tx + 16 * b;
             if (j < P.Nx) {
                 const size_t o = (size_t)i * P.Nx + j;
-                double v = u ? acc1 : acc0;
+                double v = acc[a][b];
                 if (Vall && Vall[o] < 0.f) v = 0.0;
                 out[o] = (T)v;
             }
@@ -151,10 +182,21 @@ extern "C" int oc_density(oc_handle* h, int dtype, const oc_agents* a, double si
     DensParams P;
     P.Ny = c.Ny;
     P.Nx = c.Nx;
-    P.cell = trunc_sigmas * sigma;
+    P.rcut = trunc_sigmas * sigma;
+    // coarse cells of a third of the radius: what a tile sums beyond its own reach shrinks with the cells (a 6.4 m tile with
+    // 3 m of reach on every side: the cells it meets cover 15.4 m with 3 m cells, 13.4 m with 1 m cells), as long as the
+    // coarse grid stays small
+    P.cell = P.rcut / 3.0;
+    while ((c.room_length / P.cell + 1.0) * (c.room_height / P.cell + 1.0) > 4.0e6) P.cell *= 2.0;
     P.ncx = (int)(c.room_length / P.cell) + 1;
     P.ncy = (int)(c.room_height / P.cell) + 1;
     P.inv2s2 = 1.0 / (2 * sigma * sigma);
+    // (the recurrence needs equal steps: the reference's np.linspace axes, checked in oc_create; any other axis: true exponentials)
+    P.recur = h->axes_linspace ? 1 : 0;
+    P.hx = c.room_length / (c.Nx - 1);
+    P.hy = c.room_height / (c.Ny - 1);
+    P.kx = std::exp(-P.hx * P.hx / (sigma * sigma));
+    P.ky = std::exp(-P.hy * P.hy / (sigma * sigma));
     P.invC = (h->fix_flags & OC_FIX_DENSITY_NORM) ? 1.0 / (2 * M_PI * sigma * sigma)            // Q11 corrected
                                                     : 1.0 / std::sqrt(4 * M_PI * M_PI * sigma * sigma);
     const int N = a->N, ncell = P.ncx * P.ncy;
@@ -190,7 +232,7 @@ extern "C" int oc_density(oc_handle* h, int dtype, const oc_agents* a, double si
         nact_slots = N;
     }
     hipLaunchKernelGGL(k_dens_cellstart, dim3((ncell + 1 + 255) / 256), dim3(256), 0, s, kb, nact_slots, ncell, cs);
-    dim3 g((c.Nx + DT_X - 1) / DT_X, (c.Ny + DT_Y - 1) / DT_Y);
+    dim3 g((c.Nx + DT - 1) / DT, (c.Ny + DT - 1) / DT);
     oc_timer_begin(h, "density", s);
     if (dtype == OC_F32)
         hipLaunchKernelGGL(k_density<float>, g, dim3(256), 0, s, P, spos, cs, h->X0, h->Y0, V_all, (float*)out);

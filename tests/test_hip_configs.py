@@ -91,12 +91,12 @@ def test_config_full_horizon_solve_vs_oracle(room, grid, dtype):
     against the C oracle's float64 RK45 (SciPy's arithmetic restated: oracle/oc_oracle_c.c, pinned by fixture G3) driven
     along the GPU's own accepted steps, so that only arithmetic differs: every step the GPU took must be one the float64
     controller accepts, and phi / the direction field must agree at early, middle and late slices.
-    Tolerances.  float32 ('float32'): SURVEY 8d as it stands on these grids -- phi on 2 x 2 block averages 2e-2 (the
-    checkerboard mode of the stability-limited explicit pair: tests/hjb_compare.py), pointwise 2e-1, direction within
-    1e-2 rad on >= 95 % of the clear cells and 0.25 rad everywhere (the full-size tests' figures), flips <= 0.5 %.  float64 state ('mixed', 1.26 x the float32 solve time at
+    Tolerances.  float32 ('float32'): SURVEY 8d as it stands on these grids -- phi on 2 x 2 block averages 1.5e-2 (the
+    checkerboard mode of the stability-limited explicit pair: tests/hjb_compare.py), pointwise 1e-1, direction within
+    1e-2 rad on >= 97 % of the clear cells and 0.14 rad everywhere (1.5 x the values on record), flips <= 0.5 %.  float64 state ('mixed', 1.26 x the float32 solve time at
     2048 x 2048): phi 1e-5, direction 1e-4 rad on every clear cell."""
     import torch
-    from hjb_compare import assert_steps_acceptable, clear_cells, describe, direction_errors, phi_errors
+    from hjb_compare import assert_steps_acceptable, clear_cells, describe, direction_errors, phi_errors, record_margin
     from optimal_crowds_amd import host
     from optimal_crowds_amd.engine import Engine
     T, gs = 20.0, 0.1
@@ -130,12 +130,14 @@ def test_config_full_horizon_solve_vs_oracle(room, grid, dtype):
         hx, hy = (t.double().cpu().numpy() for t in eng.field_slice(0, sl))
         a, flips = direction_errors(gx, gy, hx, hy, clear_cells(want[q], Ny, Nx, gs, hp["mu"]))
         print("%s %s slice %d: phi pointwise %.3e averaged %.3e; angle %s; flips %.2e" % (room, dtype, sl, point, avg, describe(a), flips))
+        record_margin("%s %dx%d" % (room, Nx, Ny), sl, point, avg, a, flips, err=zst["err"], mode=dtype)
         assert a.size > 100
         if dtype == "float32":
             # [C2: 3.8e-3 averaged / 3.1e-2 pointwise at t = 15 s; C3: 1.02e-2 / 5.5e-2 at t = 20 s.  The ripple's amplitude is
             #  what the controller happens to tolerate on this step sequence (tests/hjb_compare.py): a bound, not a constant]
-            assert avg <= 2e-2 and point <= 2e-1, (sl, point, avg)
-            assert (a > 1e-2).mean() <= 5e-2 and a.max() <= 0.25, describe(a)      # [1.4 % of 7 182 cells, 4.3e-2 rad at C2]
+            # (1.5 x the largest values on record, profiles/r04_parity_margins.json: C3 1.02e-2 / 6.4e-2, 1.9 % / 9.4e-2 rad)
+            assert avg <= 1.5e-2 and point <= 1.0e-1, (sl, point, avg)
+            assert (a > 1e-2).mean() <= 3e-2 and a.max() <= 0.14, describe(a)      # [1.4 % of 7 182 cells, 4.3e-2 rad at C2]
             assert flips <= 5e-3
         else:
             assert point <= 1e-5, (sl, point)

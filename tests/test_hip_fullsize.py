@@ -162,7 +162,7 @@ def test_t20_fp32_range_management_vs_oracle():
     eng.close()
 
 
-from hjb_compare import assert_steps_acceptable, clear_cells, describe, direction_errors, phi_errors      # noqa: E402
+from hjb_compare import assert_steps_acceptable, clear_cells, describe, direction_errors, phi_errors, record_margin      # noqa: E402
 
 
 def test_c4_value_grid_and_direction_field_vs_c_oracle(c4):
@@ -173,9 +173,9 @@ def test_c4_value_grid_and_direction_field_vs_c_oracle(c4):
                   error test), so what remains is float32 arithmetic alone.
     Stated float64 -> float32 tolerances at this size (measured values in brackets; tests/hjb_compare.py explains why phi
     carries a checkerboard ripple that the direction field does not see):
-      phi        2x2-block averages within 1e-2 [6.8e-3], pointwise within 2e-1 [9.8e-2, next to a door at t = 8 s];
+      phi        2x2-block averages within 1e-2 [6.8e-3], pointwise within 1.5e-1 [9.8e-2, next to a door at t = 8 s];
       direction  angle <= 1e-2 rad on at least 95 % of the cells at least 10 % away from the unit-or-zero threshold
-                 [97.1 % at t = 8 s, all of them at t = 0 and at the last slice], never beyond 0.25 rad [5.6e-2: where the
+                 [97.1 % at t = 8 s, all of them at t = 0 and at the last slice], never beyond 0.085 rad [5.6e-2: where the
                  ripple's amplitude changes from cell to cell, next to the doors]; unit/zero flips on <= 0.1 % of the cells.
     The float64 mode of the same kernels, on the same grid, reproduces the oracle to 1e-5 (next test): the float32
     deviation is rounding noise amplified by the integrator, not a difference of algorithm."""
@@ -201,13 +201,17 @@ def test_c4_value_grid_and_direction_field_vs_c_oracle(c4):
         for ref, name in ((free_phi[q], "free"), (forced_phi[q], "forced")):
             point, avg = phi_errors(got_phi[q], ref, V, sim.Ny, sim.Nx)
             print("C4 slice %d vs %s run: phi pointwise %.3e averaged %.3e" % (s, name, point, avg))
-            assert avg <= 1e-2 and point <= 2e-1, (s, point, avg)
+            # (bounds = 1.5 x the largest value on record, profiles/r04_parity_margins.json: 6.8e-3 / 9.8e-2 in round 3's step
+            #  sequence, 1.4e-3 / 9.7e-3 in round 4's -- the ripple's amplitude is chaotic in the step sequence)
+            assert avg <= 1.0e-2 and point <= 1.5e-1, (s, point, avg)
         hx, hy = vx[s].double().cpu().numpy(), vy[s].double().cpu().numpy()
         gx, gy = occ.vels(P, forced_phi[q])
         a, flips = direction_errors(gx, gy, hx, hy, clear_cells(forced_phi[q], sim.Ny, sim.Nx, cfg["grid_step"], hp["mu"]))
         print("C4 slice %d: angle %s; flips %.2e" % (s, describe(a), flips))
+        point_f, avg_f = phi_errors(got_phi[q], forced_phi[q], V, sim.Ny, sim.Nx)
+        record_margin("C4 metro_station 2048x2048", s, point_f, avg_f, a, flips, err=zst["err"])
         assert a.size > (1000 if s == 0 else 100)                 # (the last slice moves next to the doors only)
-        assert (a > 1e-2).mean() <= 5e-2 and a.max() <= 0.25
+        assert (a > 1e-2).mean() <= 4.5e-2 and a.max() <= 0.085        # (on record: 2.9 % / 5.6e-2 rad in round 3, 0 / 3.3e-3 in round 4)
         assert flips <= 1e-3
 
 

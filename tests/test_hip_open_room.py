@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import oc_oracle as oc                     # noqa: E402  (checker only)
 from oracle import oc_oracle_c as occ                  # noqa: E402
-from hjb_compare import assert_steps_acceptable, clear_cells, describe, direction_errors, phi_errors      # noqa: E402
+from hjb_compare import assert_steps_acceptable, clear_cells, describe, direction_errors, phi_errors, record_margin      # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -74,7 +74,9 @@ def test_open_room_recompute_loop(c5):
                 for q, sl in enumerate(slices):
                     vx_s, vy_s = eng.field_slice(0, sl)             # (one slice at a time: all of them would be 125 GB)
                     point, avg = phi_errors(got[q], want[q], V, sim.Ny, sim.Nx)
-                    assert avg <= 1e-2 and point <= 2e-1, (sl, point, avg)       # (checkerboard mode: tests/hjb_compare.py)
+                    # (checkerboard mode: tests/hjb_compare.py; 1.5 x the values on record, profiles/r04_parity_margins.json:
+                    #  9.3e-3 / 5.9e-2 in round 4)
+                    assert avg <= 1.4e-2 and point <= 9e-2, (sl, point, avg)
                     gx, gy = occ.vels(P, want[q])
                     hx, hy = vx_s.double().cpu().numpy(), vy_s.double().cpu().numpy()
                     del vx_s, vy_s
@@ -82,8 +84,9 @@ def test_open_room_recompute_loop(c5):
                                                 clear_cells(want[q], sim.Ny, sim.Nx, cfg["grid_step"], hp["mu"]))
                     print("open_room re-solve slice %d: phi pointwise %.3e averaged %.3e; angle %s; flips %.2e"
                           % (sl, point, avg, describe(a), flips))
+                    record_margin("C5 open_room 4096x4096 re-solve (m = density)", sl, point, avg, a, flips, err=zst["err"])
                     assert a.size > (1000 if sl == 0 else 50)
-                    assert (a > 1e-2).mean() <= 5e-2 and a.max() <= 0.25      # [4.3e-5 of 6e6 cells, 0.13 rad]
+                    assert (a > 1e-2).mean() <= 5e-4 and a.max() <= 0.22      # [7.3e-5 of 6e6 cells, 0.145 rad in round 4]
                     assert flips <= 1e-3
                     del gx, gy, hx, hy, a
                 del got, want, m64
