@@ -595,6 +595,10 @@ def main():
                                                 "avg_ms_per_attempt": kp["avg_ms"],
                                                 "note": "attempts that ran inside ONE co-resident launch (oc_set_tuning hjb_persist; "
                                                         "default: grids of a few dozen tiles only -- csrc/hjb.hip)"},
+                      "hjb_launch_resyncs": sum(s_.get("grid_resyncs", 0) for s_ in mine),
+                      "hjb_launch_resyncs_note": "attempts whose launch did nothing and were drained and re-enqueued: a grid smaller than "
+                                                 "its work list, or a launch that found a controller block not yet written (seen only "
+                                                 "where two processes share one GPU)",
                       "projected_complete_run": projected,
                       "nfev": first["nfev"] if first else None, "rk_attempts": first["n_attempt"] if first else None,
                       "rk_accepted": first["n_accept"] if first else None, "kernels": kstats, "init_s": t_init,

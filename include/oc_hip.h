@@ -343,6 +343,11 @@ int oc_agents_changed(oc_handle* h);
  * trunc_sigmas: contributions beyond this many sigmas are dropped (<= 0: 6.0). */
 int oc_density(oc_handle* h, int dtype, const oc_agents* a, double sigma, const float* V_all, double trunc_sigmas,
                void* out, void* stream);
+/* The same for grid rows [row_lo, row_hi) only -- `out` is still the (Ny, Nx) array, the other rows are left as they are: a
+ * rank of a row-block solve (oc_hjb_solve_rows) needs the density under its own rows (+ halo) only; the agents are
+ * replicated, so this needs no communication. */
+int oc_density_rows(oc_handle* h, int dtype, const oc_agents* a, double sigma, const float* V_all, double trunc_sigmas,
+                    int32_t row_lo, int32_t row_hi, void* out, void* stream);
 
 /* ---- introspection for bench.py / tests --------------------------------------------------------------------- */
 /* With profiling enabled every launch of a named kernel class is bracketed by HIP events on its own stream.

@@ -151,6 +151,8 @@ SIGNATURES = {
     "oc_agents_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "oc_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(OcAgents), C.c_double, C.c_void_p, C.c_double,
                              C.c_void_p, C.c_void_p]),
+    "oc_density_rows": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(OcAgents), C.c_double, C.c_void_p, C.c_double,
+                                 C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "oc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "oc_kernel_stats": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]),

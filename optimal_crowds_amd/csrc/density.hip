@@ -19,6 +19,7 @@ struct DensParams {
     double inv2s2, invC;
     double hx, hy, kx, ky;      // grid steps and exp(-h^2 / sigma^2): the Gaussian's factors along a grid line by recurrence
     int32_t recur, pad;         // 1: the axes are equally spaced (np.linspace): recurrence; 0: a true exponential per factor
+    int32_t row_lo, row_hi;     // grid rows [row_lo, row_hi) are computed (oc_density_rows: a rank's row block; oc_density: all)
 };
 
 __global__ void k_dens_keys(const double* __restrict__ x, const double* __restrict__ y,
@@ -76,8 +77,8 @@ __global__ void __launch_bounds__(256) k_density(DensParams P, const double2* __
     // put all 64 lanes of a store on the same banks)
     __shared__ double lex[DB][DT + 1], ley[DB][DT + 1];    // 66.6 KB
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int j0 = blockIdx.x * DT, i0 = blockIdx.y * DT;
-    const int j1 = min(j0 + DT - 1, P.Nx - 1), i1 = min(i0 + DT - 1, P.Ny - 1);
+    const int j0 = blockIdx.x * DT, i0 = P.row_lo + blockIdx.y * DT;
+    const int j1 = min(j0 + DT - 1, P.Nx - 1), i1 = min(i0 + DT - 1, P.row_hi - 1);
     // coarse cells intersecting tile +- cell
     auto cc = [&](double v, int n) {
         double f = floor(v / P.cell);
@@ -149,7 +150,7 @@ __global__ void __launch_bounds__(256) k_density(DensParams P, const double2* __
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int i = i0 + ty + 16 * a;
-        if (i >= P.Ny) continue;
+        if (i >= P.row_hi) continue;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int j = j0 + tx + 16 * b;
@@ -167,7 +168,14 @@ __global__ void __launch_bounds__(256) k_density(DensParams P, const double2* __
 
 extern "C" int oc_density(oc_handle* h, int dtype, const oc_agents* a, double sigma, const float* V_all,
                           double trunc_sigmas, void* out, void* stream) {
+    OC_REQUIRE(h, "null handle");
+    return oc_density_rows(h, dtype, a, sigma, V_all, trunc_sigmas, 0, h->cfg.Ny, out, stream);
+}
+
+extern "C" int oc_density_rows(oc_handle* h, int dtype, const oc_agents* a, double sigma, const float* V_all,
+                               double trunc_sigmas, int32_t row_lo, int32_t row_hi, void* out, void* stream) {
     OC_REQUIRE(h && a && out, "null argument");
+    OC_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= h->cfg.Ny, "bad row range");
     OC_REQUIRE(a->N >= 0 && a->N <= h->cfg.max_agents, "agent count exceeds max_agents");
     OC_REQUIRE(sigma > 0, "sigma must be positive");
     OC_REQUIRE(dtype == OC_F32 || dtype == OC_F64, "bad dtype");
@@ -182,6 +190,8 @@ extern "C" int oc_density(oc_handle* h, int dtype, const oc_agents* a, double si
     DensParams P;
     P.Ny = c.Ny;
     P.Nx = c.Nx;
+    P.row_lo = row_lo;
+    P.row_hi = row_hi;
     P.rcut = trunc_sigmas * sigma;
     // coarse cells of a third of the radius: what a tile sums beyond its own reach shrinks with the cells (a 6.4 m tile with
     // 3 m of reach on every side: the cells it meets cover 15.4 m with 3 m cells, 13.4 m with 1 m cells), as long as the
@@ -232,14 +242,15 @@ extern "C" int oc_density(oc_handle* h, int dtype, const oc_agents* a, double si
         nact_slots = N;
     }
     hipLaunchKernelGGL(k_dens_cellstart, dim3((ncell + 1 + 255) / 256), dim3(256), 0, s, kb, nact_slots, ncell, cs);
-    dim3 g((c.Nx + DT - 1) / DT, (c.Ny + DT - 1) / DT);
+    if (row_hi == row_lo) return OC_OK;
+    dim3 g((c.Nx + DT - 1) / DT, (row_hi - row_lo + DT - 1) / DT);
     oc_timer_begin(h, "density", s);
     if (dtype == OC_F32)
         hipLaunchKernelGGL(k_density<float>, g, dim3(256), 0, s, P, spos, cs, h->X0, h->Y0, V_all, (float*)out);
     else
         hipLaunchKernelGGL(k_density<double>, g, dim3(256), 0, s, P, spos, cs, h->X0, h->Y0, V_all, (double*)out);
     // algorithmic bytes: the agents' positions once + the grid written once (the kernel is bound by float64 exp / FMA)
-    oc_timer_end(h, "density", s, 16.0 * N + (dtype == OC_F32 ? 4.0 : 8.0) * (double)c.Nx * c.Ny);
+    oc_timer_end(h, "density", s, 16.0 * N + (dtype == OC_F32 ? 4.0 : 8.0) * (double)c.Nx * (row_hi - row_lo));
     OC_HIP_CHECK(hipGetLastError());
     return OC_OK;
 }

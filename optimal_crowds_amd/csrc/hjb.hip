@@ -99,6 +99,11 @@ struct HjbCtl {
     int32_t list_todo;                  // active set: k_control's order for the list builder (block 0 of k_out): 1 = build, 2 = go dense
     int32_t n_hx;                       // k_out's per-slice factors h x, h x^2, h x^3, h x^4 (0: more than HJB_MAXS slices,
     T hx[HJB_MAXS][4];                  // computed in the kernel)
+    // row-block solves with the active set: the tile rows [0, band_lo) and [band_hi, tnby) touch rows RECEIVED from a neighbour
+    // (their region reaches into the halo the exchange refreshes): activity arrives there from outside, so they are always on
+    // the work list and test themselves every attempt.  Whole-grid solves: 0 and tnby (no such rows).
+    int32_t band_lo, band_hi;
+    int32_t sh_all_active, pad_;        // row-block solves: this rank's tiles ALL had an error share (k_reduce_local)
 };
 
 // first part of an attempt (rk.py:121-137): clamp the step, its end time ...
@@ -640,10 +645,12 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
             } else {
                 double ymax = __longlong_as_double((long long)L.m_bits);
                 // (active set: tiles off the work list took no part in the launch -- their share is 0 and the far field's u)
-                if (active_set != 0 && c.work_count < nparts) ymax = fmax(ymax, fabs((double)c.u_bg * (double)c.in_scale));
+                if (active_set == 1 && c.work_count < nparts) ymax = fmax(ymax, fabs((double)c.u_bg * (double)c.in_scale));
                 const double nact = (double)L.na_cnt;
                 c.act_sum += nact;
-                all_active = (active_set != 0 && nact == (double)nparts) ? 1 : 0;
+                // (active_set = 2: a row-block solve -- the pairs are the RANKS'; whether this rank's tiles are all active was
+                // left by k_reduce_local)
+                all_active = active_set == 2 ? c.sh_all_active : ((active_set != 0 && nact == (double)nparts) ? 1 : 0);
                 const double err = sqrt(esum) / sqrt(c.n_rms);
                 ++c.n_attempt;
                 c.accepted = 0;
@@ -790,6 +797,52 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
             uint32_t* dst2 = reinterpret_cast<uint32_t*>(const_cast<HjbCtl<T>*>(ctl_in));
             for (int i = threadIdx.x; i < NW32; i += nth) dst2[i] = src[i];
         }
+    }
+}
+
+// Row-block solve with the active set: this rank's pair for the all-gather.  The tiles off the work list took no part in the
+// attempt -- their error share is 0 and their max |y_new| the far field's u (what k_control adds on one GPU) -- and whether
+// ALL of this rank's tiles had an error share (then the rank goes dense: a local matter, the collectives do not depend on
+// it) is left in the controller block for k_control.
+template <typename T>
+__global__ void __launch_bounds__(1024) k_reduce_local(const double* __restrict__ partial, int nblocks, HjbCtl<T>* __restrict__ ctl,
+                                                        double* __restrict__ out) {
+    const double2* __restrict__ p2 = reinterpret_cast<const double2*>(partial);
+    double s = 0.0, m = 0.0, na = 0.0;
+    const int nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < nblocks; i0 += 4 * nt) {
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i0 + u * nt < nblocks) ? p2[i0 + u * nt] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s += v[u].x;
+            m = fmax(m, v[u].y);
+            na += v[u].x > 0.0 ? 1.0 : 0.0;
+        }
+    }
+    __shared__ double ls[16], lm[16], la[16];
+    s = wave_sum(s);
+    m = wave_max(m);
+    na = wave_sum(na);
+    const int w = threadIdx.x >> 6, nw = (nt + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        ls[w] = s;
+        lm[w] = m;
+        la[w] = na;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int q = 0; q < nw; ++q) {
+            a += ls[q];
+            b = fmax(b, lm[q]);
+            c += la[q];
+        }
+        if (!ctl->done && ctl->dense_mode == 0 && ctl->work_count < nblocks) b = fmax(b, fabs((double)ctl->u_bg * (double)ctl->in_scale));
+        ctl->sh_all_active = (c == (double)nblocks) ? 1 : 0;
+        out[0] = a;
+        out[1] = b;
     }
 }
 
@@ -1388,7 +1441,10 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
                      SB(atol_s), SB(in_scale), SB(cc[0][0]), SB(cc[NQ / 2 - 1][5]), SB(cc[NQ / 2][0]), SB(cc[NQ - 1][5]), SB(he[0]),
                      SB(he[6]), SB(A.coef), SB(flags_prev));
     }
-    if (c_done) return;                             // an attempt enqueued past the end of the solve (PERSIST: every block sees it)
+    if (c_done) {                                   // an attempt enqueued past the end of the solve (PERSIST: every block sees it)
+        if (!PERSIST && A.att_expected == 0 && threadIdx.x == 0) atomicAdd(A.tail_counter + TAIL_COUNTER_BYTES / 4 + 4, 1);     // (diagnostics: never at attempt 0)
+        return;
+    }
     const T* __restrict__ y = A.Y[par];
     const T* kin[4] = {A.KX[par], A.KM[0], A.KM[1], A.KM[2]};
     if (!PERSIST) asm volatile("" ::SB(y), SB(kin[0]));   // (the two pointers picked by the parity: in registers before the loads
@@ -1409,7 +1465,18 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
         // say so in the mailbox; the launches enqueued behind it find a controller block that is not theirs (ticks !=
         // att_expected) and do nothing either; the host drains the stream and goes on from the controller's state with a
         // grid that fits (hjb_solve_dev).  (Never seen in practice: the list grows by a tile every few attempts.)
-        if (A.att_expected >= 0 && c_ticks != A.att_expected) return;
+        if (A.att_expected >= 0 && c_ticks != A.att_expected) {
+            // Not this launch's controller block: either the launches before it did nothing (a grid too small, below), or --
+            // seen where TWO PROCESSES share one GPU (the N = 2 rehearsal on a one-GPU box), never otherwise -- this launch's
+            // blocks started before the previous launch's last block had written the block (an sc1 load finds the old words
+            // too: it is the launch order, not a cache).  Do nothing and ask the host to drain and re-enqueue from the
+            // controller's state; an attempt some of whose blocks ran is simply run again (it changes none of its inputs).
+            if (threadIdx.x == 0) {
+                atomicAdd(A.tail_counter + TAIL_COUNTER_BYTES / 4 + 5, 1);      // (diagnostics)
+                A.mailbox[2] = (double)(A.att_expected + 1);
+            }
+            return;
+        }
         if (n_items > (int)gridDim.x) {
             if (blockIdx.x == 0 && threadIdx.x == 0) {
                 A.mailbox[1] = (double)n_items;
@@ -2093,6 +2160,7 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
     int32_t* const wsum = wsum_ext != nullptr ? wsum_ext : wsum_own;
     const int todo = ctl->list_todo, nth = (int)blockDim.x;
     const int ntile = tnbx * tnby;
+    const int band_lo = ctl->band_lo, band_hi = ctl->band_hi;
     if (todo == 0) return;
     if (todo == 2) {                                // every tile is active and stays so: no flags, no list from now on
         if (threadIdx.x == 0) {
@@ -2144,7 +2212,7 @@ __device__ __forceinline__ void build_work_list(HjbCtl<T>* __restrict__ ctl, con
                     q9 &= inside ? (uint32_t)sflag[inside ? ni * tnbx + nj : t] : 1u;
                 }
             const int q = t - t_lo;
-            if (q9) {
+            if (q9 && bi >= band_lo && bi < band_hi) {      // (tile rows that touch a neighbour's rows stay on the list)
                 if (q < 32) listed &= ~(1u << q);
                 else listed_hi &= ~(1u << (q - 32));
             }
@@ -2881,11 +2949,24 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     hc.u_bg = (T)1;
     hc.work_count = 1 << 30;            // (the first attempt looks at every tile)
     hc.h_abs0 = h_abs;
+    {   // tile rows whose region (tile +- 6 rows) reaches into rows a neighbour sends: always on the work list
+        const int TYr = OC_RING_STY, HYr = 6;       // (the one-launch attempt's tile: the only one the active set runs with)
+        const int tnby0 = (S.Ny + TYr - 1) / TYr;
+        hc.band_lo = 0;
+        hc.band_hi = tnby0;
+        if (sh && sh->has_up) hc.band_lo = std::min(tnby0, (sh->own_lo + HYr - 1) / TYr + 1);
+        if (sh && sh->has_dn) {
+            int b = tnby0;
+            while (b > 0 && (b - 1) * TYr + TYr - 1 + HYr >= sh->own_hi) --b;      // tile row b - 1 reaches row own_hi or beyond
+            hc.band_hi = b;
+        }
+    }
     if (!dev_init) ctl_prepare_attempt(hc, true);
     // (through a pinned staging block: no synchronisation -- the block is rewritten by the next solve at the earliest)
     if (!h->hjb_ctl_host) OC_HIP_CHECK(hipHostMalloc(&h->hjb_ctl_host, 4096, hipHostMallocDefault));
     memcpy(h->hjb_ctl_host, &hc, sizeof(hc));
     OC_HIP_CHECK(hipMemcpyAsync(ctl, h->hjb_ctl_host, sizeof(hc), hipMemcpyHostToDevice, s));
+    OC_HIP_CHECK(hipMemsetAsync(ctlb[1], 0xFF, sizeof(hc), s));     // (ticks = -1 until the first attempt's controller has written it)
     OC_HIP_CHECK(hipMemsetAsync(h->hjb_tail, 0, TAIL_COUNTER_BYTES, s));   // (a solve that failed half-way may have left tickets)
     if (dev_init)
         hipLaunchKernelGGL(k_init_step<T>, dim3(1), dim3(64), 0, s, ctl, h->red_out, 1, n_rms, std::fabs(tf - t0));
@@ -2976,8 +3057,12 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // 512 x 512, where the front crosses the room: 3.9 against 3.5 ms per solve): hjb_active = 1 switches by size, 2 forces it.
     // Above 12 000 tiles (grids beyond ~5000 x 5000) the list builder's per-thread masks and its LDS copy of the flags no
     // longer cover the grid: every tile is computed.
-    const bool active_set = !sh && fuse == 0 && nb3 <= 12000 &&
-                            (h->hjb_active == 2 || (h->hjb_active == 1 && nb3 >= 1024));
+    // Row blocks (round 4): the same flags and lists per rank, with the tile rows that reach into a neighbour's rows always
+    // listed (HjbCtl::band_lo / band_hi), the far field added in the rank's own reduction (k_reduce_local) and without the
+    // far-field substitution (what a rank SENDS must be in its buffers).  The size rule looks at the whole grid's tiles.
+    const int nb_rule = sh ? ((S.Nx + tx - 1) / tx) * ((sh->Ny_global + ty - 1) / ty) : nb3;
+    const bool active_set = fuse == 0 && nb3 <= 12000 && (!sh || h->hjb_active_rows != 0) &&
+                            (h->hjb_active == 2 || (h->hjb_active == 1 && nb_rule >= 1024));
     if (active_set && h->hjb_flags_n < (size_t)6 * nb3) {     // flags of two attempts + two work lists (alternating) +
         if (h->hjb_flags) OC_HIP_CHECK(hipFree(h->hjb_flags));     // the undefined-tile marks of the two state buffers
         h->hjb_flags = nullptr;
@@ -2986,7 +3071,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         h->hjb_flags_n = (size_t)6 * nb3;
     }
     // far-field substitution (Stage3Args::undef): ring solves; every tile of both buffers starts out defined
-    SA.undef = (active_set && ring && h->hjb_subst != 0) ? h->hjb_flags + (size_t)4 * nb3 : nullptr;
+    SA.undef = (active_set && ring && !sh && h->hjb_subst != 0) ? h->hjb_flags + (size_t)4 * nb3 : nullptr;
     if (SA.undef) OC_HIP_CHECK(hipMemsetAsync(SA.undef, 0, sizeof(int32_t) * 2 * (size_t)nb3, s));
     // attempt a reads work list a & 1; the builder after it writes list (a + 1) & 1 (a late block of the attempt's own launch
     // must never see the next attempt's list: the fused tail builds it while that launch is still draining)
@@ -3045,7 +3130,9 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         HjbCtl<T>* const ctl_nxt = ctlb[(enq + 1) & 1];
         SA.ctl = ctl_cur;
         SA.ctl_out = ctl_nxt;
-        SA.att_expected = enq;
+        // (row-block solves: unchecked -- every rank must enqueue the same attempts, their collectives are matched by count; a
+        // drain-and-re-enqueue on one rank alone would leave the others waiting)
+        SA.att_expected = sh ? -1 : enq;
         OA.ctl = ctl_nxt;                               // (k_out / the list builder act on the controller's decision)
         if (active_set) {
             SA.flags_cur = h->hjb_flags + (size_t)(enq & 1) * nb3;
@@ -3084,7 +3171,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         if (fused) {
             // (controller and list builder ran inside the stage launch)
         } else if (sh) {
-            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, nb3, sh->red_local);
+            if (active_set) hipLaunchKernelGGL(k_reduce_local<T>, dim3(1), dim3(1024), 0, s, (const double*)h->red_partial, nb3, ctl_cur, sh->red_local);
+            else hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, nb3, sh->red_local);
             if (sh->comm_slot >= 0) {       // RCCL from here, on the launch stream (comm.hip)
                 int rcc = oc_comm_allgather_f64_oop(h, sh->comm_slot, sh->red_local, sh->red_all, 2, s);
                 if (rcc) return rcc;
@@ -3094,7 +3182,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             }
             hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, (const HjbCtl<T>*)ctl_cur, ctl_nxt,
                                (const double*)sh->red_all, sh->world, h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP,
-                               (volatile double*)mb_dev, 0, R.slots, R.slices, R.cap);
+                               (volatile double*)mb_dev, active_set ? 2 : 0, R.slots, R.slices, R.cap);
         } else {
             hipLaunchKernelGGL(k_control<T>, dim3(1), dim3(256), 0, s, (const HjbCtl<T>*)ctl_cur, ctl_nxt,
                                (const double*)h->red_partial, nb3, h->hjb_tsteps, T_CAP, h->hjb_log, LOG_CAP,
@@ -3240,8 +3328,17 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         for (int b = 0; b < BURST; ++b)
             if ((rc = enqueue_attempt())) return rc;
         if (enq > LOG_CAP - 2 * BURST) {
-            oc_set_error("RK45: more than %d attempts", LOG_CAP);
             (void)hipStreamSynchronize(s);
+            HjbCtl<T> two[2];
+            int32_t tc[4] = {0, 0, 0, 0}, dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipMemcpy(&two[0], ctlb[0], sizeof(hc), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&two[1], ctlb[1], sizeof(hc), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(tc, h->hjb_tail, sizeof(tc), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(dbg, h->hjb_tail + TAIL_COUNTER_BYTES / 4, sizeof(dbg), hipMemcpyDeviceToHost);
+            oc_set_error("RK45: more than %d attempts (early exits: done@0 %d, not-mine %d [fresh ok %d, fresh bad %d]; ticks %d / %d, attempts %d / %d, done %d / %d, "
+                         "t %g / %g, listed %d / %d; tickets %d; mailbox %g %g %g)", LOG_CAP, dbg[4], dbg[5], dbg[6], dbg[7], two[0].ticks, two[1].ticks,
+                         two[0].n_attempt, two[1].n_attempt, two[0].done, two[1].done, two[0].t, two[1].t, two[0].work_count,
+                         two[1].work_count, tc[0], (double)mb[0], (double)mb[1], (double)mb[2]);
             return OC_ERR_SOLVER;
         }
         if (sh) {
@@ -3277,14 +3374,15 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         if (mb[2] != 0.0) {
-            // a sparse attempt's launch was too small for its list (k_stageV: att_expected): it and everything enqueued
-            // behind it did nothing.  Drain, take the attempt number from the controller blocks, go on with grids that fit.
+            // a sparse attempt's launch was too small for its list, or a launch found a controller block that was not its own
+            // (k_stageV: att_expected): it and everything enqueued behind it did nothing.  Drain, take the attempt number
+            // from the controller blocks, go on (with grids that fit).
             OC_HIP_CHECK(hipStreamSynchronize(s));
             HjbCtl<T> two[2];
             OC_HIP_CHECK(hipMemcpy(&two[0], ctlb[0], sizeof(hc), hipMemcpyDeviceToHost));
             OC_HIP_CHECK(hipMemcpy(&two[1], ctlb[1], sizeof(hc), hipMemcpyDeviceToHost));
             enq = std::max(two[0].ticks, two[1].ticks);
-            grid_floor = std::max(grid_floor, (int)mb[1]);
+            if (mb[1] < 1e8) grid_floor = std::max(grid_floor, (int)mb[1]);
             ++stats.grid_resyncs;
             mb[2] = 0.0;
             __atomic_thread_fence(__ATOMIC_SEQ_CST);

@@ -309,6 +309,9 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     } else if (!strcmp(name, "hjb_subst")) {
         OC_REQUIRE(value >= 0 && value <= 1, "hjb_subst out of range");
         h->hjb_subst = (int)value;
+    } else if (!strcmp(name, "hjb_active_rows")) {
+        OC_REQUIRE(value >= 0 && value <= 1, "hjb_active_rows must be 0 or 1");
+        h->hjb_active_rows = value;
     } else if (!strcmp(name, "hjb_grid_fit")) {
         OC_REQUIRE(value >= 0 && value <= 1, "hjb_grid_fit must be 0 or 1");
         h->hjb_grid_fit = value;

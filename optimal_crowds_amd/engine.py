@@ -807,10 +807,32 @@ class Engine:
         check(self.lib.oc_run_status(self.h, out, int(bool(reset)), self.stream()))
         return int(out[0]), int(out[1]), int(out[2]), int(out[3])
 
-    def density(self, sigma, V_all=None, trunc_sigmas=6.0, out_dtype=None):
+    def density(self, sigma, V_all=None, trunc_sigmas=6.0, out_dtype=None, rows=None):
+        """rows = (lo, hi): only those grid rows are computed (oc_density_rows), the others are zero -- what a rank of a
+        row-block solve needs (density_rows_needed)"""
         dt = self.dtype if out_dtype is None else out_dtype
-        out = torch.empty((self.Ny, self.Nx), dtype=torch.float32 if dt == OC_F32 else torch.float64,
-                          device=self.device)
-        check(self.lib.oc_density(self.h, dt, C.byref(self._astruct), float(sigma), _ptr(V_all),
-                                  float(trunc_sigmas), _ptr(out), self.stream()))
+        tdt = torch.float32 if dt == OC_F32 else torch.float64
+        if rows is None or (rows[0] <= 0 and rows[1] >= self.Ny):
+            out = torch.empty((self.Ny, self.Nx), dtype=tdt, device=self.device)
+            check(self.lib.oc_density(self.h, dt, C.byref(self._astruct), float(sigma), _ptr(V_all),
+                                      float(trunc_sigmas), _ptr(out), self.stream()))
+            return out
+        out = torch.zeros((self.Ny, self.Nx), dtype=tdt, device=self.device)
+        check(self.lib.oc_density_rows(self.h, dt, C.byref(self._astruct), float(sigma), _ptr(V_all), float(trunc_sigmas),
+                                       int(max(rows[0], 0)), int(min(rows[1], self.Ny)), _ptr(out), self.stream()))
         return out
+
+    def density_rows_needed(self):
+        """the grid rows whose density the HJB solves of THIS rank read (simulations.py:432-435 feeds the density of the whole
+        grid to every key's solve): the union of the local row ranges of the keys held here -- every row for a key held whole,
+        nothing for a rank that holds no key (its share of the step needs no density)"""
+        lo, hi = self.Ny, 0
+        for key in range(self.n_keys):
+            if not self.holds_key(key):
+                continue
+            rc = self._key_rows(key)
+            if rc is None:
+                return (0, self.Ny)
+            sh = rc.shard
+            lo, hi = min(lo, int(sh.row0)), max(hi, int(sh.row0) + int(sh.Ny_local))
+        return (lo, hi) if hi > lo else (0, 0)

@@ -422,7 +422,11 @@ class simulation:
 
     # ------------------------------------------------------------------ density (reference simulations.py:453-487)
     def _density_dev(self, sigma):
-        return self._engine.density(sigma, self._V_all_dev)
+        # (sharded: only the rows this rank's solves read -- the agents are replicated, each rank splats into its own row
+        # block without communication)
+        eng = self._engine
+        rows = eng.density_rows_needed() if getattr(eng, "key_plan", None) else None
+        return eng.density(sigma, self._V_all_dev, rows=rows)
 
     def _density_of(self, x, y, status, sigma):
         eng = self._engine

@@ -56,6 +56,9 @@ def _launcherless_bench(workload, extra=()):
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
            "--workload", workload, "--no-cpu-baseline", *extra]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    if out.returncode != 0:                 # (the whole stderr of every rank, for the record: the assertion shows its tail)
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        open(os.path.join(REPO, "gpurun_out", "bench_contract_failure_%s.log" % workload), "w").write(out.stderr)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -81,6 +84,9 @@ def _torchrun_bench(workload, extra=(), env_extra=None):
            "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
            "--workload", workload, "--no-cpu-baseline", *extra]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    if out.returncode != 0:                 # (the whole stderr of every rank, for the record: the assertion shows its tail)
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        open(os.path.join(REPO, "gpurun_out", "bench_contract_failure_%s.log" % workload), "w").write(out.stderr)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

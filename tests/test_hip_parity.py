@@ -239,6 +239,13 @@ def test_density_matches_oracle():
     assert np.abs(got - want).max() <= 2e-7 * want.max()
     got8 = eng.density(0.5, Vt, trunc_sigmas=9.0).cpu().numpy()
     assert np.abs(got8 - want).max() <= 1e-12 * want.max()
+    # a rank's row block only (oc_density_rows; SURVEY 8e: "each GPU splats into its own row block -- no communication"): the
+    # same values on those rows, nothing written elsewhere -- rows that cut through output tiles and agent cells
+    for lo, hi in ((0, 17), (23, 101), (90, got.shape[0])):
+        part = eng.density(0.5, Vt, trunc_sigmas=6.0, rows=(lo, hi)).cpu().numpy()
+        # (the output tiles are anchored at the block's first row, so a cell sums a slightly different set of far agents:
+        #  the same truncation bound, not the same bits)
+        assert np.abs(part[lo:hi] - want[lo:hi]).max() <= 2e-7 * want.max() and not part[:lo].any() and not part[hi:].any()
     eng.close()
 
 

@@ -49,7 +49,7 @@ def _density_like(Ny, Nx, seed=3):
     return m
 
 
-def _solve_virtual_ranks(setup, dtype, world, halo, T, nt, keep, m):
+def _solve_virtual_ranks(setup, dtype, world, halo, T, nt, keep, m, tuning=None, ring=False):
     """world threads, one engine each; returns per-rank (shard, stats, vx, vy, phi_keep) with tensors on the host."""
     import torch
     from optimal_crowds_amd import parallel
@@ -60,6 +60,8 @@ def _solve_virtual_ranks(setup, dtype, world, halo, T, nt, keep, m):
     def work(rank):
         try:
             eng = _new_engine(cfg, room, Nx, Ny, X0, Y0, V, dtype)
+            for name, value in (tuning or {}).items():
+                eng.set_tuning(name, value)
             sh = parallel.RowShard(Ny, rank, world, halo)
             comm = parallel.ThreadHaloComm(sh, Nx, eng.tdtype, eng.device, tw)
             tw.barrier.wait(timeout=120)                          # every comm registered
@@ -141,6 +143,43 @@ def test_row_block_solve_matches_single_solve(room_name, world, halo, dtype):
             assert np.abs(a - b).max() <= 1e-7
         else:
             assert (np.abs(a - b) > 1e-4).mean() <= 1e-3
+
+
+@pytest.mark.parametrize("room_name,gs,world,halo,dtype,with_m", [
+    ("gold_a", 0.05, 2, 8, "float64", False), ("gold_b", 0.05, 3, 9, "float64", True),
+    ("gold_a", 0.05, 2, 8, "float32", False), ("metro_station", 0.1, 4, 8, "float32", False),
+])
+def test_row_block_solve_with_the_active_set(room_name, gs, world, halo, dtype, with_m):
+    """Row blocks WITH the exact active set (round 4; oc_set_tuning "hjb_active" = 2 forces it at any grid size): every rank
+    keeps its own flags and work list, the tile rows whose region reaches into the rows a neighbour sends are always listed
+    (activity arrives there from outside), the far field's max |y| enters the rank's own reduction -- against the same
+    row-block solve with every tile computed ("hjb_active" = 0): the SAME attempts, steps, phi and direction field on every
+    owned cell, bit for bit (a trivial tile's outputs are exactly what computing it gives), and against the whole-grid solve
+    to the tolerances of the dense row-block test.  metro_station 2048 x 2048 on 4 ranks is BASELINE configs[3]'s grid."""
+    import torch
+    setup = _setup(room_name, gs)
+    cfg, room, Nx, Ny, X0, Y0, V = setup
+    T, nt = (3.0, 150) if gs < 0.1 else (2.0, 100)
+    keep = [1, nt // 3, nt - 1]
+    m = _density_like(Ny, Nx) if with_m else None
+    dense = _solve_virtual_ranks(setup, dtype, world, halo, T, nt, keep, m, tuning={"hjb_active": 0})
+    act = _solve_virtual_ranks(setup, dtype, world, halo, T, nt, keep, m, tuning={"hjb_active": 2})
+    for (sh, st, vx, vy, phi), (sh0, st0, vx0, vy0, phi0) in zip(act, dense):
+        for k in ("nfev", "n_attempt", "n_accept", "n_rescale", "final_exponent", "h_abs0", "h_min", "h_max"):
+            assert st[k] == st0[k], (k, st[k], st0[k])
+        assert st["n_exchange"] == st0["n_exchange"] and st["n_allgather"] == st0["n_allgather"]
+        o = slice(sh.own_lo, sh.own_hi)
+        assert np.array_equal(phi[:, o], phi0[:, o])
+        assert np.array_equal(vx[:, o], vx0[:, o]) and np.array_equal(vy[:, o], vy0[:, o])
+    # ... and the whole-grid solve
+    ref = _new_engine(*setup, dtype)
+    ref.alloc_field(0, nt - 1)
+    st1, phi1 = ref.solve(0, T, nt, m=None if m is None else torch.as_tensor(m), keep=keep)
+    phi1 = phi1.cpu().numpy()
+    ref.close()
+    assert act[0][1]["n_attempt"] == st1["n_attempt"] and act[0][1]["n_accept"] == st1["n_accept"]
+    phi = _assemble(act, Ny, 4)
+    assert np.allclose(phi, phi1, rtol=1e-9 if dtype == "float64" else 2e-5, atol=0)
 
 
 def test_row_block_t20_range_management():
