@@ -362,6 +362,8 @@ def main():
                          "all-reduce per step; strong scaling) -- auto picks it for metro_station / open_room; ensemble = "
                          "one independent simulation per GPU (aggregate replica throughput, weak scaling)")
     ap.add_argument("--no-ensemble-line", action="store_true", help="sharded mode: do not also measure the ensemble")
+    ap.add_argument("--no-rows-variant", action="store_true",
+                    help="sharded mode with at least two ranks per key: do not also measure the keys x row-blocks variant")
     ap.add_argument("--no-dense-line", action="store_true",
                     help="do not also run the HJB solves with every tile computed (profiling passes: keeps the kernel "
                          "averages to the product path)")
@@ -673,6 +675,30 @@ def main():
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(sim, cfg, args.workload, state0,
                                               budget_s=float(os.environ.get("OC_BENCH_CPU_BUDGET", "25")))
+    if sharded and world >= 2 * keys_n and keys_n >= 2 and not args.no_rows_variant:
+        # BASELINE configs[3] as SURVEY 8e writes it -- "2 targets on 4 GPUs = 2 keys x 2-way row split": the keys-first plan
+        # above keeps a 2048 x 2048 key whole (a sparse solve is a chain of short launches: splitting it adds two collectives per
+        # attempt and wins nothing), so the row-split variant is measured beside it, on the same ranks, for the record
+        eng.close()
+        del sim, eng
+        torch.cuda.empty_cache()
+        simr, _ = build_sim(args.workload, wall_search_radius=args.wall_radius, sharding=parallel.dist_sharding(min_cells=1),
+                            dtype=args.hjb_dtype, field=args.field)
+        elr, str_, _ = measure(simr, args, nt, world, dist, red_dev)
+        engr = simr._engine
+        rowc = [c for c in getattr(engr, "_halo_comms", {}).values() if c is not None and c.shard.world > 1]
+        miner = [s_ for rnd in str_ for s_ in rnd if s_ is not None]
+        result["rows_variant"] = {
+            "what": "the same run with every key's grid split into row blocks over its rank group (OC_ROW_MIN_CELLS = 1): one "
+                    "16-byte all-gather and one neighbour halo exchange per RK attempt, the exact active set per rank",
+            "value": K / elr, "unit": "steps/s", "ms_per_step": 1e3 * elr / K,
+            "hjb_key_plan": [list(p) for p in getattr(engr, "key_plan", [])],
+            "hjb_solve_s_total_this_rank": sum(s_["seconds"] for s_ in miner),
+            "hjb_halo_message_bytes": (rowc[0].halo_bytes if rowc and hasattr(rowc[0], "halo_bytes") else 0),
+            "hjb_halo_exchanges_this_rank": sum(c.n_exchange for c in rowc),
+            "hjb_allgathers_this_rank": sum(c.n_allgather for c in rowc),
+            "hjb_collectives_per_attempt": {"allgather_16B_per_rank": 1, "neighbour_halo_exchange": 1} if rowc else {}}
+        sim, eng = simr, engr
     if sharded and not args.no_ensemble_line:
         # the other way to use N GPUs, measured right after: one independent replica per GPU (no data-path collective)
         eng.close()

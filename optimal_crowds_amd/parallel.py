@@ -60,9 +60,11 @@ def key_row_plan(n_keys, world, ncell=None, min_cells=None):
     groups get one more): 2 keys on 4 GPUs = 2 groups of 2.  world < n_keys: key k goes whole to rank k % world.
     ncell (cells of one key's grid): a group only uses as many of its ranks as leave every row block at least
     `min_cells` cells (default ROW_MIN_CELLS, or the environment's OC_ROW_MIN_CELLS) -- "only where grid / agent counts make
-    it natural": on one MI355X a 2048^2 solve is ~100 launches of 25 us on a few dozen CUs, splitting it only adds two
+    it natural": on one MI355X a 2048^2 solve is ~100 launches of 18 us on a few dozen CUs, splitting it only adds two
     collectives per attempt, so C4's keys stay whole at any N (ranks without a key still take their share of the step) and
-    C5's 4096^2 grid goes 4-way.  ncell=None: every rank of a group gets a block."""
+    C5's 4096^2 grid goes 4-way.  (A row-block solve keeps the exact active set per rank since round 4; `bench.py --gpus N`
+    measures the row-split variant of a multi-key workload beside the keys-first line.)  ncell=None: every rank of a group gets
+    a block."""
     if world >= n_keys:
         base, rem = divmod(world, n_keys)
         plan, r0 = [], 0

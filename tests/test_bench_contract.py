@@ -71,7 +71,7 @@ def test_bench_two_ranks_without_a_launcher():
     assert d["rccl"]["ranks"] == 2 and d["rccl"]["hjb_key_plan"] == [[0], [1]]
 
 
-def _torchrun_bench(workload, extra=(), env_extra=None):
+def _torchrun_bench(workload, extra=(), env_extra=None, nproc=2):
     """the driver's N > 1 command (one rank per GPU) rehearsed on this one-GPU box: both ranks on cuda:0, collectives
     over gloo (OC_BENCH_ONE_DEVICE=1) -- the same bench.py code path, communicators and library calls as over RCCL"""
     import socket
@@ -80,8 +80,8 @@ def _torchrun_bench(workload, extra=(), env_extra=None):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, OC_BENCH_ONE_DEVICE="1", **(env_extra or {}))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(nproc), "--steps", "20", "--warmup", "5",
            "--workload", workload, "--no-cpu-baseline", *extra]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     if out.returncode != 0:                 # (the whole stderr of every rank, for the record: the assertion shows its tail)
@@ -108,6 +108,18 @@ def test_bench_two_ranks_sharded_keys_first():
     assert d["breakdown"]["hjb_solves_this_rank"] == 1
     e = d["ensemble"]
     assert e["scaling"] == "weak" and e["value"] > 0
+
+
+def test_bench_four_ranks_keys_first_with_the_rows_variant_beside_it():
+    """BASELINE configs[3]'s shape -- 2 keys on 4 ranks -- on a small room (4 processes on this one GPU): the line is the
+    keys-first plan (each key whole on the first rank of its group), and `rows_variant` is SURVEY 8e's "2 keys x 2-way row
+    split" measured on the same ranks: its plan, its halo message, its collectives per attempt."""
+    d = _torchrun_bench("exit_opposite", ("--mode", "sharded", "--no-ensemble-line"), nproc=4)
+    assert d["n_gpus"] == 4 and d["rccl"]["hjb_key_plan"] == [[0], [2]] and d["value"] > 0
+    v = d["rows_variant"]
+    assert v["hjb_key_plan"] == [[0, 1], [2, 3]] and v["value"] > 0
+    assert v["hjb_halo_message_bytes"] == 2 * 8 * 512 * 4 and v["hjb_halo_exchanges_this_rank"] >= 100
+    assert v["hjb_collectives_per_attempt"] == {"allgather_16B_per_rank": 1, "neighbour_halo_exchange": 1}
 
 
 def test_bench_two_ranks_sharded_row_blocks():
