@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OC_ABI_VERSION 2
+#define OC_ABI_VERSION 3
 
 typedef enum { OC_OK = 0, OC_ERR_ARG = -1, OC_ERR_HIP = -2, OC_ERR_STATE = -3, OC_ERR_SOLVER = -4, OC_ERR_CAPACITY = -5 } oc_status;
 typedef enum { OC_F32 = 0, OC_F64 = 1, OC_F64_F32 = 2 } oc_dtype;
@@ -79,6 +79,8 @@ typedef struct oc_hjb_stats {
      * 3 given up at a barrier deadline (grid not co-resident); the chain continues from the controller's state either way */
     int32_t persist_attempts, persist_blocks, persist_exit;
     int32_t grid_resyncs;         /* sparse attempts whose launch was too small for the work list (drained and re-enqueued) */
+    int32_t lead_attempts;        /* attempts launched with the leading controller (oc_set_tuning "hjb_lead") */
+    int32_t reserved_;
 } oc_hjb_stats;
 
 /* Replaces compute_optimal_velocity's solve_ivp(RK45, t_eval=linspace(T,0,nt)) + vels() fill loop,
@@ -382,6 +384,11 @@ int oc_set_hjb_variant(oc_handle* h, int variant);
  *                  controller and list builder (one launch per attempt instead of three); 0 = always separate launches;
  *                  2 = the fused launch at any number of blocks (two-level tickets; measured slower when every tile is
  *                  computed, kept for that comparison).  Same decisions, same results either way.
+ *   "hjb_lead"     sparse ring solves (exact active set, far-field substitution): 1 = an attempt's step controller runs at the
+ *                  START of the next attempt's launch, redundantly in every block, from the listed tiles' records -- no
+ *                  ticket, no last block; the block at list position 0 writes the controller block, the ring's records and
+ *                  the mailbox.  0 (default): measured equal to the fused tail at C4 (1.88 against 1.85 ms per solve).  Same
+ *                  decisions, same results either way.
  *   "hjb_subst"    ring solves with the exact active set: 1 (default) = the state buffers do not maintain the cells of trivial
  *                  tiles -- a load of such a cell yields the far-field value the tile stands for -- so a change of scale
  *                  does not put every tile on the work list to rewrite the far field; 0 = every buffer holds every tile.

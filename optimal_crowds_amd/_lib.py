@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OC_HIP_LIB") or os.path.join(HERE, "liboc_hip.so")     # (OC_HIP_LIB: A/B builds, tools/)
 CSRC = os.path.join(HERE, "csrc")
 
-OC_ABI_VERSION = 2       # include/oc_hip.h: bumped whenever a signature or a struct of the C-ABI changes
+OC_ABI_VERSION = 3       # include/oc_hip.h: bumped whenever a signature or a struct of the C-ABI changes
 OC_F32, OC_F64, OC_F64_F32 = 0, 1, 2
 # opt-in corrections of reference quirks (oc_hip.h: oc_set_fix_flags); 'horizon' (Q9) is host logic in the facade
 FIX_BITS = {"lookup": 1, "wall_force": 2, "pair_force": 4, "density_norm": 8}
@@ -40,6 +40,7 @@ class OcHjbStats(C.Structure):
         ("final_exponent", C.c_int32), ("n_slices_written", C.c_int32),
         ("seconds", C.c_double),
         ("persist_attempts", C.c_int32), ("persist_blocks", C.c_int32), ("persist_exit", C.c_int32), ("grid_resyncs", C.c_int32),
+        ("lead_attempts", C.c_int32), ("reserved_", C.c_int32),
     ]
 
     def as_dict(self):

@@ -403,6 +403,7 @@ struct CtlLds {
     int fast_total;                     // fast tail: length of the list fast_list built
     double rec_s[TAIL_FAST_MAX], rec_m[TAIL_FAST_MAX];      // fast tail: the attempt's records
     int32_t rec_tile[TAIL_FAST_MAX], rec_flag[TAIL_FAST_MAX];
+    int32_t slot_cnt[256];              // fast tail: records per worker slot (tile mod 256)
 };
 
 // The next attempt's work list from the attempt's records, by ONE wavefront (called beside the controller's serial part): the
@@ -527,6 +528,15 @@ __device__ __forceinline__ double wave_tree_sum(double v) {
     return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
+// max over the 64 lanes of a wavefront (non-negative values; exact in any association): the same four DPP steps
+__device__ __forceinline__ double wave_tree_max(double v) {
+    v = fmax(v, dpp_partner(v, 0));
+    v = fmax(v, dpp_partner(v, 1));
+    v = fmax(v, dpp_partner(v, 2));
+    v = fmax(v, dpp_partner(v, 3));
+    return fmax(fmax(lane_value(v, 0), lane_value(v, 16)), fmax(lane_value(v, 32), lane_value(v, 48)));
+}
+
 template <typename T, bool SC1, typename HOOK = NoHook, int UNR = 4>
 __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_in, HjbCtl<T>* __restrict__ ctl_out,
                                              const double* parts, int nparts, double* __restrict__ t_steps, int t_cap,
@@ -534,7 +544,10 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
                                              int active_set, OcRingSlot<T>* __restrict__ rslots,
                                              OcRingSlice<T>* __restrict__ rslices, int ring_cap, CtlLds<T>& L,
                                              bool store_out = true, bool ctl_loaded = false, HOOK beside = HOOK(),
-                                             const double* recs = nullptr, int nrec = 0) {
+                                             const double* recs = nullptr, int nrec = 0, bool fx = true, bool recs_loaded = false,
+                                             double rs_in = 0.0, double rm_in = 0.0, long long rtb_in = 0) {
+    // fx = false (LEAD kernels, every block but the leader): the decision is formed for this block's own use -- nothing is
+    // written to memory (step log, ring records, attempt log, mailbox); recs_loaded: the caller fetched this thread's record
     // What lies between the attempt's last block and the next attempt's first load is a chain of dependent steps, so the
     // controller is laid out for LATENCY: everything that can be known before the decision is fetched or formed before it or
     // beside it, and thread 0's serial float64 part is the decision alone --
@@ -556,6 +569,10 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
         L.m_bits = 0ull;
         L.na_cnt = 0;
     }
+    if (nrec > 0 && worker) {
+        L.slot_cnt[threadIdx.x] = 0;
+        L.red_s[threadIdx.x] = 0.0;
+    }
     constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
     static_assert(sizeof(HjbCtl<T>) % 4 == 0, "controller block must be a whole number of words");
     if (worker && !ctl_loaded) {        // (the fused tail finds it in LDS already: copied when the block started)
@@ -567,15 +584,16 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
     const double tab = (int)threadIdx.x < 43 ? ctl_table_value((int)threadIdx.x, tab_valid) : 0.0;
     // the attempt's error sums (issued together with the block's load; unused if the solve is over)
     double s = 0.0, m = 0.0, na = 0.0;
-    double rs = 0.0, rm = 0.0;
-    long long rtb = 0;
-    if (nrec > 0 && (int)threadIdx.x < nrec) {
+    double rs = rs_in, rm = rm_in;
+    long long rtb = rtb_in;
+    if (!recs_loaded && nrec > 0 && (int)threadIdx.x < nrec) {
         const double* r = recs + 4 * threadIdx.x;
         rs = ld_part<true>(r);
         rm = ld_part<true>(r + 1);
         rtb = __hip_atomic_load(reinterpret_cast<const long long*>(r + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();                    // (the controller block and the words above are in LDS)
+    CB_STAMP(5);
     // what wavefront 1 needs of the controller block for the accepted step's bookkeeping, read while nobody writes the block
     const bool spec_wave = ((int)threadIdx.x >> 6) == 1;
     double z_t = 0.0, z_tnew = 0.0, z_hh = 0.0, z_unscale = 0.0;
@@ -591,24 +609,38 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
     }
     if (nrec > 0) {
         // fast tail: the listed tiles' records (CtlLds) -- every other tile's share is (0, 0), which the full reduction adds
-        // without changing a bit; thread t takes the records of the tiles = t mod 256 in list (= ascending tile) order
+        // without changing a bit.  Worker slot t of the full reduction adds the shares of the tiles = t mod 256 in ascending
+        // order from 0.0: with ONE listed tile in the slot (the rule: the list is a few dozen neighbouring tiles) that is the
+        // tile's share itself, written by the record's thread; a slot with several is summed in list (= ascending tile) order
+        // by the thread of the first of them.  Max and count by the LDS atomics below, exact in any order.  (A loop of every
+        // worker over every record -- dependent LDS reads -- was 2.4 of the tail's 7.7 us.)
+        const int my_slot = (int)(rtb & (long long)(nth - 1));
         if ((int)threadIdx.x < nrec) {
             L.rec_s[threadIdx.x] = rs;
             L.rec_m[threadIdx.x] = rm;
             L.rec_tile[threadIdx.x] = (int32_t)(rtb & 0xFFFFFFFFll);
             L.rec_flag[threadIdx.x] = (int32_t)(rtb >> 32);
+            atomicAdd(&L.slot_cnt[my_slot], 1);
         }
         __syncthreads();
-        if (worker) {
-            for (int e = 0; e < nrec; ++e) {
-                if ((L.rec_tile[e] & (nth - 1)) == (int)threadIdx.x) {
-                    const double vs = L.rec_s[e];
-                    s += vs;
-                    m = fmax(m, L.rec_m[e]);
-                    na += vs > 0.0 ? 1.0 : 0.0;
+        CB_STAMP(6);
+        if ((int)threadIdx.x < nrec) {
+            if (L.slot_cnt[my_slot] == 1) {
+                L.red_s[my_slot] = rs;
+            } else {
+                bool first = true;
+                double acc = 0.0;
+                for (int e = 0; e < nrec; ++e) {
+                    if ((L.rec_tile[e] & (nth - 1)) == my_slot) {
+                        if (e < (int)threadIdx.x) first = false;
+                        acc += L.rec_s[e];
+                    }
                 }
+                if (first) L.red_s[my_slot] = acc;
             }
         }
+        // (max |y_new| and the count of tiles with an error share: formed by wavefront 0 from the records below -- as LDS
+        // atomics of every record's thread on one word each they were 1.5 us)
     } else if (worker) {
         for (int i0 = threadIdx.x; i0 < nparts; i0 += UNR * nth) {
             double2 v[UNR];
@@ -626,8 +658,9 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
             }
         }
     }
+    CB_STAMP(7);
     if (worker) {
-        L.red_s[threadIdx.x] = s;
+        if (nrec == 0) L.red_s[threadIdx.x] = s;
         if (m > 0.0) atomicMax(&L.m_bits, (unsigned long long)__double_as_longlong(m));     // (non-negative doubles order like their bits)
         if (na > 0.0) atomicAdd(&L.na_cnt, (int)na);
     }
@@ -637,16 +670,27 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
     if (threadIdx.x < 64) {
         const int l = (int)threadIdx.x;
         const double esum = wave_tree_sum(((L.red_s[l] + L.red_s[l + 64]) + L.red_s[l + 128]) + L.red_s[l + 192]);
+        double rec_max = 0.0;
+        int rec_cnt = 0;
+        if (nrec > 0) {
+            static_assert(TAIL_FAST_MAX <= 128, "two records per lane");
+            const bool h0 = l < nrec, h1 = l + 64 < nrec;
+            const double m0 = h0 ? L.rec_m[l] : 0.0, m1 = h1 ? L.rec_m[l + 64] : 0.0;
+            double mm = fmax(m0, m1);
+            mm = mm > 0.0 ? mm : 0.0;                   // (a NaN never enters the maximum: as `if (m > 0) atomicMax`)
+            rec_max = wave_tree_max(mm);
+            rec_cnt = __popcll(__ballot(h0 && L.rec_s[l] > 0.0)) + __popcll(__ballot(h1 && L.rec_s[l + 64] > 0.0));
+        }
         if (threadIdx.x == 0) {
             if (c.done) {                               // an attempt enqueued past the end of the solve
                 c.accepted = 0;
                 c.do_scale = 0;
                 L.logw = 0;
             } else {
-                double ymax = __longlong_as_double((long long)L.m_bits);
+                double ymax = nrec > 0 ? rec_max : __longlong_as_double((long long)L.m_bits);
                 // (active set: tiles off the work list took no part in the launch -- their share is 0 and the far field's u)
                 if (active_set == 1 && c.work_count < nparts) ymax = fmax(ymax, fabs((double)c.u_bg * (double)c.in_scale));
-                const double nact = (double)L.na_cnt;
+                const double nact = nrec > 0 ? (double)rec_cnt : (double)L.na_cnt;
                 c.act_sum += nact;
                 // (active_set = 2: a row-block solve -- the pairs are the RANKS'; whether this rank's tiles are all active was
                 // left by k_reduce_local)
@@ -725,8 +769,8 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
             L.spec_n_hx = n_hx;
             L.spec_unscale = z_unscale;
             L.spec_lim_s = z_lim_s;
-            if (z_ntsteps < t_cap) t_steps[z_ntsteps] = z_tnew;
-            if (rslots != nullptr && slot < ring_cap) {     // what the step's dense output is made of stays in this slot
+            if (fx && z_ntsteps < t_cap) t_steps[z_ntsteps] = z_tnew;
+            if (fx && rslots != nullptr && slot < ring_cap) {     // what the step's dense output is made of stays in this slot
                 OcRingSlot<T> rs_;
                 rs_.out_t = z_t;
                 rs_.out_hh = z_hh;
@@ -756,7 +800,7 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
 #pragma unroll
                 for (int pp = 0; pp < 4; ++pp) c.hx[q][pp] = hq[pp];
             }
-            if (rslices != nullptr && k >= 1 && slot < ring_cap) {
+            if (fx && rslices != nullptr && k >= 1 && slot < ring_cap) {
                 OcRingSlice<T> e;
                 e.slot = slot;
                 e.pad = 0;
@@ -782,8 +826,8 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
             L.logw |= L.spec_nv << 8;
         }
         const int tk = ++c.ticks;
-        if (tk - 1 < log_cap) att_log[tk - 1] = L.logw;
-        if (mailbox) mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
+        if (fx && tk - 1 < log_cap) att_log[tk - 1] = L.logw;
+        if (fx && mailbox) mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
     }
     if (!c.done && (int)threadIdx.x < 43) ctl_set_entry(c, (int)threadIdx.x, tab_valid ? (T)(tab * c.hh) : (T)0);
     __syncthreads();
@@ -1222,9 +1266,10 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
     // fused tail, short lists: 4 doubles per list position (error share, max |y_new|, tile | flag << 32, spare) written by the
     // block that takes the position (TAIL_REC_CAP of them), or NULL
     double* tail_rec;
+    int32_t p_prev_lead;            // LEAD: the launch of the attempt before this one was a LEAD launch too (else that attempt ended with a tail or k_control)
 };
 #ifdef OC_DIAG_BUILD
-#define P_STAMP(k) do { if (PERSIST && A.p_stamps != nullptr && threadIdx.x == 0) p_st[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define P_STAMP(k) do { if ((PERSIST || LEAD) && A.p_stamps != nullptr && threadIdx.x == 0) p_st[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define P_STAMP(k) do { } while (0)
 #endif
@@ -1338,11 +1383,32 @@ __device__ __forceinline__ double ld_fresh(const double* p) {
 // instead of hanging, and the host goes on with the launch chain from the controller's last state.
 // (The persistent variant gets twice the registers -- ONE block per CU: with the attempt and item loops around it the tile
 // code spilled 155 vector registers at 64; a sparse attempt lists fewer tiles than the chip has CUs anyway.)
-template <typename T, int NQ, int S0, bool FINAL, int RWV, int RH, bool RING = false, bool FUSED = false, bool PERSIST = false>
+// LEAD (FUSED ring kernels, oc_set_tuning "hjb_tail" = 3): the attempt's controller runs at the START of the NEXT attempt's
+// launch, by every block for itself, instead of in the last block of its own launch.  While the work list is short (what the
+// fast tail covers: lead_ok) an attempt's blocks only leave their records; the next launch's blocks each read the previous
+// controller block and those records (one batch of loads), form the decision, the next list and their own coefficients
+// redundantly -- same inputs, same arithmetic, same bits in every block -- and go on to their tile; the block at list
+// position 0 (the leader) alone writes the new controller block, the ring's records, the logs and the mailbox.  Gone from an
+// attempt's chain: the ticket round trip, the last block's fetch of the records behind it, the controller block's trip to
+// memory and back.  Attempts that do not qualify (the solve's first builds, lists beyond TAIL_FAST_MAX, dense mode) keep the
+// fused tail; which of the two an attempt used is a function of ITS controller block, so the next launch knows where to look.
+template <typename T>
+__device__ __forceinline__ bool lead_ok(const HjbCtl<T>& c, const Stage3Args<T>& A, int ntiles) {
+    // (work_count < ntiles: a list that is not every tile cannot come out "all active" -- the decision's order for the list
+    // builder is then "build" or, at the end of the solve, nothing: what the records alone can serve)
+    return A.active_set != 0 && A.undef != nullptr && A.tail_rec != nullptr && c.done == 0 && c.dense_mode == 0 &&
+           c.n_attempt >= 2 && c.work_count <= TAIL_FAST_MAX && c.work_count < ntiles;
+}
+
+template <typename T, int NQ, int S0, bool FINAL, int RWV, int RH, bool RING = false, bool FUSED = false, bool PERSIST = false,
+          bool LEAD = false>
 __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST ? 2 : 1)) k_stageV(Stage3Args<T> A) {      // float: 64 VGPRs, two blocks per CU
     static_assert(!RING || (NQ == 6 && FINAL), "the ring is written by the one-launch attempt");
     static_assert(!FUSED || RING, "the fused tail belongs to the ring path");
     static_assert(!PERSIST || FUSED, "the persistent launch is the fused-tail launch in a loop");
+    static_assert(!LEAD || (FUSED && !PERSIST), "the leading controller belongs to the one-attempt fused launch");
+    constexpr bool ROT = PERSIST || LEAD;           // the per-attempt pointers rotate in the kernel; the controller block is used out of LDS
+    __shared__ HjbCtl<T> s_prev;                    // LEAD: the previous attempt's controller block
     __shared__ int s_last;
     __shared__ CtlLds<T> s_tail;        // FUSED: the controller's LDS block (unreferenced, hence absent, otherwise)
     __shared__ int32_t s_wsum[16];      // FUSED: the list builder's wavefront sums
@@ -1353,24 +1419,26 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
     __shared__ alignas(16) T buf[2][RH + 2][LS];    // slot of region cell (r, c): [r + 1][c + 4]; one spare ring
     constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4), CW = (NW32 + 255) / 256;
     __shared__ T s_p[6][3];             // PERSIST: the dense output's P columns (kernel arguments: 18 scalar registers held
-    if (PERSIST && threadIdx.x < 18)    // across the attempt and item loops otherwise; the first barrier below publishes them)
+    if (ROT && threadIdx.x < 18)        // across the attempt and item loops otherwise; the first barrier below publishes them)
         s_p[threadIdx.x / 3][threadIdx.x % 3] = A.p[threadIdx.x / 3][threadIdx.x % 3];
 #ifdef OC_DIAG_BUILD
     unsigned long long p_st[6] = {0, 0, 0, 0, 0, 0};
 #endif
-  for (int att = PERSIST ? A.p_a0 : 0;; ++att) {    // (PERSIST: the attempts of this launch; otherwise ONE pass)
+  for (int att = ROT ? A.p_a0 : 0;; ++att) {        // (PERSIST: the attempts of this launch; otherwise ONE pass -- LEAD: attempt p_a0)
     if (PERSIST && att >= A.p_amax) return;
     P_STAMP(0);
     // the attempt's controller block, flags, work list (PERSIST: rotated here as hjb_solve_dev rotates them between launches)
-    const HjbCtl<T>* __restrict__ ctl = PERSIST ? A.p_ctl[att & 1] : A.ctl;
-    HjbCtl<T>* const ctl_out = PERSIST ? A.p_ctl[(att + 1) & 1] : A.ctl_out;
+    const HjbCtl<T>* __restrict__ ctl = ROT ? A.p_ctl[att & 1] : A.ctl;
+    HjbCtl<T>* const ctl_out = ROT ? A.p_ctl[(att + 1) & 1] : A.ctl_out;
     const int nb_all = ((A.Nx + TX - 1) / TX) * ((A.Ny + TY - 1) / TY);
-    const bool p_act = PERSIST && A.active_set != 0;
-    const int32_t* const flags_prev = PERSIST ? (p_act && att > 0 ? A.p_flags + (size_t)((att - 1) & 1) * nb_all : nullptr) : A.flags_prev;
-    int32_t* const flags_cur = PERSIST ? (p_act ? A.p_flags + (size_t)(att & 1) * nb_all : nullptr) : A.flags_cur;
-    const int32_t* const work = PERSIST ? (p_act && att > 0 ? A.p_flags + (size_t)(2 + (att & 1)) * nb_all : nullptr) : A.work;
-    int32_t* const flags_next = PERSIST ? (p_act ? A.p_flags + (size_t)((att + 1) & 1) * nb_all : nullptr) : A.flags_next;
-    int32_t* const work_next = PERSIST ? (p_act ? A.p_flags + (size_t)(2 + ((att + 1) & 1)) * nb_all : nullptr) : A.work_next;
+    const bool p_act = ROT && A.active_set != 0;
+    const int32_t* const flags_prev = ROT ? (p_act && att > 0 ? A.p_flags + (size_t)((att - 1) & 1) * nb_all : nullptr) : A.flags_prev;
+    int32_t* const flags_cur = ROT ? (p_act ? A.p_flags + (size_t)(att & 1) * nb_all : nullptr) : A.flags_cur;
+    const int32_t* const work = ROT ? (p_act && att > 0 ? A.p_flags + (size_t)(2 + (att & 1)) * nb_all : nullptr) : A.work;
+    int32_t* const flags_next = ROT ? (p_act ? A.p_flags + (size_t)((att + 1) & 1) * nb_all : nullptr) : A.flags_next;
+    int32_t* const work_next = ROT ? (p_act ? A.p_flags + (size_t)(2 + ((att + 1) & 1)) * nb_all : nullptr) : A.work_next;
+    // the records of an attempt's listed tiles (fused tail's short-list path; LEAD: read by the NEXT launch, hence by parity)
+    double* const rec_mine = A.tail_rec != nullptr ? A.tail_rec + (ROT ? (size_t)(att & 1) * 4 * TAIL_REC_CAP : 0) : nullptr;
     // Everything the launch reads of the controller block (264 contiguous bytes, fresh in every attempt: the first wavefront
     // of a CU misses the scalar cache on each of its lines) is loaded in ONE batch up front, together with this block's entry
     // of the work list: left to itself the compiler issues these loads where the values are first used, behind the early
@@ -1388,7 +1456,148 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
     int c_done, par, c_dense, c_wcount, c_nacc, c_rej, w_entry, c_ticks = 0;
     T c_oiscale, c_ubg, atol_s, in_scale;
     T cc[NQ][6], he[7];
-    if (PERSIST) {
+    bool lead_has_tail = true;                      // LEAD: does THIS attempt end with the fused tail (else its records wait for the next launch)
+    if constexpr (LEAD) {
+        // ---- both controller blocks, the previous attempt's records and (for the case that it had a tail) this block's
+        // entry of the work list: ONE batch of loads
+        const int L = att;
+        const HjbCtl<T>* const prevp = A.p_ctl[(L + 1) & 1];        // S(L-1): what attempt L-1 ran with
+        uint32_t wa[CW], wb[CW];
+        if (threadIdx.x < 256) {
+            const uint32_t* sa = reinterpret_cast<const uint32_t*>(prevp);
+            const uint32_t* sb = reinterpret_cast<const uint32_t*>(ctl);
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                const bool inr = (int)threadIdx.x + 256 * q < NW32;
+                wa[q] = inr ? sa[threadIdx.x + 256 * q] : 0u;
+                wb[q] = inr ? sb[threadIdx.x + 256 * q] : 0u;
+            }
+        }
+        double rs = 0.0, rm = 0.0;
+        long long rtb = 0, rtag = -1;
+        if (A.tail_rec != nullptr && (int)threadIdx.x < TAIL_FAST_MAX) {
+            const double* r = A.tail_rec + (size_t)((L + 1) & 1) * 4 * TAIL_REC_CAP + 4 * threadIdx.x;
+            // (tile | flag and the tag first, the sums behind them: the writer stores in the opposite order, all four words lie in
+            // one 32-byte sector -- a record whose tag is the attempt's is whole)
+            rtb = __hip_atomic_load(reinterpret_cast<const long long*>(r + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rtag = __hip_atomic_load(reinterpret_cast<const long long*>(r + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rs = ld_part<true>(r);
+            rm = ld_part<true>(r + 1);
+        }
+        const int w_spec = listed ? work[min(logical, nb - 1)] : 0;
+        if (threadIdx.x < 256) {
+            uint32_t* da = reinterpret_cast<uint32_t*>(&s_prev);
+            uint32_t* db = reinterpret_cast<uint32_t*>(&s_tail.c);
+#pragma unroll
+            for (int q = 0; q < CW; ++q)
+                if ((int)threadIdx.x + 256 * q < NW32) {        // (S(L-1) in both: the rule is that the decision is formed here)
+                    da[threadIdx.x + 256 * q] = wa[q];
+                    db[threadIdx.x + 256 * q] = wa[q];
+                }
+        }
+        __syncthreads();
+        P_STAMP(1);
+        const bool had_tail = L == 0 || A.p_prev_lead == 0 || !lead_ok(s_prev, A, nb);       // (a function of S(L-1) alone: every block agrees)
+        auto not_mine = [&]() {                     // a controller block / records that are not this launch's: see att_expected
+            if (threadIdx.x == 0) {
+                atomicAdd(A.tail_counter + TAIL_COUNTER_BYTES / 4 + 5, 1);
+                A.mailbox[2] = (double)(L + 1);
+            }
+        };
+        if (had_tail) {
+            if (L > 0 && uni(s_prev.done) != 0) {
+                // the solve is over, found by the previous launch's blocks (its leader wrote the final block where this launch
+                // finds its "previous" one): the leader copies it into the other block -- the launches enqueued past the end
+                // alternate between the two, and the host reads the one of the attempt it enqueued last
+                if (logical == 0 && threadIdx.x < 256) {
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(const_cast<HjbCtl<T>*>(ctl));
+#pragma unroll
+                    for (int q = 0; q < CW; ++q)
+                        if ((int)threadIdx.x + 256 * q < NW32) dst[threadIdx.x + 256 * q] = wa[q];
+                }
+                return;
+            }
+            __syncthreads();
+            if (threadIdx.x < 256) {                // the attempt's own block, left by the previous attempt's tail
+                uint32_t* db = reinterpret_cast<uint32_t*>(&s_tail.c);
+#pragma unroll
+                for (int q = 0; q < CW; ++q)
+                    if ((int)threadIdx.x + 256 * q < NW32) db[threadIdx.x + 256 * q] = wb[q];
+            }
+            __syncthreads();
+            if (uni(s_tail.c.ticks) != L) {
+                not_mine();
+                return;
+            }
+            w_entry = w_spec;
+        } else {
+            if (uni(s_prev.ticks) != L - 1) {
+                not_mine();
+                return;
+            }
+            const int nrec = min(uni(s_prev.work_count), nb);
+            // every record must be attempt L-1's (a launch that overtook its predecessor would find older ones)
+            if (__syncthreads_or(((int)threadIdx.x < nrec && rtag != (long long)(L - 1)) ? 1 : 0)) {
+                not_mine();
+                return;
+            }
+            const bool leader = logical == 0;
+            uint32_t* const lbits = reinterpret_cast<uint32_t*>(&buf[1][0][0]);
+            int32_t* const llist = reinterpret_cast<int32_t*>(&buf[0][0][0]);       // (the tile buffers are free until the tile starts)
+            static_assert(sizeof(buf) / 2 >= 4 * 9 * TAIL_FAST_MAX, "the next list (at most nine tiles per computed tile) fits a tile buffer");
+            auto beside = [&]() {
+                if (((int)threadIdx.x >> 6) == 2)
+                    fast_list(s_tail.rec_tile, s_tail.rec_flag, nrec, nbx, nby, lbits, llist, &s_tail.fast_total, (int)threadIdx.x & 63);
+            };
+            control_body<T, true>(prevp, const_cast<HjbCtl<T>*>(ctl), A.partial, nb, A.t_steps, A.t_cap, A.att_log, A.log_cap, nullptr, A.active_set,
+                                  A.rslots, A.rslices, A.ring_cap, s_tail, false, true, beside, nullptr, nrec, leader, true, rs, rm, rtb);
+            // (S(L) is in s_tail.c now; the list of attempt L in llist, fast_total long)
+            P_STAMP(2);
+            if (threadIdx.x == 0 && s_tail.c.list_todo == 1) s_tail.c.work_count = s_tail.fast_total;
+            __syncthreads();
+            if (leader) {
+                // the leader alone leaves S(L) in memory (the next launch's "previous" block), the list (for a launch that
+                // falls back to the tail's slow builder) and the host's mailbox
+                if (threadIdx.x < 256) {
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_tail.c);
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(const_cast<HjbCtl<T>*>(ctl));
+                    for (int i = threadIdx.x; i < NW32; i += 256) dst[i] = src[i];
+                }
+                if (s_tail.c.list_todo == 1 && work != nullptr) {
+                    int32_t* wg = const_cast<int32_t*>(work);
+                    for (int i = threadIdx.x; i < s_tail.fast_total; i += NT) wg[i] = llist[i];
+                }
+                if (threadIdx.x == 0) {
+                    const HjbCtl<T>& c = s_tail.c;
+                    if ((c.ticks & 3) == 0 || c.done || c.dense_mode || c.work_count > TAIL_FLAT_MAX) {
+                        A.mailbox[1] = c.dense_mode ? (double)nb + 0.5 : (double)c.work_count;
+                        A.mailbox[0] = (double)c.ticks + (c.done ? 4294967296.0 : 0.0);
+                    }
+                }
+            }
+            if (s_tail.c.list_todo != 1) {
+                // the solve is over (or the rule says "every tile from now on", which a short list cannot bring about): nothing
+                // to compute here.  (done: the next launch's leader copies the block into the other one as well.)
+                if (s_tail.c.done == 0 && threadIdx.x == 0 && leader) A.mailbox[2] = (double)(L + 1);
+                return;
+            }
+            w_entry = logical < s_tail.fast_total ? llist[min(logical, (int)(sizeof(buf) / 8) - 1)] : 0;
+            w_entry = uni(w_entry);
+            __syncthreads();                        // (llist / lbits are the tile buffers)
+        }
+        const HjbCtl<T>& lc = s_tail.c;
+        c_done = uni(lc.done); par = uni(lc.parity); c_dense = uni(lc.dense_mode); c_wcount = uni(lc.work_count);
+        c_nacc = uni(lc.n_accept); c_rej = uni(lc.rejected); c_ticks = L;
+        c_oiscale = uni(lc.out_in_scale); c_ubg = uni(lc.u_bg); atol_s = uni(lc.atol_s); in_scale = uni(lc.in_scale);
+        lead_has_tail = !lead_ok(lc, A, nb);
+        P_STAMP(3);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) cc[q][j] = (T)0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) he[j] = (T)0;
+    } else if (PERSIST) {
         // every block copies the attempt's controller block into LDS -- sc1 loads: the previous attempt's tail, on another CU,
         // wrote it a moment ago -- together with its first entry of the work list; the fields then come out of LDS into scalar
         // registers (a plain load here could be taken for invariant across the attempts, a scalar load could hit a stale line)
@@ -1465,7 +1674,7 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
         // say so in the mailbox; the launches enqueued behind it find a controller block that is not theirs (ticks !=
         // att_expected) and do nothing either; the host drains the stream and goes on from the controller's state with a
         // grid that fits (hjb_solve_dev).  (Never seen in practice: the list grows by a tile every few attempts.)
-        if (A.att_expected >= 0 && c_ticks != A.att_expected) {
+        if (!LEAD && A.att_expected >= 0 && c_ticks != A.att_expected) {
             // Not this launch's controller block: either the launches before it did nothing (a grid too small, below), or --
             // seen where TWO PROCESSES share one GPU (the N = 2 rehearsal on a one-GPU box), never otherwise -- this launch's
             // blocks started before the previous launch's last block had written the block (an sc1 load finds the old words
@@ -1534,13 +1743,13 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
     // below, behind the tile's own loads (store_ctl_words) -- stored on the spot, the first four wavefronts of every block sat
     // out a round trip to the L2 before they issued anything else.
     uint32_t cw[CW];
-    if (FUSED && !PERSIST && threadIdx.x < 256) {
+    if (FUSED && !ROT && threadIdx.x < 256) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
 #pragma unroll
         for (int q = 0; q < CW; ++q) cw[q] = ((int)threadIdx.x + 256 * q < NW32) ? src[threadIdx.x + 256 * q] : 0u;
     }
     auto store_ctl_words = [&]() {
-        if (FUSED && !PERSIST && threadIdx.x < 256) {
+        if (FUSED && !ROT && threadIdx.x < 256) {
             uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tail.c);
 #pragma unroll
             for (int q = 0; q < CW; ++q)
@@ -1585,7 +1794,7 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
             } else if (pre_ok && s_tail.c.dense_mode == 0) lpre = list_prepare(nbx, nby, sflag, s_wsum);
         };
         control_body<T, true>(ctl, ctl_out, A.partial, nb, A.t_steps, A.t_cap, A.att_log, A.log_cap, nullptr, A.active_set,
-                              A.rslots, A.rslices, A.ring_cap, s_tail, false, true, beside, A.tail_rec, nrec);
+                              A.rslots, A.rslices, A.ring_cap, s_tail, false, true, beside, rec_mine, nrec);
         // (the tile buffers are free: the builder's flag bytes)
         static_assert(sizeof(buf) >= 12000, "the builder's flag bytes fit the tile buffers");
         if (A.active_set) {
@@ -1694,21 +1903,22 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
     };
     // the attempt's coefficients where a stage needs them (PERSIST: out of the block's LDS copy of the controller block)
     auto coef_of = [&](int q, int j) __attribute__((always_inline)) -> T {
-        if constexpr (PERSIST) return uni(q < 3 ? s_tail.c.cA[q][j] : s_tail.c.cB[q - 3][j]);
+        if constexpr (ROT) return uni(q < 3 ? s_tail.c.cA[q][j] : s_tail.c.cB[q - 3][j]);
         else return cc[q][j];
     };
     auto he_of = [&](int j) __attribute__((always_inline)) -> T {
-        if constexpr (PERSIST) return uni(s_tail.c.he[j]);
+        if constexpr (ROT) return uni(s_tail.c.he[j]);
         else return he[j];
     };
     // the tile's record for the fused tail's short-list path (thread 0; e_pos: the tile's position on the work list, or -1)
     auto put_rec = [&](int e_pos, int tile, double es, double ym, int flag) __attribute__((always_inline)) {
-        if (FUSED && A.tail_rec != nullptr && e_pos >= 0 && e_pos < TAIL_REC_CAP) {
-            double* r = A.tail_rec + 4 * e_pos;
+        if (FUSED && rec_mine != nullptr && e_pos >= 0 && e_pos < TAIL_REC_CAP) {
+            double* r = rec_mine + 4 * e_pos;
             __hip_atomic_store(r, es, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(r + 1, ym, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(reinterpret_cast<long long*>(r + 2), (long long)(uint32_t)tile | ((long long)flag << 32),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (LEAD) __hip_atomic_store(reinterpret_cast<long long*>(r + 3), (long long)att, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     // ---- one tile of the attempt (every thread of the block; block-uniform control flow)
@@ -1955,7 +2165,7 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
                 T2 q0 = zero2, q1 = zero2;
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const T pj = PERSIST ? uni(s_p[j][pp]) : A.p[j][pp];
+                    const T pj = ROT ? uni(s_p[j][pp]) : A.p[j][pp];
                     const T2 p2 = {pj, pj};
                     q0 = __builtin_elementwise_fma(kv[rows[j]][0], p2, q0);
                     q1 = __builtin_elementwise_fma(kv[rows[j]][1], p2, q1);
@@ -2026,10 +2236,28 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
         // for its list does nothing and says so: att_expected above)
         const bool from_list = sparse && work != nullptr;
         do_tile(from_list ? w_entry : logical, from_list ? logical : -1);
+        P_STAMP(4);
         if constexpr (FUSED) {
-            __syncthreads();            // (the tail reuses the tile buffers and the reduction's LDS words)
-            fused_tail();
+            if (!LEAD || lead_has_tail) {
+                __syncthreads();        // (the tail reuses the tile buffers and the reduction's LDS words)
+                fused_tail();
+            }
         }
+#ifdef OC_DIAG_BUILD
+        if (LEAD && A.p_stamps != nullptr && threadIdx.x == 0 && logical == 0 && att < 4096) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            p_st[5] = __builtin_amdgcn_s_memrealtime();
+            unsigned long long* o = A.p_stamps + (size_t)att * 16;
+            for (int k = 0; k < 6; ++k) o[k] = p_st[k];
+            o[6] = blockIdx.x;
+            o[7] = (unsigned long long)n_items;
+            for (int k = 0; k < 5; ++k) o[8 + k] = g_cb_stamp[k];
+            o[6] = g_cb_stamp[7];
+            o[13] = g_cb_stamp[5];
+            o[14] = g_cb_stamp[6];
+            o[15] = lead_has_tail ? 3 : 2;
+        }
+#endif
         return;
     } else {
     // PERSIST: this block's items of the attempt -- entries blockIdx.x, blockIdx.x + gridDim.x, ... of the work list, or of
@@ -3117,6 +3345,24 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         if (record) (void)hipEventRecord(e, s);
         return e;
     };
+    // LEAD launches (hjb_lead: k_stageV<.., LEAD>): sparse one-GPU ring solves with the far-field substitution and the tail's
+    // records.  A LEAD launch may follow any other launch (p_prev_lead tells it which kind it follows); an un-fused launch
+    // (a list beyond FUSED_MAX, as far as the host knows) follows a LEAD launch only behind a drain that makes sure the
+    // attempt's controller block is in memory.
+    const bool lead_live = h->hjb_lead != 0 && can_fuse && ring && active_set && SA.undef != nullptr && SA.tail_rec != nullptr;
+    SA.p_ctl[0] = ctlb[0];
+    SA.p_ctl[1] = ctlb[1];
+    SA.p_flags = active_set ? h->hjb_flags : nullptr;
+    int n_lead = 0;
+    SA.p_stamps = nullptr;
+#ifdef OC_DIAG_BUILD
+    const char* lead_stamp_file = lead_live ? getenv("OC_LEAD_STAMPS") : nullptr;
+    if (lead_stamp_file) {
+        OC_HIP_CHECK(hipMalloc((void**)&SA.p_stamps, sizeof(unsigned long long) * 16 * 4096));
+        OC_HIP_CHECK(hipMemsetAsync(SA.p_stamps, 0, sizeof(unsigned long long) * 16 * 4096, s));
+    }
+#endif
+    std::vector<char> att_lead;                     // per attempt enqueued: was it a LEAD launch
     int enq = 0;
     int grid_floor = 8;                             // blocks a sparse attempt's launch has at least (raised when one was too small)
     std::vector<int> ev_attempt;                   // attempt index of every group of 4 events
@@ -3148,7 +3394,18 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         }
         // blocks that will take part, as far as the host knows (the device is a few attempts ahead of what it posted)
         const double seen = active_set ? (enq > 0 ? (double)mb[1] : (double)nb3) : (double)nb3;
-        const bool fused = can_fuse && seen <= FUSED_MAX;
+        bool fused = can_fuse && seen <= FUSED_MAX;
+        const bool prev_lead = enq > 0 && (size_t)(enq - 1) < att_lead.size() && att_lead[enq - 1] != 0;
+        if ((size_t)enq >= att_lead.size()) att_lead.resize((size_t)enq + 1, 0);
+        att_lead[enq] = 0;
+        if (lead_live && !fused && prev_lead) {
+            // the un-fused launches need the attempt's controller block in memory, which a LEAD launch leaves there only where
+            // the attempt before it ended with a tail: drain and look (once per solve, if ever)
+            OC_HIP_CHECK(hipStreamSynchronize(s));
+            HjbCtl<T> cur;
+            OC_HIP_CHECK(hipMemcpy(&cur, ctl_cur, sizeof(cur), hipMemcpyDeviceToHost));
+            if (cur.ticks != enq && cur.done == 0) fused = true;       // (not there: this attempt as a LEAD launch too)
+        }
         if (ring && fused) {
             // a sparse attempt's grid follows the list: the blocks beyond it would be dispatched -- 16 wavefronts and 40 KB of
             // LDS each -- only to return at once (1957 of them per attempt at 2048 x 2048 for ~25 listed tiles).  Any size is
@@ -3158,7 +3415,15 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
                 const int want = std::max((int)(seen * 1.5) + h->hjb_grid_margin, grid_floor);
                 gridf = dim3(std::min(8u * (unsigned)((std::max(want, 8) + 7) / 8), grid3.x));
             }
-            hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true, true>), gridf, dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
+            if (lead_live) {
+                ++n_lead;
+                att_lead[enq] = 1;
+                SA.p_prev_lead = prev_lead ? 1 : 0;
+                SA.p_a0 = enq;
+                hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true, true, false, true>), gridf, dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
+            } else {
+                hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true, true>), gridf, dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
+            }
         } else if (ring) {
             hipLaunchKernelGGL((k_stageV<T, 6, 1, true, OC_ST_RWV, OC_ST_RH, true>), grid3, dim3(OC_ST_RWV * OC_ST_RH), 0, s, SA);
         } else if (fuse == 0) {
@@ -3394,12 +3659,26 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             // the stream drained but the mailbox did not move: mapped memory is not visible -> read the device copy
             OC_HIP_CHECK(hipMemcpy(&hc, ctlb[enq & 1], sizeof(hc), hipMemcpyDeviceToHost));
             done = hc.done != 0;
+            if (!done && lead_live) {       // (the final block is where the launch that found the end left it)
+                OC_HIP_CHECK(hipMemcpy(&hc, ctlb[(enq + 1) & 1], sizeof(hc), hipMemcpyDeviceToHost));
+                done = hc.done != 0;
+            }
         }
     }
     // (the solve's last copies go through ITS stream: hipMemcpy works on the null stream, which serialises with whatever a
     // concurrent solve of another key -- Engine.solve_keys -- has enqueued there)
     OC_HIP_CHECK(hipMemcpyAsync(&hc, ctlb[enq & 1], sizeof(hc), hipMemcpyDeviceToHost, s));   // (what the last controller left)
     OC_HIP_CHECK(hipStreamSynchronize(s));
+    if (lead_live && hc.done == 0) {
+        // LEAD: the launch that found the end wrote the final block in ITS place; the launch behind it copies it into the
+        // other one -- if there was a launch behind it
+        OC_HIP_CHECK(hipMemcpyAsync(&hc, ctlb[(enq + 1) & 1], sizeof(hc), hipMemcpyDeviceToHost, s));
+        OC_HIP_CHECK(hipStreamSynchronize(s));
+        if (hc.done == 0) {
+            oc_set_error("hjb_solve: the solve's final controller block is missing (ticks %d, %d attempts enqueued)", hc.ticks, enq);
+            return OC_ERR_STATE;
+        }
+    }
     if (hc.status != 0) {
         if (hc.status == OC_ERR_SOLVER - 200) {
             oc_set_error("hjb_solve_ring: more than %d accepted steps (t = %g reached): the ring is too small", R.cap, hc.t);
@@ -3426,6 +3705,19 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         }
     }
     const int n_real = hc.n_attempt;
+#ifdef OC_DIAG_BUILD
+    if (lead_stamp_file && SA.p_stamps) {
+        std::vector<unsigned long long> st(16 * 4096);
+        OC_HIP_CHECK(hipMemcpy(st.data(), SA.p_stamps, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(lead_stamp_file, "wb")) {
+            fwrite(st.data(), 8, st.size(), f);
+            fclose(f);
+        }
+        (void)hipFree(SA.p_stamps);
+        SA.p_stamps = nullptr;
+    }
+#endif
+    stats.lead_attempts = n_lead;
     // (the controller's ticks, not the attempts enqueued: with the fused tail an attempt past the end of the solve returns
     // before anything is logged, and its slot holds an older solve's word)
     std::vector<int32_t> log((size_t)std::max(std::min(std::min(enq, (int)hc.ticks), LOG_CAP), 0));

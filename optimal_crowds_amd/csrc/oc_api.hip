@@ -53,7 +53,7 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
         h->axes_linspace = is_linspace(X0_host, cfg->Nx, cfg->room_length) && is_linspace(Y0_host, cfg->Ny, cfg->room_height);
     }
     h->red_blocks = std::max(1024, ((cfg->Nx + 31) / 32) * ((cfg->Ny + 15) / 16));
-    OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * (2 * (size_t)h->red_blocks + 4 * 128)));     // (+ the fused tail's records: hjb.hip TAIL_REC_CAP)
+    OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * (2 * (size_t)h->red_blocks + 2 * 4 * 128)));     // (+ the fused tail's records, of two attempts: hjb.hip TAIL_REC_CAP)
     OC_HIP_CHECK(hipMalloc(&h->red_out, sizeof(double) * 16));
     OC_HIP_CHECK(hipHostMalloc(&h->red_host, sizeof(double) * (2 * OC_MAX_WORLD + 8), hipHostMallocMapped));
     memset(h->red_host, 0, sizeof(double) * (2 * OC_MAX_WORLD + 8));
@@ -321,6 +321,9 @@ extern "C" int oc_set_tuning(oc_handle* h, const char* name, int value) {
     } else if (!strcmp(name, "hjb_tail_fast")) {
         OC_REQUIRE(value >= 0 && value <= 1, "hjb_tail_fast must be 0 or 1");
         h->hjb_tail_fast = value;
+    } else if (!strcmp(name, "hjb_lead")) {
+        OC_REQUIRE(value >= 0 && value <= 1, "hjb_lead must be 0 or 1");
+        h->hjb_lead = value;
     } else if (!strcmp(name, "hjb_persist")) {
         OC_REQUIRE(value >= 0 && value <= 2, "hjb_persist must be 0, 1 or 2");
         h->hjb_persist = value;

@@ -178,6 +178,7 @@ struct oc_handle {
     int hjb_grid_margin = 64;        // ... plus this many (and half as many again): room for the list to grow until the host sees it
     int hjb_active_rows = 1;         // 1: row-block solves use the active set too (per rank; hjb.hip: HjbCtl::band_lo)
     int hjb_grid_fit = 1;            // 1: a sparse attempt's (fused) launch has about as many blocks as the work list has entries
+    int hjb_lead = 0;                // 1: sparse ring solves run an attempt's controller at the START of the next launch, in every block (hjb.hip: LEAD)
     int hjb_tail_fast = 1;           // 1: the fused tail reads short work lists by list position (hjb.hip: TailRec) instead of every tile's words
     int hjb_persist = 1;             // the attempts of a ring solve inside ONE persistent launch (hjb.hip: k_stageV<.., PERSIST>): 0 never,
                                      // 1 grids of a few dozen tiles (where it measures faster), 2 wherever it can run

@@ -28,7 +28,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.oc_abi_version() == 2
+    assert lib.oc_abi_version() == 3
     assert isinstance(lib.oc_last_error(), bytes)
 
 

@@ -352,7 +352,10 @@ def test_persistent_launch_and_fast_tail_make_the_same_decisions(room_name, gs, 
                 "persist": dict(hjb_persist=2, hjb_tail_fast=0), "persist+fast": dict(hjb_persist=2, hjb_tail_fast=1),
                 "deadline": dict(hjb_persist=2, hjb_tail_fast=1, hjb_persist_wait_us=10),
                 # a sparse attempt's launch sized BELOW its work list does nothing; the host drains and re-enqueues (grid_resyncs)
-                "grid too small": dict(hjb_persist=0, hjb_grid_margin=-12), "grid not fitted": dict(hjb_persist=0, hjb_grid_fit=0)}
+                "grid too small": dict(hjb_persist=0, hjb_grid_margin=-12), "grid not fitted": dict(hjb_persist=0, hjb_grid_fit=0),
+                # "hjb_lead" = 1: the controller at the start of the NEXT launch, in every block (k_stageV<.., LEAD>)
+                "lead": dict(hjb_persist=0, hjb_lead=1), "lead, grid too small": dict(hjb_persist=0, hjb_lead=1, hjb_grid_margin=-12),
+                "lead, grid not fitted": dict(hjb_persist=0, hjb_lead=1, hjb_grid_fit=0)}
     for name, knobs in variants.items():
         eng = _engine(setup, "float32", "ring")
         eng.set_tuning("hjb_active", active)
@@ -371,6 +374,9 @@ def test_persistent_launch_and_fast_tail_make_the_same_decisions(room_name, gs, 
     assert res["deadline"][0]["persist_exit"] in (1, 2, 3)
     if room_name == "metro_station":
         assert res["grid too small"][0]["grid_resyncs"] > 0 and res["chain"][0]["grid_resyncs"] == 0
+        assert res["lead, grid too small"][0]["grid_resyncs"] > 0
+    if active:
+        assert res["lead"][0]["lead_attempts"] > 10 and res["chain"][0]["lead_attempts"] == 0
     for name in variants:
         st, phi, look = res[name]
         for k in ("nfev", "n_attempt", "n_accept", "n_rescale", "final_exponent", "h_abs0", "h_min", "h_max"):
