@@ -1270,8 +1270,11 @@ struct Stage3Args {         // arguments of the multi-stage kernel (k_stageV)
 };
 #ifdef OC_DIAG_BUILD
 #define P_STAMP(k) do { if ((PERSIST || LEAD) && A.p_stamps != nullptr && threadIdx.x == 0) p_st[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__shared__ unsigned long long g_tl_stamp[4];        // inside do_tile: loads landed and tested | stages done | stores issued | tile's record out
+#define T_STAMP(k) do { if (threadIdx.x == 0) g_tl_stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define P_STAMP(k) do { } while (0)
+#define T_STAMP(k) do { } while (0)
 #endif
 
 // value of the previous / next lane of the wavefront (DPP wave shifts: no LDS traffic; lane 0 / 63 get 0)
@@ -2050,6 +2053,7 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
         // what k_control's ymax for the tiles off the list and the ring's per-slot `u` assume; a tile that is constant at
         // any other value is simply computed)
         if (need_test) trivial = __syncthreads_and((cell_trivial && is_pow2(u_raw) && u_raw == c_ubg) ? 1 : 0) != 0;
+        T_STAMP(0);
         if (trivial) {
             const T un = u_raw * in_scale;
             const bool can_skip = subst || (own_prev && (c_rej != 0 || (in_scale == (T)1 && c_oiscale == (T)1)));
@@ -2139,6 +2143,7 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
             kv[S0 + q][1] = al[1] * s1 - cf[1] * t[1];
         }
     }
+    T_STAMP(1);
     const bool store = in && ry >= HY && ry < RH - HY && vx >= HX / 4 && vx < RWV - HX / 4;
     double esum = 0.0, ymax = 0.0;
     T ymax_t = (T)0;                    // (the maximum is exact in the state's own type: one conversion per thread)
@@ -2203,6 +2208,7 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
             }
         }
     }
+    T_STAMP(2);
     if (FINAL) {
         // The block's error share and max |y_new|: every thread leaves its pair in the tile buffer the last stage did not
         // use (all reads of it ended before that stage's barrier), ONE wavefront adds them up -- 16 cross-lane float64
@@ -2220,8 +2226,10 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
                 a += v.x;
                 b = fmax(b, v.y);
             }
-            a = wave_sum(a);
-            b = wave_max(b);
+            // (DPP trees in a fixed association: as six __shfl_down steps each -- 24 ds_bpermute round trips -- the pair was
+            // 1 us at the end of every tile, on the attempt's chain)
+            a = wave_tree_sum(a);
+            b = wave_tree_max(b);
             if (threadIdx.x == 0) {
                 st_part(A.partial + 2 * logical, a);
                 st_part(A.partial + 2 * logical + 1, b);
@@ -2229,6 +2237,7 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
             }
         }
     }
+    T_STAMP(3);
     };      // do_tile
     if constexpr (!PERSIST) {
         // this block's item: position `logical` of the work list, or tile `logical` (NO loop over further items here: with a
@@ -2256,6 +2265,15 @@ __global__ void __launch_bounds__(RWV * RH, (sizeof(T) == 4 ? 8 : 4) / (PERSIST 
             o[13] = g_cb_stamp[5];
             o[14] = g_cb_stamp[6];
             o[15] = lead_has_tail ? 3 : 2;
+        }
+        if (LEAD && A.p_stamps != nullptr && threadIdx.x == 0 && logical == n_items / 2 && att < 2048) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            p_st[5] = __builtin_amdgcn_s_memrealtime();
+            unsigned long long* o = A.p_stamps + (size_t)(2048 + att) * 16;
+            for (int k = 0; k < 6; ++k) o[k] = p_st[k];
+            for (int k = 0; k < 4; ++k) o[8 + k] = g_tl_stamp[k];
+            o[7] = (unsigned long long)n_items;
+            o[15] = lead_has_tail ? 5 : 4;
         }
 #endif
         return;

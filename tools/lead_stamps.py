@@ -40,3 +40,12 @@ print("inside the decision, medians (us): loads landed -> controller's first bar
 for q in (5, 30, 60, 90):
     if q < len(rows):
         print("attempt %3d: items %3d  " % (idx[q], rows[q, 7]) + "  ".join("%s %.2f" % (n, v) for n, v in zip(names, d[q])))
+
+# a block in the MIDDLE of the list (a computed tile): entered | prologue done | loads landed, tile tested | six stages | stores issued |
+# reduction + record | stores out
+mid = a[2048:][a[2048:, 15] == 4]
+if len(mid):
+    seq = np.stack([mid[:, 0], mid[:, 3], mid[:, 8], mid[:, 9], mid[:, 10], mid[:, 11], mid[:, 5]], axis=1)
+    dd = np.diff(seq, axis=1) * 0.01
+    print("MIDDLE block of %d attempts, medians (us): prologue %.2f | tile loads + test %.2f | six stages %.2f | outputs formed, stores issued %.2f | "
+          "reduction + record %.2f | stores out %.2f | total %.2f" % ((len(mid),) + tuple(np.median(dd, axis=0)) + (np.median(seq[:, -1] - seq[:, 0]) * 0.01,)))
