@@ -528,6 +528,21 @@ __device__ __forceinline__ double wave_tree_sum(double v) {
     return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
+// err^(-1/5), the step controller's power (scipy rk.py: ERROR_EXPONENT = -1 / (error_estimator_order + 1)), for err in
+// [1e-6, 1e6] -- beyond that range the controller's clamps (factor 10 / 0.2) decide without it.  The hardware's log2 / exp2 in
+// float give a start value (relative error ~2e-7), two Newton steps on y^-5 = x in float64 (e -> 3 e^2) leave ~2 ulp: 30
+// dependent instructions where pow() is 200, on the ONE thread the next attempt's every block waits for.
+__device__ __forceinline__ double inv_fifth_root(double x) {
+    double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)x));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y, y4 = y2 * y2, y5 = y4 * y;
+        const double r = fma(-x, y5, 1.0);
+        y = fma(y * 0.2, r, y);
+    }
+    return y;
+}
+
 // max over the 64 lanes of a wavefront (non-negative values; exact in any association): the same four DPP steps
 __device__ __forceinline__ double wave_tree_max(double v) {
     v = fmax(v, dpp_partner(v, 0));
@@ -704,7 +719,7 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
                     c.status = OC_ERR_SOLVER - 100;     // NaN error norm (state overflow)
                     c.done = 1;
                 } else if (err < 1) {
-                    double factor = (err == 0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+                    double factor = (err < 1e-6) ? 10.0 : fmin(10.0, 0.9 * inv_fifth_root(err));    // (0.9 err^-0.2 > 10 below 5.9e-6)
                     if (c.rejected) factor = fmin(1.0, factor);
                     const double hstep = fabs(c.hh);
                     c.h_abs *= factor;
@@ -739,7 +754,7 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
                     } else if (-(c.t - c.tf) >= 0) c.done = 1; // direction = -1
                     else ctl_prepare_step(c, true);
                 } else {
-                    c.h_abs *= fmax(0.2, 0.9 * pow(err, -0.2));
+                    c.h_abs *= (err > 1e6) ? 0.2 : fmax(0.2, 0.9 * inv_fifth_root(err));           // (0.9 err^-0.2 < 0.2 beyond 1845)
                     c.rejected = 1;
                     ctl_prepare_step(c, false);
                 }
