@@ -841,6 +841,9 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
             L.logw |= L.spec_nv << 8;
         }
         const int tk = ++c.ticks;
+        // the solve is over: its accepted steps into the ring's head (the host wrote the rest of the head before the solve)
+        if (fx && c.done && rslots != nullptr)
+            reinterpret_cast<OcRingHead*>(reinterpret_cast<char*>(rslots) - OC_RING_SLOTS_OFF)->n_slots = c.n_accept;
         if (fx && tk - 1 < log_cap) att_log[tk - 1] = L.logw;
         if (fx && mailbox) mailbox[0] = (double)tk + (c.done ? 4294967296.0 : 0.0);
     }
@@ -959,6 +962,19 @@ __global__ void __launch_bounds__(64) k_init_step(HjbCtl<T>* __restrict__ ctl, d
         uint32_t* dst = reinterpret_cast<uint32_t*>(ctl);
         for (int i = threadIdx.x; i < NW32; i += blockDim.x) dst[i] = src[i];
     }
+}
+
+// A solve's small resets in ONE launch (as hipMemsetAsync calls they were four, which the runtime turned into seven fill
+// kernels, ~2.5 us of stream time each): up to four word ranges, each set to its own value.
+struct WordFills {
+    uint32_t* p[4];
+    int32_t n[4];
+    uint32_t v[4];
+};
+__global__ void __launch_bounds__(256) k_fill_words(WordFills F) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F.n[r]; i += gridDim.x * blockDim.x) F.p[r][i] = F.v[r];
 }
 
 // y1 = y0 + h0 * direction * f0 with h0 on the device (red[8]): the k_lincomb of select_initial_step
@@ -3224,11 +3240,21 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     }
     if (!dev_init) ctl_prepare_attempt(hc, true);
     // (through a pinned staging block: no synchronisation -- the block is rewritten by the next solve at the earliest)
-    if (!h->hjb_ctl_host) OC_HIP_CHECK(hipHostMalloc(&h->hjb_ctl_host, 4096, hipHostMallocDefault));
+    if (!h->hjb_ctl_host) OC_HIP_CHECK(hipHostMalloc(&h->hjb_ctl_host, OC_CTL_HOST_BYTES, hipHostMallocDefault));
     memcpy(h->hjb_ctl_host, &hc, sizeof(hc));
     OC_HIP_CHECK(hipMemcpyAsync(ctl, h->hjb_ctl_host, sizeof(hc), hipMemcpyHostToDevice, s));
-    OC_HIP_CHECK(hipMemsetAsync(ctlb[1], 0xFF, sizeof(hc), s));     // (ticks = -1 until the first attempt's controller has written it)
-    OC_HIP_CHECK(hipMemsetAsync(h->hjb_tail, 0, TAIL_COUNTER_BYTES, s));   // (a solve that failed half-way may have left tickets)
+    WordFills fills;
+    memset(&fills, 0, sizeof(fills));
+    int n_fills = 0;
+    auto add_fill = [&](void* p, size_t bytes, uint32_t v) {
+        fills.p[n_fills] = (uint32_t*)p;
+        fills.n[n_fills] = (int32_t)(bytes / 4);
+        fills.v[n_fills] = v;
+        ++n_fills;
+    };
+    static_assert(sizeof(HjbCtl<T>) % 4 == 0 && TAIL_COUNTER_BYTES % 4 == 0, "word fills");
+    add_fill(ctlb[1], sizeof(hc), 0xFFFFFFFFu);         // (ticks = -1 until the first attempt's controller has written it)
+    add_fill(h->hjb_tail, TAIL_COUNTER_BYTES, 0u);      // (a solve that failed half-way may have left tickets)
     if (dev_init)
         hipLaunchKernelGGL(k_init_step<T>, dim3(1), dim3(64), 0, s, ctl, h->red_out, 1, n_rms, std::fabs(tf - t0));
     volatile double* mb = h->red_host + 2 * OC_MAX_WORLD + 4;      // [0] ticks + 2^32 * done (k_control), [1] listed tiles,
@@ -3277,7 +3303,17 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         SA.ring_slot_elems = R.slot_elems;
         SA.ring_first = R.first;
         // (nothing has been computed yet: the stage launches record each tile's first slot)
-        OC_HIP_CHECK(hipMemsetAsync(R.first, 0x7F, sizeof(int32_t) * (size_t)R.ntile, s));
+        add_fill(R.first, sizeof(int32_t) * (size_t)R.ntile, 0x7F7F7F7Fu);
+        // the ring's head but for the number of accepted steps, which the controller that ends the solve writes (control_body)
+        OcRingHead* const rh0 = (OcRingHead*)((char*)h->hjb_ctl_host + 3072);
+        memset(rh0, 0, sizeof(*rh0));
+        rh0->n_slots = 0;
+        rh0->nt = nt;
+        rh0->cap = R.cap;
+        rh0->nslice = R.nslice;
+        rh0->te_step = hc.te_step;
+        rh0->Tfinal = hc.Tfinal;
+        OC_HIP_CHECK(hipMemcpyAsync(R.head, rh0, sizeof(*rh0), hipMemcpyHostToDevice, s));
         SA.ring_cap = R.cap;
         SA.ring_ntile = R.ntile;
     }
@@ -3333,7 +3369,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     }
     // far-field substitution (Stage3Args::undef): ring solves; every tile of both buffers starts out defined
     SA.undef = (active_set && ring && !sh && h->hjb_subst != 0) ? h->hjb_flags + (size_t)4 * nb3 : nullptr;
-    if (SA.undef) OC_HIP_CHECK(hipMemsetAsync(SA.undef, 0, sizeof(int32_t) * 2 * (size_t)nb3, s));
+    if (SA.undef) add_fill(SA.undef, sizeof(int32_t) * 2 * (size_t)nb3, 0u);
+    hipLaunchKernelGGL(k_fill_words, dim3(8), dim3(256), 0, s, fills);
     // attempt a reads work list a & 1; the builder after it writes list (a + 1) & 1 (a late block of the attempt's own launch
     // must never see the next attempt's list: the fused tail builds it while that launch is still draining)
     auto work_list = [&](int a) -> int32_t* { return active_set ? h->hjb_flags + (2 + (size_t)(a & 1)) * nb3 : nullptr; };
@@ -3700,13 +3737,22 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     }
     // (the solve's last copies go through ITS stream: hipMemcpy works on the null stream, which serialises with whatever a
     // concurrent solve of another key -- Engine.solve_keys -- has enqueued there)
-    OC_HIP_CHECK(hipMemcpyAsync(&hc, ctlb[enq & 1], sizeof(hc), hipMemcpyDeviceToHost, s));   // (what the last controller left)
+    // What the last controller left, the attempt log and the step log in ONE batch into the pinned block, one wait (as three
+    // copies into pageable memory they were three host round trips, ~40 us of a 1.8 ms solve).
+    static_assert(2 * sizeof(HjbCtl<T>) <= 4096, "two controller blocks in the staging block's second page");
+    char* const pin = (char*)h->hjb_ctl_host;
+    const int log_pre = std::min(std::min(enq, LOG_CAP), OC_CTL_HOST_LOG), ts_pre = std::min(T_CAP, OC_CTL_HOST_TS);
+    OC_HIP_CHECK(hipMemcpyAsync(pin + 4096, ctlb[0], sizeof(hc), hipMemcpyDeviceToHost, s));
+    OC_HIP_CHECK(hipMemcpyAsync(pin + 4096 + sizeof(hc), ctlb[1], sizeof(hc), hipMemcpyDeviceToHost, s));
+    if (log_pre > 0) OC_HIP_CHECK(hipMemcpyAsync(pin + 8192, h->hjb_log, sizeof(int32_t) * log_pre, hipMemcpyDeviceToHost, s));
+    if (t_steps && t_steps_cap > 0)
+        OC_HIP_CHECK(hipMemcpyAsync(pin + 8192 + 4 * OC_CTL_HOST_LOG, h->hjb_tsteps, sizeof(double) * ts_pre, hipMemcpyDeviceToHost, s));
     OC_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(&hc, pin + 4096 + (size_t)(enq & 1) * sizeof(hc), sizeof(hc));
     if (lead_live && hc.done == 0) {
         // LEAD: the launch that found the end wrote the final block in ITS place; the launch behind it copies it into the
         // other one -- if there was a launch behind it
-        OC_HIP_CHECK(hipMemcpyAsync(&hc, ctlb[(enq + 1) & 1], sizeof(hc), hipMemcpyDeviceToHost, s));
-        OC_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(&hc, pin + 4096 + (size_t)((enq + 1) & 1) * sizeof(hc), sizeof(hc));
         if (hc.done == 0) {
             oc_set_error("hjb_solve: the solve's final controller block is missing (ticks %d, %d attempts enqueued)", hc.ticks, enq);
             return OC_ERR_STATE;
@@ -3721,16 +3767,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         else oc_set_error("RK45: NaN error norm at t=%g (state overflow?)", hc.t);
         return OC_ERR_SOLVER;
     }
-    OcRingHead rh;
     if (ring) {
-        memset(&rh, 0, sizeof(rh));
-        rh.n_slots = hc.n_accept;
-        rh.nt = nt;
-        rh.cap = R.cap;
-        rh.nslice = R.nslice;
-        rh.te_step = hc.te_step;
-        rh.Tfinal = hc.Tfinal;
-        OC_HIP_CHECK(hipMemcpyAsync(R.head, &rh, sizeof(rh), hipMemcpyHostToDevice, s));     // (rh lives until the sync below)
         if (n_keep > 0) {               // the audit output: phi at the kept t_eval points, from the ring
             int rc2 = ring_emit<T, TO>(h, R, hc.n_accept, 0, nt, nullptr, nullptr, phi_keep, keep_slot_dev, s);
             if (rc2) return rc2;
@@ -3754,9 +3791,12 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // (the controller's ticks, not the attempts enqueued: with the fused tail an attempt past the end of the solve returns
     // before anything is logged, and its slot holds an older solve's word)
     std::vector<int32_t> log((size_t)std::max(std::min(std::min(enq, (int)hc.ticks), LOG_CAP), 0));
-    if (!log.empty())
+    if ((int)log.size() <= log_pre) {
+        if (!log.empty()) memcpy(log.data(), pin + 8192, sizeof(int32_t) * log.size());
+    } else {
         OC_HIP_CHECK(hipMemcpyAsync(log.data(), h->hjb_log, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost, s));
-    OC_HIP_CHECK(hipStreamSynchronize(s));
+        OC_HIP_CHECK(hipStreamSynchronize(s));
+    }
     for (size_t a = 0; a < log.size(); ++a)
         if (log[a] & 2) stats.n_slices_written += log[a] >> 8;
     if (prof_on) {
@@ -3803,7 +3843,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     if (t_steps && t_steps_cap > 0) {
         t_steps[0] = t0;
         const int m = std::min(hc.n_tsteps, t_steps_cap - 1);
-        if (m > 0) OC_HIP_CHECK(hipMemcpy(t_steps + 1, h->hjb_tsteps, sizeof(double) * m, hipMemcpyDeviceToHost));
+        if (m > 0 && m <= ts_pre) memcpy(t_steps + 1, pin + 8192 + 4 * OC_CTL_HOST_LOG, sizeof(double) * m);
+        else if (m > 0) OC_HIP_CHECK(hipMemcpy(t_steps + 1, h->hjb_tsteps, sizeof(double) * m, hipMemcpyDeviceToHost));
     }
     stats.h_abs0 = hc.h_abs0;
     stats.nfev = S.nfev + 6 * n_real;
@@ -4009,7 +4050,7 @@ int hjb_solve_t(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, voi
                     // the fused writer of the default path (k_out), its controller block filled in by the host: the
                     // one-launch-per-stage variant stays bit-identical to the default one
                     if (!h->hjb_ctl) OC_HIP_CHECK(hipMalloc(&h->hjb_ctl, 8192));
-                    if (!h->hjb_ctl_host) OC_HIP_CHECK(hipHostMalloc(&h->hjb_ctl_host, 4096, hipHostMallocDefault));
+                    if (!h->hjb_ctl_host) OC_HIP_CHECK(hipHostMalloc(&h->hjb_ctl_host, OC_CTL_HOST_BYTES, hipHostMallocDefault));
                     HjbCtl<T>& oc = *(HjbCtl<T>*)h->hjb_ctl_host;
                     memset(&oc, 0, sizeof(oc));
                     oc.accepted = 1;

@@ -89,11 +89,12 @@ struct OcRingSlice {
     T h[4];                                 // h x, h x^2, h x^3, h x^4 of the slice's t_eval point in its step
 };
 #define OC_RING_NEVER 0x7F7F7F7F            // first[t] of a tile that was never computed (memset 0x7F)
-inline size_t oc_ring_align(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr size_t oc_ring_align(size_t v) { return (v + 255) & ~(size_t)255; }
+#define OC_RING_SLOTS_OFF oc_ring_align(sizeof(OcRingHead))     // (the slot records follow the head: hjb.hip's controller finds the head from them)
 inline int oc_ring_ntile(int rows, int Nx) {
     return ((Nx + OC_RING_STX - 1) / OC_RING_STX) * ((rows + OC_RING_STY - 1) / OC_RING_STY);
 }
-inline size_t oc_ring_slots_off() { return oc_ring_align(sizeof(OcRingHead)); }
+inline size_t oc_ring_slots_off() { return OC_RING_SLOTS_OFF; }
 inline size_t oc_ring_slices_off(size_t tsize, int slots) {
     return oc_ring_slots_off() + oc_ring_align((tsize == 4 ? sizeof(OcRingSlot<float>) : sizeof(OcRingSlot<double>)) * (size_t)slots);
 }
@@ -167,6 +168,11 @@ struct oc_handle {
     void* red_mailbox_dev = nullptr; // device address of the mailbox
     long long red_seq = 0;
     int32_t red_blocks = 0;
+#define OC_CTL_HOST_LOG 4096        // attempt-log words and ...
+#define OC_CTL_HOST_TS 4096         // ... step-log doubles the pinned block takes at the end of a solve
+#define OC_CTL_HOST_BYTES (8192 + 4 * OC_CTL_HOST_LOG + 8 * OC_CTL_HOST_TS)
+    // pinned staging block: [0, 2048) the controller block going up, [2048, 2056) the persistent launch's sync words,
+    // [3072, 3072 + sizeof(OcRingHead)) the ring's head going up, [4096, 8192) the two controller blocks coming down, then the logs
     void* hjb_ctl_host = nullptr;    // pinned staging copy of the controller block (host-controlled cross-check variants)
     void* hjb_ctl = nullptr;         // device-resident step controller (hjb.hip: HjbCtl), accepted step times, attempt log
     double* hjb_tsteps = nullptr;
