@@ -674,10 +674,15 @@ __device__ __forceinline__ void control_body(const HjbCtl<T>* __restrict__ ctl_i
         }
     }
     CB_STAMP(7);
-    if (worker) {
-        if (nrec == 0) L.red_s[threadIdx.x] = s;
-        if (m > 0.0) atomicMax(&L.m_bits, (unsigned long long)__double_as_longlong(m));     // (non-negative doubles order like their bits)
-        if (na > 0.0) atomicAdd(&L.na_cnt, (int)na);
+    if (worker && nrec == 0) {
+        // (maximum and count: a DPP tree per worker wavefront, then FOUR LDS atomics -- one per worker and word they were
+        // 1.5 us of every tail that sweeps the tiles' partials: small grids, dense attempts, k_control)
+        L.red_s[threadIdx.x] = s;
+        const double wm = wave_tree_max(m), wn = wave_tree_sum(na);         // (m >= 0, never NaN: fmax from 0; na a small integer)
+        if ((threadIdx.x & 63) == 0) {
+            if (wm > 0.0) atomicMax(&L.m_bits, (unsigned long long)__double_as_longlong(wm));   // (non-negative doubles order like their bits)
+            if (wn > 0.0) atomicAdd(&L.na_cnt, (int)wn);
+        }
     }
     CB_STAMP(0);
     __syncthreads();
