@@ -68,6 +68,12 @@ int oc_hjb_make_coef(oc_handle* h, int dtype, const float* V, const void* m, voi
 /* out = hjb(t, phi, m): replaces the closure `hjb` at optimals.py:144-164.  phi/out: dtype (Ny*Nx). */
 int oc_hjb_rhs(oc_handle* h, int dtype, const void* phi, const void* coef, void* out, void* stream);
 
+/* The step controller's power err^(-1/5) (SciPy rk.py: factor = SAFETY * error_norm ** ERROR_EXPONENT, ERROR_EXPONENT = -1/5
+ * for RK45) as the DEVICE controller forms it -- the hardware's float log2 / exp2 and two float64 Newton steps (hjb.hip:
+ * inv_fifth_root) -- for n values x[i] in [1e-6, 1e6] (outside that range the controller's clamps decide without it).
+ * x, out: device pointers to float64.  A test hook: the solve's parity with SciPy rests on this being good to a few ulp. */
+int oc_hjb_ctl_power(oc_handle* h, const double* x, int64_t n, double* out, void* stream);
+
 typedef struct oc_hjb_stats {
     int32_t nfev, n_attempt, n_accept, n_rescale;
     double h_abs0, h_min, h_max;

@@ -104,6 +104,7 @@ SIGNATURES = {
     "oc_destroy": (C.c_int, [C.c_void_p]),
     "oc_hjb_make_coef": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "oc_hjb_rhs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "oc_hjb_ctl_power": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "oc_hjb_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                C.POINTER(OcHjbStats), C.c_void_p]),

@@ -591,7 +591,7 @@ __device__ __forceinline__ void pair_share(const GcfmParams& P, const Scratch& S
     constexpr int NJ = 64 / NS;                   // records of a real tile owned by this share
     constexpr int NW = 2;                         // 32-bit mask words per lane (64 records)
     constexpr int WB = 32;
-    constexpr int NROUND = 2;                     // rounds of 32 records for a dense virtual tile
+    [[maybe_unused]] constexpr int NROUND = 2;                     // rounds of 32 records for a dense virtual tile
     const float b_max = (float)P.b_max, db = (float)(P.b_max - P.b_min);
     const float neg_inv_eta_log2e = (float)(-1.4426950408889634 / P.eta);
     const bool unit_dir = (P.fix & OC_FIX_PAIR_FORCE) != 0;

@@ -4185,6 +4185,17 @@ extern "C" int oc_hjb_make_coef(oc_handle* h, int dtype, const float* V, const v
     return OC_OK;
 }
 
+__global__ void k_ctl_power(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = inv_fifth_root(x[i]);
+}
+extern "C" int oc_hjb_ctl_power(oc_handle* h, const double* x, int64_t n, double* out, void* stream) {
+    OC_REQUIRE(h && x && out && n >= 0, "oc_hjb_ctl_power: bad argument");
+    if (n > 0) hipLaunchKernelGGL(k_ctl_power, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    OC_HIP_CHECK(hipGetLastError());
+    return OC_OK;
+}
+
 extern "C" int oc_hjb_rhs(oc_handle* h, int dtype, const void* phi, const void* coef, void* out, void* stream) {
     OC_REQUIRE(h && phi && coef && out, "null argument");
     OC_HIP_CHECK(hipSetDevice(h->device));

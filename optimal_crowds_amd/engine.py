@@ -438,6 +438,12 @@ class Engine:
         check(self.lib.oc_hjb_rhs(self.h, self.dtype, _ptr(phi), _ptr(coef), _ptr(out), self.stream()))
         return out
 
+    def ctl_power(self, x):
+        """err ** -0.2 as the device step controller forms it (test hook: oc_hjb_ctl_power); x: float64 device tensor"""
+        out = torch.empty_like(x)
+        check(self.lib.oc_hjb_ctl_power(self.h, _ptr(x), x.numel(), _ptr(out), self.stream()))
+        return out
+
     def vels(self, phi64, scale=1.0):
         vx = torch.zeros((self.Ny, self.Nx), dtype=self.field_tdtype, device=self.device)
         vy = torch.zeros_like(vx)

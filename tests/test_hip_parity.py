@@ -26,6 +26,22 @@ def _rects(room, key):
     return np.array([room["targets"][t] for t in key.split(" or ")], dtype=np.float64)
 
 
+def test_step_controller_power_is_good_to_a_few_ulp():
+    """SciPy's step factor is SAFETY * error_norm ** (-1 / 5) (rk.py:12, 155-165).  The device controller forms the power with
+    the hardware's float log2 / exp2 and two float64 Newton steps instead of pow() (hjb.hip: inv_fifth_root): within 3 ulp of
+    the correctly rounded power over the whole range in which the controller's clamps (10 / 0.2) do not decide by themselves."""
+    import torch
+    eng, room, cfg, X0, Y0 = _engine("gold_a", "float32")
+    rng = np.random.default_rng(5)
+    x = np.concatenate([10.0 ** rng.uniform(-6, 6, 200000), np.logspace(-6, 6, 1001), [1.0, 5.9e-6, 1845.3, 0.999999, 1.000001]])
+    got = eng.ctl_power(torch.as_tensor(x).to(eng.device)).cpu().numpy()
+    ref = np.power(x.astype(np.longdouble), np.longdouble(-0.2))
+    ulp = np.abs((got.astype(np.longdouble) - ref) / (np.spacing(ref.astype(np.float64))))
+    assert float(ulp.max()) <= 3.0, float(ulp.max())
+    assert float(np.mean(ulp <= 1.0)) > 0.8          # (measured: 86 % within 1 ulp, all within 3)
+    eng.close()
+
+
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-13), ("float32", 3e-6)])
 def test_rhs_matches_oracle_and_golden(golden, dtype, tol):
     import torch
