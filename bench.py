@@ -430,13 +430,13 @@ def main():
         eng.set_tuning(name, int(val))
     nt = sim._nt0
     K, W = args.steps, args.warmup
-    # the exact active set of the HJB solve (csrc/hjb.hip): on by default from 1024 stage tiles (112 x 20 cells) on, single
+    # the exact active set of the HJB solve (csrc/hjb.hip): on by default from 96 stage tiles (112 x 20 cells) on, single
     # GPU / whole-key solves only; `--tune hjb_active=0` computes every tile of every attempt
     tune_active = [kv.split("=")[1] for kv in args.tune.split(",") if kv.startswith("hjb_active=")]
     active_knob = int(tune_active[-1]) if tune_active else int(os.environ.get("OC_HJB_ACTIVE", "1"))
     n_stage_tiles = -(-sim.Nx // 112) * -(-sim.Ny // 20)
     rows_split = sharded and any(len(p) > 1 for p in getattr(eng, "key_plan", []))
-    active_set = (active_knob == 2 or (active_knob == 1 and n_stage_tiles >= 1024)) and n_stage_tiles <= 12000 and not rows_split
+    active_set = (active_knob == 2 or (active_knob == 1 and n_stage_tiles >= 96)) and n_stage_tiles <= 12000 and not rows_split
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if args.update == "sequential" and (world > 1 or sharded):
         raise SystemExit("--update sequential is a single-GPU mode")

@@ -403,8 +403,8 @@ int oc_set_hjb_variant(oc_handle* h, int variant);
  *                  and coef = 0 -- the far field of a solve with m = 0, where optimals.py:144-164 evaluates to exactly 0
  *                  -- are not computed; every slice of the direction field is still written, and fields, step sequence
  *                  and statistics are bit-identical to computing every tile.  0 = off, 1 = on for grids of at least
- *                  1024 stage tiles of 112 x 20 cells (default), 2 = on at any size (both: up to 12 000 tiles).  Whole-key solves only
- *                  (oc_hjb_solve_rows always computes every tile). */
+ *                  96 stage tiles of 112 x 20 cells (default), 2 = on at any size (both: up to 12 000 tiles).  Row-block
+ *                  solves (oc_hjb_solve_rows*) use it per rank ("hjb_active_rows", default 1). */
 int oc_set_tuning(oc_handle* h, const char* name, int value);
 
 /* Opt-in corrections of reference quirks (SURVEY.md quirk register, section 8f-4).  Default 0: every entry point is

@@ -3364,7 +3364,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // far-field substitution (what a rank SENDS must be in its buffers).  The size rule looks at the whole grid's tiles.
     const int nb_rule = sh ? ((S.Nx + tx - 1) / tx) * ((sh->Ny_global + ty - 1) / ty) : nb3;
     const bool active_set = fuse == 0 && nb3 <= 12000 && (!sh || h->hjb_active_rows != 0) &&
-                            (h->hjb_active == 2 || (h->hjb_active == 1 && nb_rule >= 1024));
+                            (h->hjb_active == 2 || (h->hjb_active == 1 && nb_rule >= OC_ACTIVE_MIN_TILES));
     if (active_set && h->hjb_flags_n < (size_t)6 * nb3) {     // flags of two attempts + two work lists (alternating) +
         if (h->hjb_flags) OC_HIP_CHECK(hipFree(h->hjb_flags));     // the undefined-tile marks of the two state buffers
         h->hjb_flags = nullptr;

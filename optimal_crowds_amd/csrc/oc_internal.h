@@ -241,7 +241,11 @@ struct oc_handle {
     int hjb_variant = 0;
     int out_tile = -1;              // tile of k_out: -1 = by grid size, 0 = 64 x 16, 1 = 128 x 8, 2 = 256 x 4 cells
     int hjb_fuse = 0;               // stage launches of an RK attempt: 0 = all six stages in one, 1 = 2 x three stages (hjb.hip)
-    int hjb_active = 1;             // exact active set (hjb.hip): 0 off, 1 on for grids of >= 1024 stage tiles, 2 on at any size
+    // exact active set (hjb.hip): 0 off, 1 on for grids of >= OC_ACTIVE_MIN_TILES stage tiles, 2 on at any size.  (The threshold
+    // was 1024 while a sparse attempt cost 22 us; at 15.5 us the list pays from ~100 tiles on: exit_opposite, 130 tiles, 1.76 ->
+    // 1.61 ms per solve, slalom, 520 tiles, 2.82 -> 1.66 ms; room_test's 20 tiles run faster whole, inside the persistent launch.)
+#define OC_ACTIVE_MIN_TILES 96
+    int hjb_active = 1;
     std::map<std::string, oc_timer> timers;
 };
 

@@ -16,7 +16,7 @@ from test_hjb_rows import _density_like, _new_engine, _setup      # noqa: E402
 
 def _solve(eng, T, nt, m, active, keep=None):
     import torch
-    eng.set_tuning("hjb_active", 2 if active else 0)           # 2: at any grid size (1 = only from 1024 stage tiles on)
+    eng.set_tuning("hjb_active", 2 if active else 0)           # 2: at any grid size (1 = only from 96 stage tiles on)
     mt = None if m is None else torch.as_tensor(m)
     st, phi = eng.solve(0, T, nt, m=mt, keep=keep, want_steps=True)
     vx, vy = eng.fields[0][0], eng.fields[0][1]
