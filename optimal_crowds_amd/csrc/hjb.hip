@@ -982,6 +982,134 @@ __global__ void __launch_bounds__(256) k_fill_words(WordFills F) {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F.n[r]; i += gridDim.x * blockDim.x) F.p[r][i] = F.v[r];
 }
 
+// ---- select_initial_step (scipy common.py:68-134) of a whole-grid solve in FOUR launches (round 3: twelve -- fill, rhs, two
+// norms with a reduction each, h0, axpy, rhs, norm, reduction, first step).  Same arithmetic per cell, same element -> thread
+// mapping and the same summation orders as the kernels they replace (k_fill, k_rhs, k_norm_scaled, k_reduce_final, k_axpy_h0,
+// k_init_step): h_abs0 and everything that follows are bit-identical.
+// (1) y0 = 1 (optimals.py:190: phi(T) = 1), f0 = hjb(T, y0) = K0 of the first step, the partials of d0 = |y0 / scale| and
+//     d1 = |f0 / scale| (k_norm_scaled<0>'s grid-stride mapping: the caller launches its grid)
+template <typename T>
+__global__ void __launch_bounds__(256) k_init_a(const T* __restrict__ coef, T* __restrict__ y, T* __restrict__ k0, T a_lap, T atol,
+                                                T rtol, int64_t n, double* __restrict__ partial_y, double* __restrict__ partial_f) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T one = (T)1, cf = coef[i];
+        // (rhs_point on a constant field: the mirror ghosts are the constant too)
+        const T f = (cf != cf) ? (T)0 : rhs_value(one, one, one, one, one, a_lap, cf);
+        y[i] = one;
+        k0[i] = f;
+        const T sc = atol + fabs(one) * rtol;
+        const T v0 = one / sc, v1 = f / sc;
+        s0 += (double)v0 * (double)v0;
+        s1 += (double)v1 * (double)v1;
+    }
+    block_reduce_store(s0, 0.0, partial_y);
+    __syncthreads();                    // (block_reduce_store's LDS words are used again)
+    block_reduce_store(s1, 0.0, partial_f);
+}
+// k_reduce_final's sum of `nblocks` (sum, max) pairs, by a block of 1024 threads; the value is thread 0's
+__device__ __forceinline__ double reduce_final_sum(const double* __restrict__ partial, int nblocks, double* ls /* [16] LDS */) {
+    const double2* __restrict__ p2 = reinterpret_cast<const double2*>(partial);
+    double s = 0.0;
+    const int nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < nblocks; i0 += 4 * nt) {
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i0 + u * nt < nblocks) ? p2[i0 + u * nt] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += v[u].x;
+    }
+    s = wave_sum(s);
+    const int w = threadIdx.x >> 6, nw = (nt + 63) >> 6;
+    __syncthreads();                    // (ls may still be read from a previous call)
+    if ((threadIdx.x & 63) == 0) ls[w] = s;
+    __syncthreads();
+    double a = 0.0;
+    if (threadIdx.x == 0)
+        for (int q = 0; q < nw; ++q) a += ls[q];
+    return a;
+}
+// (2) the two reductions and h0 (k_init_step's phase 0)
+__global__ void __launch_bounds__(1024) k_init_r0(const double* __restrict__ partial_y, const double* __restrict__ partial_f,
+                                                   int nblocks, double* __restrict__ red, double n_rms, double interval) {
+    __shared__ double ls[16];
+    const double sy = reduce_final_sum(partial_y, nblocks, ls);
+    const double sf = reduce_final_sum(partial_f, nblocks, ls);
+    if (threadIdx.x == 0) {
+        red[2] = sy;
+        red[4] = sf;
+        const double d0 = sqrt(sy) / sqrt(n_rms), d1 = sqrt(sf) / sqrt(n_rms);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = fmin(h0, interval);
+        red[8] = h0;
+        red[9] = d1;
+    }
+}
+// (3) y1 = y0 + h0 * direction * f0 (k_axpy_h0), f1 = hjb(y1) (k_rhs), the partials of d2 = |(f1 - f0) / scale|
+//     (k_norm_scaled<1>) -- y1 and f1 are formed in registers and never stored
+template <typename T>
+__global__ void __launch_bounds__(256) k_init_b(const T* __restrict__ coef, const T* __restrict__ y, const T* __restrict__ k0,
+                                                const double* __restrict__ red, double direction, int Ny, int Nx, T a_lap, T atol,
+                                                T rtol, int64_t n, double* __restrict__ partial) {
+    const T cc = (T)(red[8] * direction);
+    auto y1 = [&](int64_t c) -> T { return y[c] + fma_t(cc, k0[c], (T)0); };
+    double s = 0.0;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(c / Nx), j = (int)(c - (int64_t)i * Nx);
+        const T cf = coef[c];
+        T f1 = (T)0;
+        if (!(cf != cf)) {              // (rhs_point)
+            const int iu = (i == 0) ? 1 : i - 1, id = (i == Ny - 1) ? Ny - 2 : i + 1;
+            const int jl = (j == 0) ? 1 : j - 1, jr = (j == Nx - 1) ? Nx - 2 : j + 1;
+            f1 = rhs_value(y1((int64_t)iu * Nx + j), y1((int64_t)id * Nx + j), y1((int64_t)i * Nx + jl), y1((int64_t)i * Nx + jr),
+                           y1(c), a_lap, cf);
+        }
+        const T sc = atol + fabs(y[c]) * rtol;
+        const T v = (f1 - k0[c]) / sc;
+        s += (double)v * (double)v;
+    }
+    block_reduce_store(s, 0.0, partial);
+}
+
+// (4) the third reduction, the first step (k_init_step's phase 1: h_abs and the first attempt's coefficient tables into the
+//     controller block the host uploaded) and the solve's small resets (k_fill_words)
+template <typename T>
+__global__ void __launch_bounds__(1024) k_init_r1(HjbCtl<T>* __restrict__ ctl, const double* __restrict__ partial, int nblocks,
+                                                   double* __restrict__ red, double n_rms, double interval, WordFills F) {
+    __shared__ double ls[16];
+    __shared__ HjbCtl<T> c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        for (int i = threadIdx.x; i < F.n[r]; i += blockDim.x) F.p[r][i] = F.v[r];
+    const double s2 = reduce_final_sum(partial, nblocks, ls);
+    constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&c);
+        for (int i = threadIdx.x; i < NW32; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        red[6] = s2;
+        const double h0 = red[8], d1 = red[9];
+        const double d2 = sqrt(s2) / sqrt(n_rms) / h0;
+        double h1;
+        if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
+        else h1 = pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+        c.h_abs = fmin(fmin(100 * h0, h1), interval);
+        c.h_abs0 = c.h_abs;
+        ctl_prepare_step(c, true);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 43) ctl_prepare_entry(c, (int)threadIdx.x);
+    __syncthreads();
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(ctl);
+        for (int i = threadIdx.x; i < NW32; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
 // y1 = y0 + h0 * direction * f0 with h0 on the device (red[8]): the k_lincomb of select_initial_step
 template <typename T>
 __global__ void k_axpy_h0(const T* __restrict__ base, const T* __restrict__ k, const double* __restrict__ red,
@@ -3165,9 +3293,15 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // buffers: Y[0] = y, Y[1] = y_new; KX[0] = K[0], KX[1] = K[6] (FSAL pair); KM = K1 .. K5
     T* Y[2] = {S.y, S.ynew};
     T* KX[2] = {S.K[0], S.K[6]};
-    hipLaunchKernelGGL(k_fill<T>, S.g1(), dim3(256), 0, s, S.y, (T)1, n);
     const double t0 = Tfinal, tf = 0.0, direction = -1.0;
-    S.rhs(S.y, KX[0]);                  // f0 = K0 of the first step
+    double* const part_b = h->red_partial + 2 * (size_t)h->red_blocks + 2 * 4 * 128;    // (a second set of 1024 pairs: oc_api.hip)
+    if (sh == nullptr) {                // (whole grid: y0, f0 and the first two norms' partials in one launch -- k_init_a)
+        hipLaunchKernelGGL(k_init_a<T>, dim3(RB), dim3(256), 0, s, S.coef, S.y, KX[0], S.a_lap, (T)atol0, (T)rtol, n, h->red_partial, part_b);
+        ++S.nfev;
+    } else {
+        hipLaunchKernelGGL(k_fill<T>, S.g1(), dim3(256), 0, s, S.y, (T)1, n);
+        S.rhs(S.y, KX[0]);              // f0 = K0 of the first step
+    }
     // ---- select_initial_step (scipy common.py:68-134), order = 4: on the device (k_init_step) for a whole-grid solve; a
     // row-block solve completes each norm with the caller's all-gather, read back by the host
     const bool dev_init = sh == nullptr;
@@ -3175,19 +3309,11 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     if (dev_init) {
         const double interval = std::fabs(tf - t0);
         double* red = h->red_out;
-        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, S.y + own_off, (const T*)nullptr,
-                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
-        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, RB, red + 2, (volatile double*)nullptr, 0.0);
-        hipLaunchKernelGGL((k_norm_scaled<T, 0>), dim3(RB), dim3(256), 0, s, KX[0] + own_off, (const T*)nullptr,
-                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
-        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, RB, red + 4, (volatile double*)nullptr, 0.0);
-        hipLaunchKernelGGL(k_init_step<T>, dim3(1), dim3(64), 0, s, (HjbCtl<T>*)nullptr, red, 0, n_rms, interval);
-        hipLaunchKernelGGL(k_axpy_h0<T>, S.g1(), dim3(256), 0, s, S.y, KX[0], (const double*)red, direction, S.ytmp, n);
-        S.rhs(S.ytmp, S.K[1]);
-        hipLaunchKernelGGL((k_norm_scaled<T, 1>), dim3(RB), dim3(256), 0, s, S.K[1] + own_off, KX[0] + own_off,
-                           S.y + own_off, (T)atol0, (T)rtol, n_own, h->red_partial);
-        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, h->red_partial, RB, red + 6, (volatile double*)nullptr, 0.0);
-        // (phase 1 runs once the controller block has been uploaded, below)
+        hipLaunchKernelGGL(k_init_r0, dim3(1), dim3(1024), 0, s, (const double*)h->red_partial, (const double*)part_b, RB, red, n_rms, interval);
+        hipLaunchKernelGGL(k_init_b<T>, dim3(RB), dim3(256), 0, s, S.coef, (const T*)S.y, (const T*)KX[0], (const double*)red, direction, S.Ny, S.Nx,
+                           S.a_lap, (T)atol0, (T)rtol, n, h->red_partial);
+        ++S.nfev;
+        // (k_init_r1 -- the third reduction and the first step -- runs once the controller block has been uploaded, below)
     } else {
         double interval = std::fabs(tf - t0);
         double s0, s1, s2;
@@ -3260,8 +3386,6 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     static_assert(sizeof(HjbCtl<T>) % 4 == 0 && TAIL_COUNTER_BYTES % 4 == 0, "word fills");
     add_fill(ctlb[1], sizeof(hc), 0xFFFFFFFFu);         // (ticks = -1 until the first attempt's controller has written it)
     add_fill(h->hjb_tail, TAIL_COUNTER_BYTES, 0u);      // (a solve that failed half-way may have left tickets)
-    if (dev_init)
-        hipLaunchKernelGGL(k_init_step<T>, dim3(1), dim3(64), 0, s, ctl, h->red_out, 1, n_rms, std::fabs(tf - t0));
     volatile double* mb = h->red_host + 2 * OC_MAX_WORLD + 4;      // [0] ticks + 2^32 * done (k_control), [1] listed tiles,
     mb[0] = 0.0;                                                   // [2] 1 + ticks of an attempt whose launch was too small
     mb[1] = 1e9;
@@ -3375,7 +3499,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     // far-field substitution (Stage3Args::undef): ring solves; every tile of both buffers starts out defined
     SA.undef = (active_set && ring && !sh && h->hjb_subst != 0) ? h->hjb_flags + (size_t)4 * nb3 : nullptr;
     if (SA.undef) add_fill(SA.undef, sizeof(int32_t) * 2 * (size_t)nb3, 0u);
-    hipLaunchKernelGGL(k_fill_words, dim3(8), dim3(256), 0, s, fills);
+    if (dev_init)       // (the resets ride along with the first step)
+        hipLaunchKernelGGL(k_init_r1<T>, dim3(1), dim3(1024), 0, s, ctl, (const double*)h->red_partial, RB, h->red_out, n_rms, std::fabs(tf - t0), fills);
+    else
+        hipLaunchKernelGGL(k_fill_words, dim3(8), dim3(256), 0, s, fills);
     // attempt a reads work list a & 1; the builder after it writes list (a + 1) & 1 (a late block of the attempt's own launch
     // must never see the next attempt's list: the fused tail builds it while that launch is still draining)
     auto work_list = [&](int a) -> int32_t* { return active_set ? h->hjb_flags + (2 + (size_t)(a & 1)) * nb3 : nullptr; };

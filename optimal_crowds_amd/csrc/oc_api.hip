@@ -53,7 +53,7 @@ extern "C" int oc_create(int device, const oc_config* cfg, const double* X0_host
         h->axes_linspace = is_linspace(X0_host, cfg->Nx, cfg->room_length) && is_linspace(Y0_host, cfg->Ny, cfg->room_height);
     }
     h->red_blocks = std::max(1024, ((cfg->Nx + 31) / 32) * ((cfg->Ny + 15) / 16));
-    OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * (2 * (size_t)h->red_blocks + 2 * 4 * 128)));     // (+ the fused tail's records, of two attempts: hjb.hip TAIL_REC_CAP)
+    OC_HIP_CHECK(hipMalloc(&h->red_partial, sizeof(double) * (2 * (size_t)h->red_blocks + 2 * 4 * 128 + 2 * 1024)));     // (+ the fused tail's records, of two attempts: hjb.hip TAIL_REC_CAP; + a second set of partial pairs: k_init_a)
     OC_HIP_CHECK(hipMalloc(&h->red_out, sizeof(double) * 16));
     OC_HIP_CHECK(hipHostMalloc(&h->red_host, sizeof(double) * (2 * OC_MAX_WORLD + 8), hipHostMallocMapped));
     memset(h->red_host, 0, sizeof(double) * (2 * OC_MAX_WORLD + 8));
