@@ -3479,8 +3479,8 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     OA.sty = ty;
     // the exact active set (k_stageV): two flag arrays, one per attempt parity.  Single-GPU, one-launch attempts only: in a
     // row-block solve activity also arrives through the halo exchange, which the tile flags do not see.
-    // Below ~1000 tiles (grids under ~1500 x 1500) the bookkeeping costs more than the skipped tiles save (exit_opposite
-    // 512 x 512, where the front crosses the room: 3.9 against 3.5 ms per solve): hjb_active = 1 switches by size, 2 forces it.
+    // On tiny grids the bookkeeping costs more than the skipped tiles save (room_test, 20 tiles: 6.4 against 5.8 ms per solve; the
+    // threshold was ~1000 tiles while a sparse attempt cost 22 us): hjb_active = 1 switches by size (OC_ACTIVE_MIN_TILES), 2 forces it.
     // Above 12 000 tiles (grids beyond ~5000 x 5000) the list builder's per-thread masks and its LDS copy of the flags no
     // longer cover the grid: every tile is computed.
     // Row blocks (round 4): the same flags and lists per rank, with the tile rows that reach into a neighbour's rows always
@@ -3596,7 +3596,10 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         }
         // blocks that will take part, as far as the host knows (the device is a few attempts ahead of what it posted)
         const double seen = active_set ? (enq > 0 ? (double)mb[1] : (double)nb3) : (double)nb3;
-        bool fused = can_fuse && seen <= FUSED_MAX;
+        // (nothing posted yet -- the attempts enqueued behind the solve's first sweep: the list such a sweep leaves is short as a
+        // rule; fused, on a grid that holds any list -- the tail draws its tickets in two levels if it must)
+        const bool unknown = active_set && enq > 0 && seen >= 1e8;
+        bool fused = can_fuse && (seen <= FUSED_MAX || unknown);
         const bool prev_lead = enq > 0 && (size_t)(enq - 1) < att_lead.size() && att_lead[enq - 1] != 0;
         if ((size_t)enq >= att_lead.size()) att_lead.resize((size_t)enq + 1, 0);
         att_lead[enq] = 0;
@@ -3613,7 +3616,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
             // LDS each -- only to return at once (1957 of them per attempt at 2048 x 2048 for ~25 listed tiles).  Any size is
             // correct (a block takes every gridDim.x-th item); this one leaves room for the list to grow until the host sees it.
             dim3 gridf = grid3;
-            if (active_set && enq > 0 && h->hjb_grid_fit != 0) {
+            if (active_set && enq > 0 && h->hjb_grid_fit != 0 && !unknown) {
                 const int want = std::max((int)(seen * 1.5) + h->hjb_grid_margin, grid_floor);
                 gridf = dim3(std::min(8u * (unsigned)((std::max(want, 8) + 7) / 8), grid3.x));
             }
