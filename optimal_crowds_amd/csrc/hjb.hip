@@ -13,6 +13,8 @@
 #include <cmath>
 #include <chrono>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 namespace {
@@ -4508,11 +4510,37 @@ extern "C" int oc_hjb_solve_ring(oc_handle* h, int dtype, const void* coef, doub
 // nothing of the interpreter lies between the solves' launches (threads started from Python cost 0.3 - 0.7 ms per round of
 // two 2 ms solves: thread start and join, the calls around the solve).  Every job needs its own handle (solver scratch) and
 // stream.  Returns the first job's error code that is not OC_OK (each job's own is in jobs[i].rc, its message in .error).
+// The host threads of oc_hjb_solve_ring_many: started once, kept (a thread started per call cost its creation and its first
+// HIP call's per-thread set-up, ~0.1 ms of a 1.7 ms solve, in every round of solves).  Never destroyed: the threads sleep on
+// their condition variables until the process ends.
+namespace {
+struct SolveWorker {
+    std::mutex m;
+    std::condition_variable cv;
+    oc_hjb_ring_job* job = nullptr;     // set by the caller, cleared by the worker when it is done
+    void (*fn)(oc_hjb_ring_job*) = nullptr;
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return job != nullptr; });
+            oc_hjb_ring_job* j = job;
+            lk.unlock();
+            fn(j);
+            lk.lock();
+            job = nullptr;
+            cv.notify_all();
+        }
+    }
+};
+std::mutex g_workers_m;                  // one oc_hjb_solve_ring_many at a time uses the workers
+std::vector<SolveWorker*>* g_workers = nullptr;
+}
+
 extern "C" int oc_hjb_solve_ring_many(oc_hjb_ring_job* jobs, int32_t n) {
     OC_REQUIRE(jobs != nullptr && n >= 1 && n <= 64, "bad job list");
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j) OC_REQUIRE(jobs[i].h != jobs[j].h, "two jobs on one handle (each needs its own solver scratch)");
-    auto run = [](oc_hjb_ring_job* jb) {
+    void (*run)(oc_hjb_ring_job*) = [](oc_hjb_ring_job* jb) {
         jb->error[0] = 0;
         jb->rc = oc_hjb_make_coef(jb->h, jb->coef_dtype, jb->V, jb->m, jb->coef, jb->stream);
         if (jb->rc == OC_OK)
@@ -4523,11 +4551,28 @@ extern "C" int oc_hjb_solve_ring_many(oc_hjb_ring_job* jobs, int32_t n) {
             jb->error[sizeof(jb->error) - 1] = 0;
         }
     };
-    std::vector<std::thread> th;
-    th.reserve(n > 1 ? n - 1 : 0);
-    for (int i = 1; i < n; ++i) th.emplace_back(run, jobs + i);
-    run(jobs);
-    for (auto& t : th) t.join();
+    {
+        std::lock_guard<std::mutex> pool(g_workers_m);
+        if (!g_workers) g_workers = new std::vector<SolveWorker*>();
+        while ((int)g_workers->size() < n - 1) {
+            SolveWorker* w = new SolveWorker();
+            g_workers->push_back(w);
+            std::thread([w] { w->loop(); }).detach();
+        }
+        for (int i = 1; i < n; ++i) {
+            SolveWorker* w = (*g_workers)[i - 1];
+            std::lock_guard<std::mutex> lk(w->m);
+            w->fn = run;
+            w->job = jobs + i;
+            w->cv.notify_all();
+        }
+        run(jobs);
+        for (int i = 1; i < n; ++i) {
+            SolveWorker* w = (*g_workers)[i - 1];
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [&] { return w->job == nullptr; });
+        }
+    }
     for (int i = 0; i < n; ++i)
         if (jobs[i].rc != OC_OK) {
             oc_set_error("job %d: %s", i, jobs[i].error);
