@@ -1049,12 +1049,13 @@ __global__ void __launch_bounds__(1024) k_init_r0(const double* __restrict__ par
 }
 // (3) y1 = y0 + h0 * direction * f0 (k_axpy_h0), f1 = hjb(y1) (k_rhs), the partials of d2 = |(f1 - f0) / scale|
 //     (k_norm_scaled<1>) -- y1 and f1 are formed in registers and never stored
+//     (y0 is the constant 1 that k_init_a wrote: not read back)
 template <typename T>
-__global__ void __launch_bounds__(256) k_init_b(const T* __restrict__ coef, const T* __restrict__ y, const T* __restrict__ k0,
+__global__ void __launch_bounds__(256) k_init_b(const T* __restrict__ coef, const T* __restrict__ k0,
                                                 const double* __restrict__ red, double direction, int Ny, int Nx, T a_lap, T atol,
                                                 T rtol, int64_t n, double* __restrict__ partial) {
-    const T cc = (T)(red[8] * direction);
-    auto y1 = [&](int64_t c) -> T { return y[c] + fma_t(cc, k0[c], (T)0); };
+    const T cc = (T)(red[8] * direction), one = (T)1;
+    auto y1 = [&](int64_t c) -> T { return one + fma_t(cc, k0[c], (T)0); };
     double s = 0.0;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(c / Nx), j = (int)(c - (int64_t)i * Nx);
@@ -1066,7 +1067,7 @@ __global__ void __launch_bounds__(256) k_init_b(const T* __restrict__ coef, cons
             f1 = rhs_value(y1((int64_t)iu * Nx + j), y1((int64_t)id * Nx + j), y1((int64_t)i * Nx + jl), y1((int64_t)i * Nx + jr),
                            y1(c), a_lap, cf);
         }
-        const T sc = atol + fabs(y[c]) * rtol;
+        const T sc = atol + fabs(one) * rtol;
         const T v = (f1 - k0[c]) / sc;
         s += (double)v * (double)v;
     }
@@ -1075,21 +1076,28 @@ __global__ void __launch_bounds__(256) k_init_b(const T* __restrict__ coef, cons
 
 // (4) the third reduction, the first step (k_init_step's phase 1: h_abs and the first attempt's coefficient tables into the
 //     controller block the host uploaded) and the solve's small resets (k_fill_words)
+//     The controller block and the ring's head arrive as KERNEL ARGUMENTS (as copies from pinned memory they were two blit
+//     launches in the solve's chain).
 template <typename T>
-__global__ void __launch_bounds__(1024) k_init_r1(HjbCtl<T>* __restrict__ ctl, const double* __restrict__ partial, int nblocks,
-                                                   double* __restrict__ red, double n_rms, double interval, WordFills F) {
+struct InitBlocks {
+    HjbCtl<T> ctl;
+    OcRingHead head;
+    OcRingHead* head_dst;       // or NULL
+};
+template <typename T>
+__global__ void __launch_bounds__(1024) k_init_r1(HjbCtl<T>* __restrict__ ctl, const InitBlocks<T> B, const double* __restrict__ partial,
+                                                   int nblocks, double* __restrict__ red, double n_rms, double interval, WordFills F) {
     __shared__ double ls[16];
     __shared__ HjbCtl<T> c;
+    if (threadIdx.x == 0) {
+        c = B.ctl;
+        if (B.head_dst != nullptr) *B.head_dst = B.head;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         for (int i = threadIdx.x; i < F.n[r]; i += blockDim.x) F.p[r][i] = F.v[r];
     const double s2 = reduce_final_sum(partial, nblocks, ls);
     constexpr int NW32 = (int)(sizeof(HjbCtl<T>) / 4);
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&c);
-        for (int i = threadIdx.x; i < NW32; i += blockDim.x) dst[i] = src[i];
-    }
     __syncthreads();
     if (threadIdx.x == 0) {
         red[6] = s2;
@@ -3312,7 +3320,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         const double interval = std::fabs(tf - t0);
         double* red = h->red_out;
         hipLaunchKernelGGL(k_init_r0, dim3(1), dim3(1024), 0, s, (const double*)h->red_partial, (const double*)part_b, RB, red, n_rms, interval);
-        hipLaunchKernelGGL(k_init_b<T>, dim3(RB), dim3(256), 0, s, S.coef, (const T*)S.y, (const T*)KX[0], (const double*)red, direction, S.Ny, S.Nx,
+        hipLaunchKernelGGL(k_init_b<T>, dim3(RB), dim3(256), 0, s, S.coef, (const T*)KX[0], (const double*)red, direction, S.Ny, S.Nx,
                            S.a_lap, (T)atol0, (T)rtol, n, h->red_partial);
         ++S.nfev;
         // (k_init_r1 -- the third reduction and the first step -- runs once the controller block has been uploaded, below)
@@ -3374,8 +3382,13 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     if (!dev_init) ctl_prepare_attempt(hc, true);
     // (through a pinned staging block: no synchronisation -- the block is rewritten by the next solve at the earliest)
     if (!h->hjb_ctl_host) OC_HIP_CHECK(hipHostMalloc(&h->hjb_ctl_host, OC_CTL_HOST_BYTES, hipHostMallocDefault));
-    memcpy(h->hjb_ctl_host, &hc, sizeof(hc));
-    OC_HIP_CHECK(hipMemcpyAsync(ctl, h->hjb_ctl_host, sizeof(hc), hipMemcpyHostToDevice, s));
+    if (!dev_init) {                    // (whole-grid solves: the block goes up as a kernel argument of k_init_r1)
+        memcpy(h->hjb_ctl_host, &hc, sizeof(hc));
+        OC_HIP_CHECK(hipMemcpyAsync(ctl, h->hjb_ctl_host, sizeof(hc), hipMemcpyHostToDevice, s));
+    }
+    InitBlocks<T> init_blocks;
+    memset(&init_blocks, 0, sizeof(init_blocks));
+    init_blocks.ctl = hc;
     WordFills fills;
     memset(&fills, 0, sizeof(fills));
     int n_fills = 0;
@@ -3444,7 +3457,12 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         rh0->nslice = R.nslice;
         rh0->te_step = hc.te_step;
         rh0->Tfinal = hc.Tfinal;
-        OC_HIP_CHECK(hipMemcpyAsync(R.head, rh0, sizeof(*rh0), hipMemcpyHostToDevice, s));
+        if (dev_init) {
+            init_blocks.head = *rh0;
+            init_blocks.head_dst = R.head;
+        } else {
+            OC_HIP_CHECK(hipMemcpyAsync(R.head, rh0, sizeof(*rh0), hipMemcpyHostToDevice, s));
+        }
         SA.ring_cap = R.cap;
         SA.ring_ntile = R.ntile;
     }
@@ -3502,7 +3520,7 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
     SA.undef = (active_set && ring && !sh && h->hjb_subst != 0) ? h->hjb_flags + (size_t)4 * nb3 : nullptr;
     if (SA.undef) add_fill(SA.undef, sizeof(int32_t) * 2 * (size_t)nb3, 0u);
     if (dev_init)       // (the resets ride along with the first step)
-        hipLaunchKernelGGL(k_init_r1<T>, dim3(1), dim3(1024), 0, s, ctl, (const double*)h->red_partial, RB, h->red_out, n_rms, std::fabs(tf - t0), fills);
+        hipLaunchKernelGGL(k_init_r1<T>, dim3(1), dim3(1024), 0, s, ctl, init_blocks, (const double*)h->red_partial, RB, h->red_out, n_rms, std::fabs(tf - t0), fills);
     else
         hipLaunchKernelGGL(k_fill_words, dim3(8), dim3(256), 0, s, fills);
     // attempt a reads work list a & 1; the builder after it writes list (a + 1) & 1 (a late block of the attempt's own launch
@@ -3601,7 +3619,9 @@ int hjb_solve_dev(oc_handle* h, const void* coef_v, double Tfinal, int32_t nt, v
         // (nothing posted yet -- the attempts enqueued behind the solve's first sweep: the list such a sweep leaves is short as a
         // rule; fused, on a grid that holds any list -- the tail draws its tickets in two levels if it must)
         const bool unknown = active_set && enq > 0 && seen >= 1e8;
-        bool fused = can_fuse && (seen <= FUSED_MAX || unknown);
+        // (the FIRST attempt of an active-set solve sweeps every tile and needs the list built behind it: the two-level fused
+        // tail costs less than the two launches -- k_control and the list builder's own -- it replaces)
+        bool fused = can_fuse && (seen <= FUSED_MAX || unknown || (active_set && enq == 0));
         const bool prev_lead = enq > 0 && (size_t)(enq - 1) < att_lead.size() && att_lead[enq - 1] != 0;
         if ((size_t)enq >= att_lead.size()) att_lead.resize((size_t)enq + 1, 0);
         att_lead[enq] = 0;
