@@ -26,6 +26,8 @@ import copy
 import hashlib
 import json
 import os
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # (kernel arguments in device memory: optimal_crowds_amd/__init__.py)
 import sys
 import time
 
